@@ -1,0 +1,228 @@
+"""CPU: the oracle (oracle/dmlnet_ref.py) against the golden vectors minted from the real reference.
+
+These are the pins of SURVEY.md §8(c) G1-G8.  Tolerances: the oracle ran bit-identical to the
+reference in the authoring container; 1e-5 relative leaves room for a different CPU / thread count.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers as H
+from oracle import dmlnet_ref as O
+
+T = torch.from_numpy
+
+
+def close(a, b, rtol=1e-5):
+    assert H.max_abs(a, b) <= rtol * (1.0 + float(b.abs().max())), (H.max_abs(a, b), float(b.abs().max()))
+
+
+def test_g1_distance_head():
+    g = H.load_golden("g1_distance_head")
+    lg, ctr, ft = O.distance_head(T(g["x"]))
+    close(lg, T(g["logits"]))
+    assert torch.equal(ft, T(g["features"]))
+    assert torch.equal(ctr, T(g["centers"]))
+    assert torch.equal(lg.argmax(1), T(g["argmax"]))
+    close(O.distance_head(T(g["x"]), T(g["protos"]))[0], T(g["logits_general"]))
+    # F5: with 3*I prototypes the logit has the closed form -|f|^2 + 6 f_k - 9
+    f = T(g["features"])
+    closed = (-(f ** 2).sum(-1, keepdim=True) + 6 * f - 9).permute(0, 3, 1, 2)
+    close(closed, T(g["logits"]), 1e-5)
+
+
+def test_g2_losses():
+    g = H.load_golden("g2_losses")
+    lo = T(g["logit"]).requires_grad_(True)
+    loss = O.dml_loss(lo, T(g["label"]), alpha=0.01, ignore_index=-1)
+    loss.backward()
+    close(loss, T(g["loss"]), 1e-6)
+    close(lo.grad, T(g["grad"]), 1e-6)
+    close(O.dml_loss_loop(lo.detach(), T(g["label"])), T(g["loss"]), 1e-6)
+    close(O.pixel_acc(lo.detach(), T(g["label"])), T(g["acc"]), 1e-6)
+    lo2 = T(g["logit2"]).requires_grad_(True)
+    l2 = O.ce_over_n(lo2, T(g["label2"]), 255)
+    l2.backward()
+    close(l2, T(g["loss2"]), 1e-6)
+    close(lo2.grad, T(g["grad2"]), 1e-6)
+
+
+def _head(seed=3):
+    head = O._Head(16, (6, 12, 18))
+    shapes = OrderedDict(("classifier." + k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd = H.synth_state_dict(shapes, seed=seed)
+    head.load_state_dict(OrderedDict((k[len("classifier."):], v) for k, v in sd.items()))
+    head.train()
+    head.aspp.project[3].eval()
+    return head
+
+
+def test_g3_head():
+    g = H.load_golden("g3_head")
+    head = _head()
+    low = H.synth_tensor(3, "g3.low", (2, 256, 16, 16)).requires_grad_(True)
+    out = H.synth_tensor(3, "g3.out", (2, 2048, 4, 4)).requires_grad_(True)
+    wgt = H.synth_tensor(3, "g3.wgt", (2, 16, 16, 16))
+    y = head({"low_level": low, "out": out})
+    (y * wgt).sum().backward()
+    close(y, T(g["y"]))
+    close(low.grad, T(g["dlow"]))
+    close(out.grad, T(g["dout"]))
+    pg = dict((k, p.grad) for k, p in head.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    for n, cs in zip(names, g["grad_checksums"]):
+        assert np.allclose(H.checksum(pg[n]), cs, rtol=1e-4, atol=1e-6), n
+    close(pg["classifier.3.weight"], T(g["grad__classifier_3_weight"]), 1e-4)
+    close(pg["aspp.convs.2.0.weight"][::8, ::64], T(g["grad_sample__aspp_convs_2_0_weight"]), 1e-4)
+    bufs = dict(head.named_buffers())
+    close(bufs["project.1.running_var"], T(g["rv_project"]))
+    close(bufs["aspp.convs.4.2.running_mean"], T(g["rm_pool"]))
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("s1", dict(inplanes=64, planes=16, stride=1, dilation=1, downsample=False)),
+    ("s2", dict(inplanes=32, planes=16, stride=2, dilation=1, downsample=True)),
+    ("d2", dict(inplanes=64, planes=16, stride=1, dilation=2, downsample=False)),
+])
+def test_g4_bottleneck(name, cfg):
+    g = H.load_golden("g4_bottleneck")
+    blk = O._Bottleneck(cfg)
+    shapes = OrderedDict(("backbone.blk." + k, tuple(v.shape)) for k, v in blk.state_dict().items())
+    sd = H.synth_state_dict(shapes, seed=4)
+    blk.load_state_dict(OrderedDict((k[len("backbone.blk."):], v) for k, v in sd.items()))
+    blk.train()
+    x = H.synth_tensor(4, "g4.x." + name, (2, cfg["inplanes"], 8, 8)).requires_grad_(True)
+    y = blk(x)
+    w = H.synth_tensor(4, "g4.w." + name, tuple(y.shape))
+    (y * w).sum().backward()
+    close(y, T(g[name + "_y"]))
+    close(x.grad, T(g[name + "_dx"]))
+    for k, p in blk.named_parameters():
+        close(p.grad, T(g[name + "_grad__" + k.replace(".", "_")]), 1e-4)
+    for k, b in blk.named_buffers():
+        if "num_batches" not in k:
+            close(b, T(g[name + "_buf__" + k.replace(".", "_")]))
+
+
+def full_model(train=True):
+    m = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=1))
+    if train:
+        m.train()
+        m.classifier.aspp.project[3].eval()
+        O.set_bn_momentum(m.backbone, 0.01)
+    return m
+
+
+def test_state_dict_contract():
+    m = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    sd = m.state_dict()
+    assert len(sd) == 674
+    assert sum(p.numel() for p in m.parameters()) == 58752688
+    assert "backbone.layer3.22.conv3.weight" in sd and "classifier.aspp.convs.4.2.running_var" in sd
+    assert "classifier.classifier.3.bias" in sd and not any("centers" in k for k in sd)
+    names = [str(n) for n in H.load_golden("g5_full_train")["grad_names"]]
+    assert names == [k for k, _ in m.named_parameters()]
+
+
+def test_g5_full_train_and_g8_trajectory():
+    g = H.load_golden("g5_full_train")
+    m = full_model()
+    img = H.synth_tensor(5, "g5.img", (2, 3, 64, 64))
+    lab = H.synth_labels(5, "g5.lab", (2, 64, 64), 16, 255, ignore_rows=3)
+    lg, ctr, ft = m(img)
+    loss = O.ce_over_n(lg, lab, 255)
+    loss.backward()
+    close(lg, T(g["logits"]), 1e-4)
+    close(loss, T(g["loss"]), 1e-5)
+    grads = OrderedDict((k, p.grad) for k, p in m.named_parameters())
+    for (k, gr), cs in zip(grads.items(), g["grad_checksums"]):
+        assert np.allclose(H.checksum(gr)[1:], cs[1:], rtol=2e-3), k
+    close(grads["classifier.classifier.3.bias"], T(g["grad__classifier_classifier_3_bias"]), 1e-4)
+    close(grads["backbone.conv1.weight"], T(g["grad__backbone_conv1_weight"]), 1e-3)
+    close(dict(m.named_buffers())["backbone.bn1.running_var"], T(g["rv_stem"]))
+    # G8: 6 SGD steps with two LR groups + PolyLR
+    t = H.load_golden("g8_trajectory")
+    m = full_model()
+    lr, total = float(t["lr"]), int(t["total_itrs"])
+    opt = O.make_optimizer(m, lr=lr, weight_decay=1e-4)
+    losses = [float(O.train_step(m, opt, img, lab, it, total, [0.1 * lr, lr],
+                                 lambda a, b: O.ce_over_n(a, b, 255))) for it in range(6)]
+    assert np.allclose(losses, t["losses"], rtol=5e-4), (losses, t["losses"])
+    assert np.allclose([gp["lr"] for gp in opt.param_groups], t["lrs"][-1], rtol=1e-6)
+    close(m.state_dict()["classifier.classifier.3.bias"], T(t["b_last"]), 1e-3)
+    close(m.state_dict()["backbone.conv1.weight"], T(t["w_stem"]), 1e-3)
+
+
+def load_bn_stats(model, flat):
+    off = 0
+    sd = model.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            n = v.numel()
+            v.copy_(flat[off:off + n].view_as(v))
+            off += n
+    assert off == flat.numel()
+
+
+def test_g5b_eval_config1():
+    """BASELINE config #1: 1x3x256x256 eval forward on CPU."""
+    g = H.load_golden("g5b_full_eval")
+    m = full_model(train=False)
+    load_bn_stats(m, T(g["bn_stats"]))
+    m.eval()
+    with torch.no_grad():
+        lg, ctr, ft = m(H.synth_tensor(5, "g5b.img", (1, 3, 256, 256)))
+    assert lg.shape == (1, 16, 256, 256) and ft.shape == (1, 256, 256, 16) and ctr.shape == (16, 16)
+    close(lg[:, :, ::4, ::4], T(g["logits_sub"]), 1e-4)
+    close(ft[:, ::4, ::4, :], T(g["feats_sub"]), 1e-4)
+    assert np.allclose(H.checksum(lg), g["logits_checksum"], rtol=1e-4)
+    agree = (lg.argmax(1).to(torch.uint8) == T(g["argmax"])).float().mean().item()
+    assert agree > 0.999
+
+
+def test_g6_bilinear():
+    g = H.load_golden("g6_bilinear")
+    close(O.bilinear(T(g["a"]), (20, 28)), T(g["ua"]), 1e-6)
+    close(O.bilinear(T(g["b"]), (6, 5)), T(g["ub"]), 1e-6)
+    c = T(g["c"]).requires_grad_(True)
+    uc = O.bilinear(c, (13, 17))
+    (uc * T(g["wc"])).sum().backward()
+    close(uc, T(g["uc"]), 1e-6)
+    close(c.grad, T(g["dc"]), 1e-5)
+    # Appendix A: exact x4 weights cycle through 0.625, 0.875, 0.125, 0.375
+    ramp = torch.arange(4.0).view(1, 1, 1, 4)
+    up = O.bilinear(ramp, (1, 16)).flatten()
+    assert torch.allclose(up[2:6], torch.tensor([0.125, 0.375, 0.625, 0.875]))
+
+
+def test_g7_scoring():
+    g = H.load_golden("g7_scoring")
+    out = g["logits"][0]
+    assert np.array_equal(O.dissum_score(out, 1000, False), g["dissum_deeplab"])
+    assert np.array_equal(O.dissum_score(out, 400, True), g["dissum_anomaly"])
+    assert np.allclose(O.msp_score(T(g["logits"])).numpy(), g["msp"], atol=1e-6)
+    proto = O.mean_prototype(g["shots"].tolist())
+    assert np.allclose(proto, g["proto"])
+    rel = O.novel_relabel(g["preds"][0], out, g["feats"][0], proto)
+    assert np.array_equal(rel, g["relabel"][0])
+
+
+def test_poly_lr():
+    assert O.poly_lr(0.1, 0, 100) == pytest.approx(0.1)
+    assert O.poly_lr(0.1, 50, 100) == pytest.approx(0.1 * 0.5 ** 0.9)
+    assert O.poly_lr(0.1, 100, 100) == pytest.approx(1e-6)       # utils/scheduler.py:10 min_lr floor
+
+
+def test_stage_plan_matches_reference_dilations():
+    plan = O.stage_plan(16)
+    l4 = [c for c in plan if c["stage"] == 4]
+    assert [c["dilation"] for c in l4] == [1, 2, 2] and [c["stride"] for c in l4] == [1, 1, 1]
+    plan8 = O.stage_plan(8)
+    l3 = [c for c in plan8 if c["stage"] == 3]
+    assert l3[0]["dilation"] == 1 and l3[1]["dilation"] == 2
+    assert [c["dilation"] for c in plan8 if c["stage"] == 4][:2] == [2, 4]
+    assert len(plan) == 33
