@@ -1,0 +1,213 @@
+/*
+ * dmlnet_hip.h -- C ABI of libdmlnet_hip.so, the MI355X (gfx950) kernels under the DMLNet hot path.
+ *
+ * The reference (Jun-CEN/Open-World-Semantic-Segmentation) is 100 % Python and has no FFI: every
+ * entry point below replaces a stock ATen/cuDNN op that the reference reaches through the call
+ * site cited next to it (paths relative to /root/reference/DeepLabV3Plus-Pytorch unless noted).
+ * The Python package `open-world-semantic-segmentation_amd/network` binds these with ctypes and
+ * re-exposes the reference's own module API (network.deeplabv3plus_embedding_resnet101, ...).
+ *
+ * Conventions
+ *   - plain pointers and sizes only; every pointer is a DEVICE pointer unless stated;
+ *   - activations are NHWC, channel pitch ("ld", in elements) given explicitly so that producers
+ *     can write straight into channel slices of a concat buffer (replaces torch.cat,
+ *     network/utils.py:32,360);
+ *   - conv weights are K-R-S-C ("OHWI"): w[n][r][s][c];
+ *   - `dtype` selects the storage type of activations / compute weights: DML_F32 or DML_BF16;
+ *     accumulation, batch-norm statistics, the distance head, the loss and the optimizer state
+ *     are always fp32;
+ *   - the caller owns every buffer (including workspaces); nothing here allocates, frees or
+ *     synchronises; every launch goes to `stream` (a hipStream_t passed as void*);
+ *   - return value: 0 on success, a negative DML_E* code for a rejected argument, or a positive
+ *     hipError_t from the launch.  Nothing throws.
+ */
+#ifndef DMLNET_HIP_H
+#define DMLNET_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DML_ABI_VERSION 1
+
+enum { DML_F32 = 0, DML_BF16 = 1 };
+enum { DML_EINVAL = -1, DML_EALIGN = -2, DML_EUNSUPPORTED = -3 };
+
+int dml_abi_version(void);
+/* Name of the code object the library was built for ("gfx950"). */
+const char* dml_target_arch(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * Convolution as implicit GEMM on MFMA (nn.Conv2d call sites: network/backbone/resnet.py:24-32,139;
+ * network/utils.py:11-23,311,322,337-352).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct DmlConvDesc {
+    const void* x;        /* source activations [B,Hi,Wi,C] (fwd: conv input; dgrad: dY), pitch ldx    */
+    const void* w;        /* fwd: w[N][R][S][C]; dgrad: transposed copy wt[N=Cin][R][S][C=Cout]         */
+    void* y;              /* result [B,Ho,Wo,N], pitch ldy                                               */
+    const float* bias;    /* optional [N] (only network/utils.py:23 has a bias)                          */
+    float* stats;         /* optional BN partials [ceil(M/DML_STAT_ROWS)][N][2] = (sum, M2 about the     */
+                          /* group mean) taken from the fp32 accumulators (fused K9)         */
+    const float* pre_scale;  /* optional fused BN+ReLU on the A operand: a = relu(x*scale[c]+shift[c]),  */
+    const float* pre_shift;  /* applied before zero padding (fwd mode only)                              */
+    int32_t B, Hi, Wi, C, ldx;
+    int32_t Ho, Wo, N, ldy;
+    int32_t R, S, stride, dil, pad;
+    int32_t dtype;        /* DML_F32 | DML_BF16 for x, w, y                                              */
+    int32_t y_f32;        /* 1: write y as float regardless of dtype                                     */
+    int32_t accum;        /* 1: y += result                                                              */
+    int32_t mode;         /* 0 = forward gather, 1 = data-gradient gather (transposed conv)              */
+    int32_t pre_relu;     /* with pre_scale: apply ReLU after the affine                                 */
+} DmlConvDesc;
+
+#define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
+
+int dml_conv_igemm(const DmlConvDesc* d, void* stream);
+
+typedef struct DmlWgradDesc {
+    const void* x;        /* conv input [B,Hi,Wi,C], pitch ldx                                           */
+    const void* dy;       /* output gradient [B,Ho,Wo,N], pitch ldy                                      */
+    float* dw;            /* fp32 weight gradient [N][R][S][C], accumulated with atomics (+=)            */
+    int32_t B, Hi, Wi, C, ldx;
+    int32_t Ho, Wo, N, ldy;
+    int32_t R, S, stride, dil, pad;
+    int32_t dtype;
+    int32_t splitk;       /* number of slices of the pixel dimension (>=1); 0 = pick automatically      */
+} DmlWgradDesc;
+
+int dml_conv_wgrad(const DmlWgradDesc* d, void* stream);
+
+/* master fp32 weight [N][RS][Cm] -> compute copy [N][RS][Cp] (zero padded, dtype) and, if wt != NULL,
+ * the transposed copy wt[Cp][RS][N] used by the data gradient. */
+int dml_prep_weight(const float* w_master, void* w, void* wt, int N, int RS, int Cm, int Cp, int dtype,
+                    void* stream);
+/* dst[N][RS][Cm] += src[N][RS][Cp] (drops the padding channels of a padded weight gradient). */
+int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int Cm, int Cp, void* stream);
+/* bias gradient: db[n] += sum_m dy[m][n]  (network/utils.py:23) */
+int dml_bias_grad(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, void* stream);
+
+/* x[B,C,H,W] fp32 (the reference's input layout) -> NHWC with C padded to Cp, dtype. */
+int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int Cp, int dtype,
+                   void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * BatchNorm2d (112 instances; train: batch statistics, eval: running statistics).
+ * ---------------------------------------------------------------------------------------------- */
+/* Chan-merge the conv epilogue partials -> mean / biased var -> scale = gamma*invstd,
+ * shift = beta - mean*scale; updates running stats with the unbiased variance and `momentum`
+ * exactly as nn.BatchNorm2d does; saves mean / invstd for the backward. */
+int dml_bn_finalize(const float* partials, int64_t M, int N, const float* gamma, const float* beta,
+                    float* running_mean, float* running_var, float momentum, float eps,
+                    float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* Standalone statistics for tensors that were not produced by dml_conv_igemm (writes the same
+ * partial format). */
+int dml_bn_stats(const void* y, float* partials, int64_t M, int N, int ldy, int dtype, void* stream);
+/* eval mode: scale/shift from the running statistics. */
+int dml_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                       const float* running_var, float eps, float* scale, float* shift, int N,
+                       void* stream);
+/* z = act(y*scale + shift [+ res]) with optional inverted dropout (network/utils.py:354).
+ * y, res, z have independent pitches; y may be float when y_f32 != 0. */
+int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
+                 int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype,
+                 float drop_p, uint64_t drop_seed, void* stream);
+/* backward, pass 1: per-channel sums of g = dz*[z>0]*gscale and g*xhat -> partials[blocks][N][2].
+ * returns the number of partial rows through *nblocks (host int). */
+int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* save_mean,
+                      const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
+                      int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream);
+/* backward, pass 1b: fold partials, write dgamma/dbeta (+=) and the per-channel coefficients
+ * coef[3][N] with dy = coef0*g + coef1*y + coef2. */
+int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, const float* gamma,
+                        const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                        float* coef, void* stream);
+/* backward, pass 2: dy = coef0*g + coef1*y + coef2; optionally dres (+)= g for the identity branch. */
+int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* coef, void* dy,
+                     void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
+                     int relu, float gscale, int dres_accum, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pooling (network/backbone/resnet.py:143; network/utils.py:320,326-329).
+ * ---------------------------------------------------------------------------------------------- */
+int dml_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C, int dtype,
+                         void* stream);
+int dml_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C,
+                         int dtype, void* stream);
+/* y[b][c] = mean over HW of x[b,:,:,c]  (AdaptiveAvgPool2d(1)); y has dtype. */
+int dml_global_avgpool_fwd(const void* x, void* y, int B, int HW, int C, int ldx, int dtype, void* stream);
+/* z[b,h,w,c] = v[b][c] (bilinear upsample of a 1x1 map is a broadcast) */
+int dml_broadcast_hw(const void* v, void* z, int B, int HW, int C, int ldz, int dtype, void* stream);
+/* dv[b][c] = sum over HW of dz[b,:,:,c] */
+int dml_reduce_hw(const void* dz, void* dv, int B, int HW, int C, int lddz, int dtype, void* stream);
+/* dx[b,:,:,c] += dv[b][c] / HW */
+int dml_avgpool_bwd_add(const void* dv, void* dx, int B, int HW, int C, int lddx, int dtype, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Bilinear resize, align_corners=False (F.interpolate call sites network/utils.py:30,88,329).
+ * in_f32 / out_f32 select float storage for that side, otherwise `dtype`.
+ * ---------------------------------------------------------------------------------------------- */
+int dml_bilinear_fwd(const void* x, void* y, int B, int h, int w, int H, int W, int C, int ldx, int ldy,
+                     int dtype, int in_f32, int out_f32, void* stream);
+int dml_bilinear_bwd(const void* dy, void* dx, int B, int h, int w, int H, int W, int C, int lddy,
+                     int lddx, int dtype, int in_f32, int out_f32, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * Pixel -> prototype squared-distance head (network/utils.py:92-118; anomaly/models/models.py:636-657)
+ * and what the drivers compute from it on the host (test_embedding.py:339-350,428-445;
+ * anomaly/eval_ood_traditional.py:301-305).
+ * ---------------------------------------------------------------------------------------------- */
+/* x: embedding at full resolution, NCHW fp32 (what F.interpolate returns at utils.py:88).
+ * logits[b,k,h,w] = -sum_c (x[b,c,h,w]-protos[k][c])^2 (NCHW), features_out = x in NHWC.
+ * Any of logits / feats / argmax / dissum may be NULL.  192 B per pixel at K=C=16. */
+int dml_proto_dist_fwd(const float* x_nchw, const float* protos, float* logits, float* feats,
+                       uint8_t* argmax, float* dissum, int B, int C, int K, int H, int W, void* stream);
+/* Fused: bilinear x(H/h) upsample of the low-resolution embedding e[B,h,w,C] (NHWC fp32) + the
+ * distance head, writing logits NCHW and features_out NHWC at [H,W]. */
+int dml_upsample_dist_fwd(const float* e, const float* protos, float* logits, float* feats,
+                          uint8_t* argmax, float* dissum, int B, int h, int w, int C, int K, int H,
+                          int W, void* stream);
+/* df[b,h,w,c] = -2 * sum_k glogits[b,k,h,w] * (feats[b,h,w,c]-protos[k][c]) (+ gfeats[b,h,w,c]) */
+int dml_proto_dist_bwd(const float* glogits, const float* gfeats, const float* feats,
+                       const float* protos, float* df, int B, int C, int K, int H, int W, void* stream);
+
+/* preds = argmax_k logits (ties -> lowest k), msp = 1 - max softmax  (test_embedding.py:339-341) */
+int dml_argmax_msp(const float* logits, int64_t* preds, float* msp, int B, int K, int H, int W,
+                   void* stream);
+/* s = -sum_k logit_k, clipped (inclusive: s>=clip -> clip, else s>clip -> clip), then per-image
+ * min-max normalised.  work: 2*B floats. */
+int dml_dissum_score(const float* logits, float* score, float* work, int B, int K, int H, int W,
+                     float clip, int inclusive, void* stream);
+/* preds[p] = new_label where -|f_p - proto|^2 > thresh and > max_k logits[k][p] */
+int dml_novel_relabel(const float* feats, const float* logits, const float* proto, int64_t* preds,
+                      int B, int C, int K, int H, int W, float thresh, int64_t new_label, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * DML loss = CE(-dist^2)/n + alpha * VAR/n (anomaly/models/models.py:42-78; live part of
+ * utils/loss.py:34-42 is alpha = 0).
+ * sums (device, double[4]) = { sum nll over valid px, #valid px, VAR, #correct }.
+ * ---------------------------------------------------------------------------------------------- */
+int dml_loss_fwd(const float* logits, const int64_t* labels, double* sums, float* block_partials,
+                 int B, int K, int H, int W, int64_t ignore_index, void* stream);
+/* loss = (sums[0]/sums[1] + alpha*sums[2]) / n_images  (written to *loss, device float) */
+int dml_loss_finalize(const double* sums, float* loss, float alpha, float n_images, void* stream);
+/* glogits = gout * d loss / d logits; gout is a device scalar. */
+int dml_loss_bwd(const float* logits, const int64_t* labels, const double* sums, const float* gout,
+                 float* glogits, int B, int K, int H, int W, int64_t ignore_index, float alpha,
+                 float n_images, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
+ * SGD with momentum and weight decay, torch semantics (main_embedding.py:385-388):
+ *   g = gscale*g + wd*p ; v = mu*v + g ; p -= lr*v
+ * ---------------------------------------------------------------------------------------------- */
+int dml_sgd_step(float* p, const float* g, float* v, int64_t n, float lr, float momentum,
+                 float weight_decay, float gscale, void* stream);
+
+/* fill / scale helpers used by the host runtime */
+int dml_fill_f32(float* p, int64_t n, float value, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DMLNET_HIP_H */

@@ -1,0 +1,410 @@
+// BatchNorm2d pieces for NHWC tensors on gfx950: statistics merge, affine(+residual)(+ReLU)(+dropout)
+// apply, and the two-pass backward.  All HBM-bound: 16-byte vector accesses, fp32 math.
+//
+// Replaces nn.BatchNorm2d (112 instances: network/backbone/resnet.py:84-92,140,181; network/utils.py:13,21,
+// 313,323,339,352), the ReLU / residual add at resnet.py:96-113 and nn.Dropout at network/utils.py:354.
+#include "common.h"
+
+namespace {
+
+struct Moments {   // Chan et al. parallel-variance state
+    double n, mean, m2;
+};
+__device__ __forceinline__ void merge(Moments& a, double nb, double meanb, double m2b) {
+    if (nb <= 0.0) return;
+    const double n = a.n + nb;
+    const double d = meanb - a.mean;
+    a.mean += d * (nb / n);
+    a.m2 += m2b + d * d * (a.n * nb / n);
+    a.n = n;
+}
+
+// partials[g][n] = (sum, M2 about the group mean) over rows [64 g, 64 g + 64)
+constexpr int FIN_CH = 4, FIN_SL = 64;
+__global__ __launch_bounds__(256) void bn_finalize_kernel(
+    const float* __restrict__ partials, int64_t M, int N, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* scale, float* shift, float* save_mean, float* save_invstd) {
+    __shared__ double sh[3][FIN_SL][FIN_CH];
+    const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
+    const int n = blockIdx.x * FIN_CH + ch;
+    const int64_t G = (M + DML_STAT_ROWS - 1) / DML_STAT_ROWS;
+    Moments acc = {0.0, 0.0, 0.0};
+    if (n < N) {
+        for (int64_t g = sl; g < G; g += FIN_SL) {
+            const int64_t rows = min((int64_t)DML_STAT_ROWS, M - g * DML_STAT_ROWS);
+            const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
+            merge(acc, (double)rows, (double)p.x / (double)rows, (double)p.y);
+        }
+    }
+    sh[0][sl][ch] = acc.n; sh[1][sl][ch] = acc.mean; sh[2][sl][ch] = acc.m2;
+    __syncthreads();
+    for (int s = FIN_SL / 2; s > 0; s >>= 1) {
+        if (sl < s) {
+            Moments a = {sh[0][sl][ch], sh[1][sl][ch], sh[2][sl][ch]};
+            merge(a, sh[0][sl + s][ch], sh[1][sl + s][ch], sh[2][sl + s][ch]);
+            sh[0][sl][ch] = a.n; sh[1][sl][ch] = a.mean; sh[2][sl][ch] = a.m2;
+        }
+        __syncthreads();
+    }
+    if (sl == 0 && n < N) {
+        const double mean = sh[1][0][ch], m2 = sh[2][0][ch], cnt = sh[0][0][ch];
+        const double var_b = m2 / cnt;
+        const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+        const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
+        const float sc = g * invstd;
+        scale[n] = sc;
+        shift[n] = b - (float)mean * sc;
+        if (save_mean) save_mean[n] = (float)mean;
+        if (save_invstd) save_invstd[n] = invstd;
+        if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+        if (running_var) {
+            const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
+            running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void bn_stats_kernel(const T* __restrict__ y, float* __restrict__ partials,
+                                                      int64_t M, int N, int ldy) {
+    const int n = blockIdx.y * 64 + threadIdx.x;
+    const int64_t g = blockIdx.x;
+    if (n >= N) return;
+    const int64_t r0 = g * DML_STAT_ROWS;
+    const int rows = (int)min((int64_t)DML_STAT_ROWS, M - r0);
+    float s = 0.f;
+    for (int r = 0; r < rows; ++r) s += Elem<T>::ld(y + (r0 + r) * ldy + n);
+    const float mean = s / (float)rows;
+    float m2 = 0.f;
+    for (int r = 0; r < rows; ++r) {
+        const float d = Elem<T>::ld(y + (r0 + r) * ldy + n) - mean;
+        m2 += d * d;
+    }
+    partials[(g * N + n) * 2] = s;
+    partials[(g * N + n) * 2 + 1] = m2;
+}
+
+__global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, const float* rm, const float* rv,
+                                      float eps, float* scale, float* shift, int N) {
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float invstd = 1.0f / sqrtf(rv[n] + eps);
+    const float sc = (gamma ? gamma[n] : 1.f) * invstd;
+    scale[n] = sc;
+    shift[n] = (beta ? beta[n] : 0.f) - rm[n] * sc;
+}
+
+__device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
+    uint64_t h = seed + idx * 0x9E3779B97F4A7C15ull;
+    h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull;
+    h ^= h >> 27; h *= 0x94D049BB133111EBull;
+    h ^= h >> 31;
+    return (uint32_t)(h >> 32) >= thresh;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(
+    const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
+    const float* __restrict__ shift, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
+    float drop_p, uint64_t drop_seed, FastDiv div_nv) {
+    constexpr int V = Vec16<T>::N;
+    const int NV = N / V;
+    const int64_t total = M * NV;
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)min(4294967295.0, (double)drop_p * 4294967296.0) : 0u;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = fdiv((uint32_t)i, div_nv);
+        const int c = ((int)((uint32_t)i - m * (uint32_t)NV)) * V;
+        float v[V], sc[V], sh[V];
+        Vec16<T>::load(y + (int64_t)m * ldy + c, v);
+#pragma unroll
+        for (int q = 0; q < V; q += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(scale + c + q);
+            const float4 b = *reinterpret_cast<const float4*>(shift + c + q);
+            sc[q] = a.x; sc[q + 1] = a.y; sc[q + 2] = a.z; sc[q + 3] = a.w;
+            sh[q] = b.x; sh[q + 1] = b.y; sh[q + 2] = b.z; sh[q + 3] = b.w;
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) v[q] = v[q] * sc[q] + sh[q];
+        if (res != nullptr) {
+            float r[V];
+            Vec16<T>::load(res + (int64_t)m * ldres + c, r);
+#pragma unroll
+            for (int q = 0; q < V; ++q) v[q] += r[q];
+        }
+        if (relu) {
+#pragma unroll
+            for (int q = 0; q < V; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+        }
+        if (drop_p > 0.f) {
+#pragma unroll
+            for (int q = 0; q < V; ++q)
+                v[q] = drop_keep(drop_seed, (uint64_t)m * N + c + q, thresh) ? v[q] * keep_scale : 0.f;
+        }
+        Vec16<T>::store(z + (int64_t)m * ldz + c, v);
+    }
+}
+
+// ---------------------------------------------------------------------------------- backward
+// pass 1: partials[rb][n] = (sum g, sum g * xhat),  g = dz * [z > 0] * gscale
+constexpr int RED_COLS = 64;   // vector columns per block
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
+    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* __restrict__ partials,
+    int64_t M, int N, int lddz, int ldy, int ldz, int relu, float gscale, int rows_per_block, int chv, int rt) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float sh[256 * 2 * V];
+    const int NV = N / V;
+    const int col = threadIdx.x % chv, rl = threadIdx.x / chv;
+    const int v = blockIdx.y * chv + col;
+    const bool active = rl < rt && v < NV;
+    float sg[V], sgx[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { sg[q] = 0.f; sgx[q] = 0.f; }
+    if (active) {
+        const int c = v * V;
+        float mu[V], is[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) { mu[q] = save_mean[c + q]; is[q] = save_invstd[c + q]; }
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+        const int64_t r1 = min(M, r0 + rows_per_block);
+        for (int64_t m = r0 + rl; m < r1; m += rt) {
+            float g[V], yy[V];
+            Vec16<T>::load(dz + m * lddz + c, g);
+            Vec16<T>::load(y + m * ldy + c, yy);
+            if (relu) {
+                float zz[V];
+                Vec16<T>::load(z + m * ldz + c, zz);
+#pragma unroll
+                for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
+            }
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const float gg = g[q] * gscale;
+                sg[q] += gg;
+                sgx[q] += gg * (yy[q] - mu[q]) * is[q];
+            }
+        }
+    }
+    // reduce over the rt row lanes that share a column
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        sh[(threadIdx.x * V + q) * 2] = sg[q];
+        sh[(threadIdx.x * V + q) * 2 + 1] = sgx[q];
+    }
+    __syncthreads();
+    if (rl == 0 && v < NV) {
+        for (int r = 1; r < rt; ++r) {
+            const int t = r * chv + col;
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                sg[q] += sh[(t * V + q) * 2];
+                sgx[q] += sh[(t * V + q) * 2 + 1];
+            }
+        }
+        float* p = partials + ((int64_t)blockIdx.x * N + v * V) * 2;
+#pragma unroll
+        for (int q = 0; q < V; ++q) { p[2 * q] = sg[q]; p[2 * q + 1] = sgx[q]; }
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
+    const float* __restrict__ partials, int nblocks, int64_t M, int N, const float* __restrict__ gamma,
+    const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma, float* dbeta,
+    float* coef) {
+    __shared__ double sh[2][FIN_SL][FIN_CH];
+    const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
+    const int n = blockIdx.x * FIN_CH + ch;
+    double s0 = 0.0, s1 = 0.0;
+    if (n < N)
+        for (int g = sl; g < nblocks; g += FIN_SL) {
+            const float2 p = *reinterpret_cast<const float2*>(partials + ((int64_t)g * N + n) * 2);
+            s0 += p.x; s1 += p.y;
+        }
+    sh[0][sl][ch] = s0; sh[1][sl][ch] = s1;
+    __syncthreads();
+    for (int s = FIN_SL / 2; s > 0; s >>= 1) {
+        if (sl < s) { sh[0][sl][ch] += sh[0][sl + s][ch]; sh[1][sl][ch] += sh[1][sl + s][ch]; }
+        __syncthreads();
+    }
+    if (sl == 0 && n < N) {
+        const double dbeta_s = sh[0][0][ch], dgamma_s = sh[1][0][ch];
+        const double g = gamma ? (double)gamma[n] : 1.0, is = save_invstd[n], mu = save_mean[n];
+        const double A = g * is;
+        const double Bc = -A * is * dgamma_s / (double)M;
+        const double C0 = -A * dbeta_s / (double)M - Bc * mu;
+        coef[n] = (float)A; coef[N + n] = (float)Bc; coef[2 * N + n] = (float)C0;
+        if (dgamma) dgamma[n] += (float)dgamma_s;
+        if (dbeta) dbeta[n] += (float)dbeta_s;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
+    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const float* __restrict__ coef,
+    T* __restrict__ dy, T* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres, int relu,
+    float gscale, int dres_accum, FastDiv div_nv) {
+    constexpr int V = Vec16<T>::N;
+    const int NV = N / V;
+    const int64_t total = M * NV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t m = fdiv((uint32_t)i, div_nv);
+        const int c = ((int)((uint32_t)i - m * (uint32_t)NV)) * V;
+        float g[V], yy[V], o[V];
+        Vec16<T>::load(dz + (int64_t)m * lddz + c, g);
+        Vec16<T>::load(y + (int64_t)m * ldy + c, yy);
+        if (relu) {
+            float zz[V];
+            Vec16<T>::load(z + (int64_t)m * ldz + c, zz);
+#pragma unroll
+            for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            g[q] *= gscale;
+            o[q] = coef[c + q] * g[q] + coef[N + c + q] * yy[q] + coef[2 * N + c + q];
+        }
+        Vec16<T>::store(dy + (int64_t)m * lddy + c, o);
+        if (dres != nullptr) {
+            if (dres_accum) {
+                float r[V];
+                Vec16<T>::load(dres + (int64_t)m * lddres + c, r);
+#pragma unroll
+                for (int q = 0; q < V; ++q) g[q] += r[q];
+            }
+            Vec16<T>::store(dres + (int64_t)m * lddres + c, g);
+        }
+    }
+}
+
+inline bool vec_ok(int dtype, int a) { return a % (dtype == DML_BF16 ? 8 : 4) == 0; }
+
+}  // namespace
+
+extern "C" int dml_bn_finalize(const float* partials, int64_t M, int N, const float* gamma, const float* beta,
+                               float* running_mean, float* running_var, float momentum, float eps,
+                               float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    if (!partials || !scale || !shift || M <= 0 || N <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), partials, M, N, gamma, beta, running_mean, running_var,
+                       momentum, eps, scale, shift, save_mean, save_invstd);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_stats(const void* y, float* partials, int64_t M, int N, int ldy, int dtype, void* stream) {
+    if (!y || !partials || M <= 0 || N <= 0) return DML_EINVAL;
+    dim3 grid((unsigned)((M + DML_STAT_ROWS - 1) / DML_STAT_ROWS), (N + 63) / 64);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(bn_stats_kernel<bf16_t>, grid, dim3(64), 0, st, (const bf16_t*)y, partials, M, N, ldy);
+    else
+        hipLaunchKernelGGL(bn_stats_kernel<float>, grid, dim3(64), 0, st, (const float*)y, partials, M, N, ldy);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
+                                  const float* running_var, float eps, float* scale, float* shift, int N,
+                                  void* stream) {
+    if (!running_mean || !running_var || !scale || !shift || N <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), gamma, beta, running_mean, running_var, eps, scale,
+                       shift, N);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
+                            int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype, float drop_p,
+                            uint64_t drop_seed, void* stream) {
+    if (!y || !z || !scale || !shift || M <= 0 || N <= 0) return DML_EINVAL;
+    if (!vec_ok(dtype, N) || !vec_ok(dtype, ldy) || !vec_ok(dtype, ldz) || (res && !vec_ok(dtype, ldres)))
+        return DML_EALIGN;
+    if (M >= (1ll << 31)) return DML_EINVAL;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    const FastDiv dv = make_fastdiv((uint32_t)(N / V));
+    const int grid = grid_for(M * (N / V), 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y,
+                           (const bf16_t*)res, (bf16_t*)z, scale, shift, M, N, ldy, ldres, ldz, relu, drop_p,
+                           drop_seed, dv);
+    else
+        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y,
+                           (const float*)res, (float*)z, scale, shift, M, N, ldy, ldres, ldz, relu, drop_p,
+                           drop_seed, dv);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* save_mean,
+                                 const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
+                                 int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream) {
+    if (!dz || !y || !save_mean || !save_invstd || !partials || !nblocks || M <= 0 || N <= 0) return DML_EINVAL;
+    if (relu && !z) return DML_EINVAL;
+    if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || (relu && !vec_ok(dtype, ldz)))
+        return DML_EALIGN;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    const int NV = N / V;
+    const int chv = NV < RED_COLS ? NV : RED_COLS;
+    const int rt = 256 / chv;
+    const int col_chunks = (NV + chv - 1) / chv;
+    int64_t rpb = (M * col_chunks + 1023) / 1024;
+    if (rpb < 4 * rt) rpb = 4 * rt;
+    rpb = ((rpb + rt - 1) / rt) * rt;
+    const int rb = (int)((M + rpb - 1) / rpb);
+    *nblocks = rb;
+    dim3 grid(rb, col_chunks);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz,
+                           (const bf16_t*)y, (const bf16_t*)z, save_mean, save_invstd, partials, M, N, lddz, ldy,
+                           ldz, relu, gscale, (int)rpb, chv, rt);
+    else
+        hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz,
+                           (const float*)y, (const float*)z, save_mean, save_invstd, partials, M, N, lddz, ldy,
+                           ldz, relu, gscale, (int)rpb, chv, rt);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, const float* gamma,
+                                   const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                                   float* coef, void* stream) {
+    if (!partials || !save_mean || !save_invstd || !coef || nblocks <= 0 || N <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), partials, nblocks, M, N, gamma, save_mean, save_invstd,
+                       dgamma, dbeta, coef);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* coef, void* dy,
+                                void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
+                                int relu, float gscale, int dres_accum, int dtype, void* stream) {
+    if (!dz || !y || !coef || !dy || M <= 0 || N <= 0) return DML_EINVAL;
+    if (relu && !z) return DML_EINVAL;
+    if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || !vec_ok(dtype, lddy) ||
+        (relu && !vec_ok(dtype, ldz)) || (dres && !vec_ok(dtype, lddres)))
+        return DML_EALIGN;
+    if (M >= (1ll << 31)) return DML_EINVAL;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    const FastDiv dv = make_fastdiv((uint32_t)(N / V));
+    const int grid = grid_for(M * (N / V), 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz,
+                           (const bf16_t*)y, (const bf16_t*)z, coef, (bf16_t*)dy, (bf16_t*)dres, M, N, lddz, ldy,
+                           ldz, lddy, lddres, relu, gscale, dres_accum, dv);
+    else
+        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz,
+                           (const float*)y, (const float*)z, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
+                           lddy, lddres, relu, gscale, dres_accum, dv);
+    DML_LAUNCH_CHECK();
+    return 0;
+}

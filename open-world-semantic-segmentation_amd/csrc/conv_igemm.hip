@@ -1,0 +1,643 @@
+// Implicit-GEMM convolution on MFMA for gfx950 (MI355X).
+//
+//   forward : y[m][n]  = sum_{r,s,c} x[src(m,r,s)][c] * w[n][r][s][c]          m = (b,yo,xo)
+//   dgrad   : dx[m][n] = sum_{r,s,c} dy[srcT(m,r,s)][c] * wt[n][r][s][c]       m = (b,yi,xi), n = Cin
+//   wgrad   : dw[n][r][s][c] += sum_m dy[m][n] * x[src(m,r,s)][c]
+//
+// Replaces nn.Conv2d at network/backbone/resnet.py:24-32,139 and network/utils.py:11-23,311,322,
+// 337-352 of the reference (cuDNN there).  Layout NHWC / KRSC so that the GEMM K dimension is
+// contiguous in both operands; 128-row pixel tiles; bf16 (v_mfma_f32_16x16x32_bf16) or exact fp32
+// (v_mfma_f32_16x16x4_f32) with fp32 accumulation.  The MFMA "row" operand is the weight tile so
+// that every lane ends up with 4 consecutive output channels of one pixel (8/16-byte stores).
+// The epilogue can emit per-channel BatchNorm partial statistics straight from the accumulators.
+#include "common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int NTHREADS = 256;
+
+typedef __bf16 mfma_bf16x8 __attribute__((ext_vector_type(8)));
+
+struct ConvArgs {
+    const void* x;
+    const void* w;
+    void* y;
+    const float* bias;
+    float* stats;
+    int B, Hi, Wi, C, ldx;
+    int Ho, Wo, N, ldy;
+    int R, S, stride, dil, pad;
+    int M, Ktot;
+    int y_f32, accum;
+    int nblk_n, nblk_m;
+    FastDiv div_wo, div_howo, div_c;
+};
+
+// bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+    const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
+    const int base = xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+    return base + slot;
+}
+
+template <typename T> __device__ __forceinline__ int swz_chunk(int row, int chunk);
+// bf16: 64-byte rows, ds_read_b128 lane groups {0-3,12-15,20-27}... -> conflict-free permutation
+template <> __device__ __forceinline__ int swz_chunk<bf16_t>(int row, int chunk) {
+    return chunk ^ ((0x78 >> (((row >> 2) & 3) * 2)) & 3);
+}
+// fp32: 128-byte rows, 8 chunks of 16 B
+template <> __device__ __forceinline__ int swz_chunk<float>(int row, int chunk) { return chunk ^ (row & 7); }
+
+// ------------------------------------------------------------------------------------------------
+// forward / data-gradient kernel
+// ------------------------------------------------------------------------------------------------
+template <typename T, int BN, bool ALIGNED, int MODE>
+__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) {
+    constexpr int BM = 128;
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int KV = BK / VEC;                 // 16-byte chunks per tile row
+    constexpr int RPP = NTHREADS / KV;           // rows staged per pass
+    constexpr int A_LD = BM / RPP;
+    constexpr int B_LD = (BN + RPP - 1) / RPP;
+    constexpr int TM = 64, TN = BN / 2;          // wave tile (2 x 2 waves)
+    constexpr int MT = TM / 16, NT = TN / 16;
+
+    __shared__ __attribute__((aligned(256))) T smem[2 * (BM + BN) * BK];
+    auto As = [&](int buf) -> T* { return smem + buf * (BM + BN) * BK; };
+    auto Bs = [&](int buf) -> T* { return smem + buf * (BM + BN) * BK + BM * BK; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk_m = tile / a.nblk_n, blk_n = tile - blk_m * a.nblk_n;
+    const int m0 = blk_m * BM, n0 = blk_n * BN;
+
+    const T* __restrict__ X = static_cast<const T*>(a.x);
+    const T* __restrict__ Wt = static_cast<const T*>(a.w);
+
+    const int kvec = tid % KV, prow = tid / KV;
+
+    // per-thread A rows: pixel decomposition (loop invariant)
+    int a_iy[A_LD], a_ix[A_LD], a_img[A_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = m0 + prow + j * RPP;
+        if (m < a.M) {
+            const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+            const uint32_t yo = fdiv(rem, a.div_wo);
+            const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+            if (MODE == 0) {
+                a_iy[j] = (int)yo * a.stride - a.pad;
+                a_ix[j] = (int)xo * a.stride - a.pad;
+            } else {
+                a_iy[j] = (int)yo + a.pad;
+                a_ix[j] = (int)xo + a.pad;
+            }
+            a_img[j] = (int)b * a.Hi;
+        } else {
+            a_iy[j] = -(1 << 28);
+            a_ix[j] = -(1 << 28);
+            a_img[j] = 0;
+        }
+    }
+
+    uint4 a_reg[A_LD], b_reg[B_LD];
+
+    auto load_tiles = [&](int kt, int tap_r, int tap_s, int c0) {
+        // ---- A operand (gathered activations)
+        int r = tap_r, s = tap_s, c = c0 + kvec * VEC;
+        bool kvalid = true;
+        if (!ALIGNED) {
+            const int k = kt * BK + kvec * VEC;
+            kvalid = k < a.Ktot;
+            const uint32_t tap = fdiv((uint32_t)k, a.div_c);
+            c = k - (int)tap * a.C;
+            r = (int)tap / a.S;
+            s = (int)tap - r * a.S;
+        }
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            int ys, xs;
+            bool ok = kvalid;
+            if (MODE == 0) {
+                ys = a_iy[j] + r * a.dil;
+                xs = a_ix[j] + s * a.dil;
+            } else {
+                const int ty = a_iy[j] - r * a.dil, tx = a_ix[j] - s * a.dil;
+                if (a.stride == 2) {
+                    ok = ok && (((ty | tx) & 1) == 0);
+                    ys = ty >> 1;
+                    xs = tx >> 1;
+                } else {
+                    ys = ty;
+                    xs = tx;
+                }
+            }
+            ok = ok && ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+            if (ok) {
+                const int64_t off = ((int64_t)(a_img[j] + ys) * a.Wi + xs) * a.ldx + c;
+                a_reg[j] = *reinterpret_cast<const uint4*>(X + off);
+            } else {
+                a_reg[j] = make_uint4(0, 0, 0, 0);
+            }
+        }
+        // ---- B operand (weights, K contiguous)
+        const int kk = kt * BK + kvec * VEC;
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int n = n0 + prow + j * RPP;
+            const bool ok = (prow + j * RPP < BN) && n < a.N && (ALIGNED || kk < a.Ktot);
+            if (ok)
+                b_reg[j] = *reinterpret_cast<const uint4*>(Wt + (int64_t)n * a.Ktot + kk);
+            else
+                b_reg[j] = make_uint4(0, 0, 0, 0);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int row = prow + j * RPP;
+            *reinterpret_cast<uint4*>(As(buf) + row * BK + swz_chunk<T>(row, kvec) * VEC) = a_reg[j];
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int row = prow + j * RPP;
+            if (row < BN)
+                *reinterpret_cast<uint4*>(Bs(buf) + row * BK + swz_chunk<T>(row, kvec) * VEC) = b_reg[j];
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int KT = (a.Ktot + BK - 1) / BK;
+    int tap_r = 0, tap_s = 0, c0 = 0;
+    auto advance = [&]() {
+        if (ALIGNED) {
+            c0 += BK;
+            if (c0 >= a.C) {
+                c0 = 0;
+                if (++tap_s == a.S) { tap_s = 0; ++tap_r; }
+            }
+        }
+    };
+
+    load_tiles(0, tap_r, tap_s, c0);
+    store_tiles(0);
+    __syncthreads();
+
+    const int lr = lane & 15, lq = lane >> 4;
+    int cur = 0;
+    for (int kt = 0; kt < KT; ++kt) {
+        const bool has_next = kt + 1 < KT;
+        if (has_next) {
+            advance();
+            load_tiles(kt + 1, tap_r, tap_s, c0);
+        }
+        const T* as = As(cur) + (wm * TM) * BK;
+        const T* bs = Bs(cur) + (wn * TN) * BK;
+        if constexpr (sizeof(T) == 2) {
+            mfma_bf16x8 bf[NT], af[MT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const int row = i * 16 + lr;
+                bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + row * BK + swz_chunk<T>(row, lq) * 8);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int row = j * 16 + lr;
+                af[j] = *reinterpret_cast<const mfma_bf16x8*>(as + row * BK + swz_chunk<T>(row, lq) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float bf[NT], af[MT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int row = i * 16 + lr;
+                    bf[i] = bs[row * BK + swz_chunk<T>(row, kk) * 4 + lq];
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int row = j * 16 + lr;
+                    af[j] = as[row * BK + swz_chunk<T>(row, kk) * 4 + lq];
+                }
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[i], af[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (has_next) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // ---------------------------------------------------------------- epilogue
+    // acc[i][j][reg] = out[m = m0 + wm*64 + j*16 + (lane&15)][n = n0 + wn*TN + i*16 + (lane>>4)*4 + reg]
+    const int mw0 = m0 + wm * TM;
+    const int nw0 = n0 + wn * TN;
+
+    if (a.stats != nullptr) {
+        const int cnt = min(TM, max(0, a.M - mw0));
+        if (cnt > 0) {
+            const float inv = 1.0f / (float)cnt;
+            const int grp = mw0 / TM;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const bool v = (mw0 + j * 16 + lr) < a.M;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s[q] += v ? acc[i][j][q] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) s[q] += __shfl_xor(s[q], o, 64);
+                }
+                float m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const bool v = (mw0 + j * 16 + lr) < a.M;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dlt = acc[i][j][q] - s[q] * inv;
+                        m2[q] += v ? dlt * dlt : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) m2[q] += __shfl_xor(m2[q], o, 64);
+                }
+                if (lr == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nw0 + i * 16 + lq * 4 + q;
+                        if (n < a.N) {
+                            float* p = a.stats + ((int64_t)grp * a.N + n) * 2;
+                            p[0] = s[q];
+                            p[1] = m2[q];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldy & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = mw0 + j * 16 + lr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = nw0 + i * 16 + lq * 4;
+            if (n >= a.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.bias != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < a.N) v[q] += a.bias[n + q];
+            }
+            const int64_t off = (int64_t)m * a.ldy + n;
+            if (a.y_f32) {
+                float* yp = static_cast<float*>(a.y) + off;
+                if (vec_ok) {
+                    if (a.accum) {
+                        const float4 o = *reinterpret_cast<const float4*>(yp);
+                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                    }
+                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
+                }
+            } else if constexpr (sizeof(T) == 4) {
+                float* yp = static_cast<float*>(a.y) + off;
+                if (vec_ok) {
+                    if (a.accum) {
+                        const float4 o = *reinterpret_cast<const float4*>(yp);
+                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                    }
+                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
+                }
+            } else {
+                bf16_t* yp = static_cast<bf16_t*>(a.y) + off;
+                if (vec_ok) {
+                    if (a.accum) {
+                        const uint2 o = *reinterpret_cast<const uint2*>(yp);
+                        v[0] += __uint_as_float(o.x << 16);
+                        v[1] += __uint_as_float(o.x & 0xffff0000u);
+                        v[2] += __uint_as_float(o.y << 16);
+                        v[3] += __uint_as_float(o.y & 0xffff0000u);
+                    }
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(yp) = pk;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.N) yp[q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[q]) + v[q] : v[q]);
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// weight-gradient kernel: dw[n][kc] += sum_m dy[m][n] * x[src(m, tap(kc))][c(kc)]
+// tile 128 (n) x 128 (kc), K loop over 32-pixel slabs, split over the pixel dimension (blockIdx.y).
+// Both operands are "K-major" in memory (pixel rows, channel contiguous): the bf16 fragments are
+// read with the gfx950 LDS transpose read ds_read_b64_tr_b16, the fp32 ones need no transpose.
+// ------------------------------------------------------------------------------------------------
+struct WgradArgs {
+    const void* x;
+    const void* dy;
+    float* dw;
+    int B, Hi, Wi, C, ldx;
+    int Ho, Wo, N, ldy;
+    int R, S, stride, dil, pad;
+    int M, Ktot;
+    int nblk_n, nblk_k;
+    int slab_tiles;   // K tiles (of 32 pixels) per split
+    FastDiv div_wo, div_howo, div_c;
+};
+
+template <typename T> struct WgLds;
+template <> struct WgLds<float> { static constexpr int PITCH = 128 + 16; };    // floats; banks (kg*16 + i)
+template <> struct WgLds<bf16_t> { static constexpr int PITCH = 128 + 8; };    // bf16
+
+__device__ __forceinline__ bf16x4 lds_tr16_b64(const bf16_t* p) {
+    // 16 lanes x 4 bf16 block transposed in hardware (ds_read_b64_tr_b16)
+    typedef short v4i16 __attribute__((ext_vector_type(4)));
+    return __builtin_amdgcn_ds_read_tr16_b64_v4i16((v4i16 __attribute__((address_space(3)))*)(p));
+}
+
+template <typename T>
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a) {
+    constexpr int TILE = 128;
+    constexpr int VEC = Elem<T>::VEC;
+    constexpr int CV = TILE / VEC;                // 16-byte vectors per tile row (16 bf16 / 32 f32)
+    constexpr int RPP = NTHREADS / CV;            // rows per pass (16 / 8)
+    constexpr int LD = BK / RPP;                  // loads per thread per operand (2 / 4)
+    constexpr int PITCH = WgLds<T>::PITCH;
+    constexpr int MT = 4, NT = 4;                 // wave tile 64 (n) x 64 (kc)
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * 2 * BK * PITCH];
+    auto Ys = [&](int buf) -> T* { return smem + buf * 2 * BK * PITCH; };
+    auto Xs = [&](int buf) -> T* { return smem + buf * 2 * BK * PITCH + BK * PITCH; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int blk_n = blockIdx.x % a.nblk_n, blk_k = blockIdx.x / a.nblk_n;
+    const int n0 = blk_n * TILE, kc0 = blk_k * TILE;
+
+    const T* __restrict__ X = static_cast<const T*>(a.x);
+    const T* __restrict__ DY = static_cast<const T*>(a.dy);
+
+    const int vcol = tid % CV, prow = tid / CV;
+    // this thread's fixed filter tap / channel for the X operand
+    const int kc = kc0 + vcol * VEC;
+    const bool kc_ok = kc < a.Ktot;
+    const uint32_t tap = fdiv((uint32_t)(kc_ok ? kc : 0), a.div_c);
+    const int xc = (kc_ok ? kc : 0) - (int)tap * a.C;
+    const int tr = (int)tap / a.S, ts = (int)tap - tr * a.S;
+    const int dyo = tr * a.dil - a.pad, dxo = ts * a.dil - a.pad;
+    const int yn = n0 + vcol * VEC;
+    const bool yn_ok = yn < a.N;
+
+    const int tile_beg = blockIdx.y * a.slab_tiles;
+    const int tiles_total = (a.M + BK - 1) / BK;
+    const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
+
+    uint4 y_reg[LD], x_reg[LD];
+    auto load_tiles = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int m = t * BK + prow + j * RPP;
+            uint4 yv = make_uint4(0, 0, 0, 0), xv = make_uint4(0, 0, 0, 0);
+            if (m < a.M) {
+                if (yn_ok) yv = *reinterpret_cast<const uint4*>(DY + (int64_t)m * a.ldy + yn);
+                if (kc_ok) {
+                    const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+                    const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+                    const uint32_t yo = fdiv(rem, a.div_wo);
+                    const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+                    const int ys = (int)yo * a.stride + dyo, xs = (int)xo * a.stride + dxo;
+                    if ((unsigned)ys < (unsigned)a.Hi && (unsigned)xs < (unsigned)a.Wi)
+                        xv = *reinterpret_cast<const uint4*>(
+                            X + ((int64_t)((int)b * a.Hi + ys) * a.Wi + xs) * a.ldx + xc);
+                }
+            }
+            y_reg[j] = yv;
+            x_reg[j] = xv;
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int row = prow + j * RPP;
+            *reinterpret_cast<uint4*>(Ys(buf) + row * PITCH + vcol * VEC) = y_reg[j];
+            *reinterpret_cast<uint4*>(Xs(buf) + row * PITCH + vcol * VEC) = x_reg[j];
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (tile_beg < tile_end) {
+        load_tiles(tile_beg);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, lq = lane >> 4;
+    int cur = 0;
+    for (int t = tile_beg; t < tile_end; ++t) {
+        const bool has_next = t + 1 < tile_end;
+        if (has_next) load_tiles(t + 1);
+        const T* ys = Ys(cur) + wn * 64;
+        const T* xs = Xs(cur) + wk * 64;
+        if constexpr (sizeof(T) == 2) {
+            // A[i = n][k = pixel]: lanes of a 16-group address the 4 x 16 block (rows k0..k0+3,
+            // cols 16*i..) in 8-byte pieces: lane L -> row L/4, cols 4*(L%4)..; the hardware
+            // returns to lane i the 4 k-values of column i.
+            mfma_bf16x8 af[NT], bfr[MT];
+            const int trow = lr >> 2, tcol = (lr & 3) * 4;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const bf16x4 lo = lds_tr16_b64(ys + (lq * 8 + trow) * PITCH + i * 16 + tcol);
+                const bf16x4 hi = lds_tr16_b64(ys + (lq * 8 + 4 + trow) * PITCH + i * 16 + tcol);
+                bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                af[i] = __builtin_bit_cast(mfma_bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const bf16x4 lo = lds_tr16_b64(xs + (lq * 8 + trow) * PITCH + j * 16 + tcol);
+                const bf16x4 hi = lds_tr16_b64(xs + (lq * 8 + 4 + trow) * PITCH + j * 16 + tcol);
+                bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[j] = __builtin_bit_cast(mfma_bf16x8, v);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        } else {
+#pragma unroll
+            for (int kk = 0; kk < BK / 4; ++kk) {
+                float af[NT], bfr[MT];
+#pragma unroll
+                for (int i = 0; i < NT; ++i) af[i] = ys[(kk * 4 + lq) * PITCH + i * 16 + lr];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) bfr[j] = xs[(kk * 4 + lq) * PITCH + j * 16 + lr];
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(af[i], bfr[j], acc[i][j], 0, 0, 0);
+            }
+        }
+        if (has_next) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+
+    // acc[i][j][q] = dw[n = n0 + wn*64 + i*16 + lq*4 + q][kc = kc0 + wk*64 + j*16 + lr]
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + i * 16 + lq * 4 + q;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int k = kc0 + wk * 64 + j * 16 + lr;
+                if (k < a.Ktot) atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q]);
+            }
+        }
+}
+
+template <typename T, int MODE>
+int launch_conv(const ConvArgs& base, hipStream_t st) {
+    ConvArgs a = base;
+    const bool aligned = (a.C % BK) == 0;
+    a.nblk_m = (a.M + 127) / 128;
+    auto go = [&](auto bn_tag, auto al_tag) {
+        constexpr int BN = decltype(bn_tag)::value;
+        constexpr bool AL = decltype(al_tag)::value;
+        a.nblk_n = (a.N + BN - 1) / BN;
+        const int grid = a.nblk_m * a.nblk_n;
+        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, AL, MODE>), dim3(grid), dim3(NTHREADS), 0, st, a);
+    };
+    using I128 = std::integral_constant<int, 128>;
+    using I64 = std::integral_constant<int, 64>;
+    using I32 = std::integral_constant<int, 32>;
+    const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+    if (aligned) {
+        if (bn == 128) go(I128{}, std::true_type{});
+        else if (bn == 64) go(I64{}, std::true_type{});
+        else go(I32{}, std::true_type{});
+    } else {
+        if (bn == 128) go(I128{}, std::false_type{});
+        else if (bn == 64) go(I64{}, std::false_type{});
+        else go(I32{}, std::false_type{});
+    }
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+}  // namespace
+
+extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
+    if (!d || !d->x || !d->w || !d->y) return DML_EINVAL;
+    if (d->dtype != DML_F32 && d->dtype != DML_BF16) return DML_EINVAL;
+    const int vec = d->dtype == DML_BF16 ? 8 : 4;
+    if (d->C % vec || d->ldx % vec) return DML_EALIGN;
+    if (d->pre_scale || d->pre_shift) return DML_EUNSUPPORTED;
+    if (d->mode != 0 && d->mode != 1) return DML_EINVAL;
+    if (d->mode == 1 && d->stride != 1 && d->stride != 2) return DML_EUNSUPPORTED;
+    if (d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0 || d->R <= 0 || d->S <= 0) return DML_EINVAL;
+    if ((int64_t)d->B * d->Ho * d->Wo >= (1ll << 31)) return DML_EINVAL;
+    if (d->stats && d->bias) return DML_EINVAL;
+    ConvArgs a;
+    a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.stats = d->stats;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
+    a.M = d->B * d->Ho * d->Wo;
+    a.Ktot = d->R * d->S * d->C;
+    a.y_f32 = d->y_f32; a.accum = d->accum;
+    a.nblk_n = a.nblk_m = 0;
+    a.div_wo = make_fastdiv((uint32_t)d->Wo);
+    a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+    a.div_c = make_fastdiv((uint32_t)d->C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (d->dtype == DML_BF16)
+        return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
+    return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
+}
+
+extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
+    if (!d || !d->x || !d->dy || !d->dw) return DML_EINVAL;
+    if (d->dtype != DML_F32 && d->dtype != DML_BF16) return DML_EINVAL;
+    const int vec = d->dtype == DML_BF16 ? 8 : 4;
+    if (d->C % vec || d->ldx % vec || d->N % vec || d->ldy % vec) return DML_EALIGN;
+    if ((int64_t)d->B * d->Ho * d->Wo >= (1ll << 31)) return DML_EINVAL;
+    WgradArgs a;
+    a.x = d->x; a.dy = d->dy; a.dw = d->dw;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
+    a.M = d->B * d->Ho * d->Wo;
+    a.Ktot = d->R * d->S * d->C;
+    a.nblk_n = (a.N + 127) / 128;
+    a.nblk_k = (a.Ktot + 127) / 128;
+    a.div_wo = make_fastdiv((uint32_t)d->Wo);
+    a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+    a.div_c = make_fastdiv((uint32_t)d->C);
+    const int tiles = (a.M + BK - 1) / BK;
+    int splitk = d->splitk;
+    if (splitk <= 0) {
+        // aim for >= 4 workgroups per CU, but keep >= 8 K tiles (256 pixels) per slice
+        const int base = a.nblk_n * a.nblk_k;
+        splitk = (1024 + base - 1) / base;
+        const int cap = (tiles + 7) / 8;
+        if (splitk > cap) splitk = cap;
+        if (splitk < 1) splitk = 1;
+    }
+    if (splitk > tiles) splitk = tiles > 0 ? tiles : 1;
+    a.slab_tiles = (tiles + splitk - 1) / splitk;
+    splitk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(a.nblk_n * a.nblk_k, splitk);
+    if (d->dtype == DML_BF16)
+        hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);
+    else
+        hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
+    DML_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,569 @@
+// Pixel -> prototype squared-Euclidean-distance head, its backward, the DML loss and the open-world
+// scores, for gfx950.  All HBM-bound (about 4 flop/byte): one lane owns 4 consecutive pixels so that
+// every global access is a 16-byte vector; prototypes sit in LDS and are read as broadcasts.
+//
+// Replaces network/utils.py:92-118 (the reference materialises a B x HW x K x C tensor twice),
+// utils/loss.py:34-42 / anomaly/models/models.py:42-78 (per-image per-class Python loop with host
+// round trips), and the host numpy post-processing of test_embedding.py:339-350,428-445 and
+// anomaly/eval_ood_traditional.py:301-305.
+#include "common.h"
+
+namespace {
+
+constexpr int MAXC = 32, MAXK = 33;   // embedding dim / prototype count supported by these kernels
+
+__device__ __forceinline__ void load_protos(float* sp, const float* __restrict__ protos, int n) {
+    for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = protos[i];
+    __syncthreads();
+}
+
+// logits for PX pixels held as f[c][px]; writes NCHW planes / argmax / dissum
+template <int PX, int CM>
+__device__ __forceinline__ void dist_and_store(const float (&f)[CM][PX], const float* sp, int C, int K,
+                                               float* __restrict__ logits, uint8_t* __restrict__ argmax,
+                                               float* __restrict__ dissum, int64_t plane, int64_t pix_in_img,
+                                               int64_t img_base_logits, int64_t img_pix_base) {
+    float best[PX], sum[PX];
+    int bi[PX];
+#pragma unroll
+    for (int p = 0; p < PX; ++p) { best[p] = -INFINITY; bi[p] = 0; sum[p] = 0.f; }
+    for (int k = 0; k < K; ++k) {
+        float d[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) d[p] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < C) {
+                const float m = sp[k * C + c];
+#pragma unroll
+                for (int p = 0; p < PX; ++p) {
+                    const float t = f[c][p] - m;
+                    d[p] += t * t;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const float lg = -d[p];
+            d[p] = lg;
+            sum[p] += d[p];
+            if (lg > best[p]) { best[p] = lg; bi[p] = k; }
+        }
+        if (logits != nullptr) {
+            float* o = logits + img_base_logits + (int64_t)k * plane + pix_in_img;
+            if constexpr (PX == 4) *reinterpret_cast<float4*>(o) = make_float4(d[0], d[1], d[2], d[3]);
+            else o[0] = d[0];
+        }
+    }
+    if (argmax != nullptr) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) argmax[img_pix_base + pix_in_img + p] = (uint8_t)bi[p];
+    }
+    if (dissum != nullptr) {
+#pragma unroll
+        for (int p = 0; p < PX; ++p) dissum[img_pix_base + pix_in_img + p] = -sum[p];
+    }
+}
+
+template <int PX, int CM>
+__device__ __forceinline__ void store_feats(const float (&f)[CM][PX], int C, float* __restrict__ feats,
+                                            int64_t pix_global) {
+    if (feats == nullptr) return;
+#pragma unroll
+    for (int p = 0; p < PX; ++p) {
+        float* o = feats + (pix_global + p) * C;
+        if ((C & 3) == 0) {
+#pragma unroll
+            for (int c = 0; c < CM; c += 4)
+                if (c < C) *reinterpret_cast<float4*>(o + c) = make_float4(f[c][p], f[c + 1][p], f[c + 2][p], f[c + 3][p]);
+        } else {
+#pragma unroll
+            for (int c = 0; c < CM; ++c)
+                if (c < C) o[c] = f[c][p];
+        }
+    }
+}
+
+// ---- standalone head: x NCHW (what F.interpolate returns) -> logits NCHW, features NHWC
+template <int PX, int CM>
+__global__ __launch_bounds__(256) void proto_dist_fwd_kernel(const float* __restrict__ x,
+                                                             const float* __restrict__ protos,
+                                                             float* __restrict__ logits, float* __restrict__ feats,
+                                                             uint8_t* __restrict__ argmax,
+                                                             float* __restrict__ dissum, int B, int C, int K,
+                                                             int64_t HW) {
+    __shared__ float sp[MAXK * MAXC];
+    load_protos(sp, protos, K * C);
+    const int64_t groups_per_img = HW / PX;
+    const int64_t total = (int64_t)B * groups_per_img;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / groups_per_img;
+        const int64_t pix = (i - b * groups_per_img) * PX;
+        float f[CM][PX];
+#pragma unroll
+        for (int c = 0; c < CM; ++c) {
+            if (c < C) {
+                const float* src = x + (b * C + c) * HW + pix;
+                if constexpr (PX == 4) {
+                    const float4 t = *reinterpret_cast<const float4*>(src);
+                    f[c][0] = t.x; f[c][1] = t.y; f[c][2] = t.z; f[c][3] = t.w;
+                } else {
+                    f[c][0] = src[0];
+                }
+            }
+        }
+        store_feats<PX, CM>(f, C, feats, b * HW + pix);
+        dist_and_store<PX, CM>(f, sp, C, K, logits, argmax, dissum, HW, pix, b * K * HW, b * HW);
+    }
+}
+
+// ---- fused: bilinear upsample of the low-resolution embedding e[B,h,w,C] + head at [H,W]
+template <int PX, int CM>
+__global__ __launch_bounds__(256) void upsample_dist_fwd_kernel(const float* __restrict__ e,
+                                                                const float* __restrict__ protos,
+                                                                float* __restrict__ logits,
+                                                                float* __restrict__ feats,
+                                                                uint8_t* __restrict__ argmax,
+                                                                float* __restrict__ dissum, int B, int h, int w,
+                                                                int C, int K, int H, int W, float sy, float sx) {
+    __shared__ float sp[MAXK * MAXC];
+    load_protos(sp, protos, K * C);
+    const int WG = W / PX;
+    const int64_t HW = (int64_t)H * W;
+    const int64_t total = (int64_t)B * H * WG;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int xg = (int)(i % WG);
+        int64_t t = i / WG;
+        const int Y = (int)(t % H);
+        const int b = (int)(t / H);
+        float sY = sy * ((float)Y + 0.5f) - 0.5f;
+        sY = sY < 0.f ? 0.f : sY;
+        const int y0 = min((int)sY, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float ly1 = sY - (float)y0, ly0 = 1.f - ly1;
+        const float* r0 = e + ((int64_t)b * h + y0) * w * C;
+        const float* r1 = e + ((int64_t)b * h + y1) * w * C;
+        float f[CM][PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int X = xg * PX + p;
+            float sX = sx * ((float)X + 0.5f) - 0.5f;
+            sX = sX < 0.f ? 0.f : sX;
+            const int x0 = min((int)sX, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float lx1 = sX - (float)x0, lx0 = 1.f - lx1;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                if (c < C)
+                    f[c][p] = ly0 * (lx0 * r0[x0 * C + c] + lx1 * r0[x1 * C + c]) +
+                              ly1 * (lx0 * r1[x0 * C + c] + lx1 * r1[x1 * C + c]);
+            }
+        }
+        const int64_t pix = (int64_t)Y * W + xg * PX;
+        store_feats<PX, CM>(f, C, feats, (int64_t)b * HW + pix);
+        dist_and_store<PX, CM>(f, sp, C, K, logits, argmax, dissum, HW, pix, (int64_t)b * K * HW, (int64_t)b * HW);
+    }
+}
+
+// ---- backward of the head: df = -2 sum_k g_k (f - m_k) (+ gfeats)
+template <int PX, int CM>
+__global__ __launch_bounds__(256) void proto_dist_bwd_kernel(const float* __restrict__ glogits,
+                                                             const float* __restrict__ gfeats,
+                                                             const float* __restrict__ feats,
+                                                             const float* __restrict__ protos,
+                                                             float* __restrict__ df, int B, int C, int K,
+                                                             int64_t HW) {
+    __shared__ float sp[MAXK * MAXC];
+    load_protos(sp, protos, K * C);
+    const int64_t groups_per_img = HW / PX;
+    const int64_t total = (int64_t)B * groups_per_img;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / groups_per_img;
+        const int64_t pix = (i - b * groups_per_img) * PX;
+        float gs[PX];                 // sum_k g_k
+        float gm[CM][PX];           // sum_k g_k m_kc
+#pragma unroll
+        for (int p = 0; p < PX; ++p) gs[p] = 0.f;
+#pragma unroll
+        for (int c = 0; c < CM; ++c)
+#pragma unroll
+            for (int p = 0; p < PX; ++p) gm[c][p] = 0.f;
+        for (int k = 0; k < K; ++k) {
+            float g[PX];
+            const float* src = glogits + (b * K + k) * HW + pix;
+            if constexpr (PX == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src);
+                g[0] = t.x; g[1] = t.y; g[2] = t.z; g[3] = t.w;
+            } else {
+                g[0] = src[0];
+            }
+#pragma unroll
+            for (int p = 0; p < PX; ++p) gs[p] += g[p];
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                if (c < C) {
+                    const float m = sp[k * C + c];
+#pragma unroll
+                    for (int p = 0; p < PX; ++p) gm[c][p] += g[p] * m;
+                }
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            const int64_t o = (b * HW + pix + p) * C;
+#pragma unroll
+            for (int c = 0; c < CM; ++c) {
+                if (c < C) {
+                    float v = -2.f * (gs[p] * feats[o + c] - gm[c][p]);
+                    if (gfeats != nullptr) v += gfeats[o + c];
+                    df[o + c] = v;
+                }
+            }
+        }
+    }
+}
+
+// ---- argmax / max-softmax-probability
+__global__ __launch_bounds__(256) void argmax_msp_kernel(const float* __restrict__ logits,
+                                                         int64_t* __restrict__ preds, float* __restrict__ msp,
+                                                         int B, int K, int64_t HW) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, pix = i - b * HW;
+        const float* src = logits + b * K * HW + pix;
+        float best = src[0];
+        int bi = 0;
+        for (int k = 1; k < K; ++k) {
+            const float v = src[(int64_t)k * HW];
+            if (v > best) { best = v; bi = k; }
+        }
+        if (preds) preds[i] = bi;
+        if (msp) {
+            float den = 0.f;
+            for (int k = 0; k < K; ++k) den += expf(src[(int64_t)k * HW] - best);
+            msp[i] = 1.f - 1.f / den;
+        }
+    }
+}
+
+// ---- dissum score: clip(-sum_k logit_k), then per-image min-max normalisation
+__device__ __forceinline__ void atomic_min_f(float* addr, float v) {
+    if (v >= 0.f) atomicMin(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMax(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+__device__ __forceinline__ void atomic_max_f(float* addr, float v) {
+    if (v >= 0.f) atomicMax(reinterpret_cast<int*>(addr), __float_as_int(v));
+    else atomicMin(reinterpret_cast<unsigned*>(addr), __float_as_uint(v));
+}
+__global__ void minmax_init_kernel(float* work, int B) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < B) { work[2 * i] = INFINITY; work[2 * i + 1] = -INFINITY; }
+}
+__global__ __launch_bounds__(256) void dissum_kernel(const float* __restrict__ logits, float* __restrict__ score,
+                                                     float* work, int K, int64_t HW, float clip, int inclusive) {
+    __shared__ float smin[4], smax[4];
+    const int b = blockIdx.y;
+    float lo = INFINITY, hi = -INFINITY;
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < HW;
+         pix += (int64_t)gridDim.x * blockDim.x) {
+        const float* src = logits + (int64_t)b * K * HW + pix;
+        float s = 0.f;
+        for (int k = 0; k < K; ++k) s += src[(int64_t)k * HW];
+        s = -s;
+        if (inclusive ? (s >= clip) : (s > clip)) s = clip;
+        score[(int64_t)b * HW + pix] = s;
+        lo = fminf(lo, s);
+        hi = fmaxf(hi, s);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        lo = fminf(lo, __shfl_xor(lo, o, 64));
+        hi = fmaxf(hi, __shfl_xor(hi, o, 64));
+    }
+    if ((threadIdx.x & 63) == 0) { smin[threadIdx.x >> 6] = lo; smax[threadIdx.x >> 6] = hi; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int i = 1; i < 4; ++i) { lo = fminf(lo, smin[i]); hi = fmaxf(hi, smax[i]); }
+        lo = fminf(smin[0], lo); hi = fmaxf(smax[0], hi);
+        if (lo <= hi) { atomic_min_f(work + 2 * b, lo); atomic_max_f(work + 2 * b + 1, hi); }
+    }
+}
+__global__ __launch_bounds__(256) void minmax_norm_kernel(float* __restrict__ score, const float* work,
+                                                          int64_t HW) {
+    const int b = blockIdx.y;
+    const float lo = work[2 * b], hi = work[2 * b + 1];
+    const float den = hi - lo;
+    for (int64_t pix = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pix < HW;
+         pix += (int64_t)gridDim.x * blockDim.x) {
+        float* p = score + (int64_t)b * HW + pix;
+        *p = (*p - lo) / den;
+    }
+}
+
+__global__ __launch_bounds__(256) void novel_relabel_kernel(const float* __restrict__ feats,
+                                                            const float* __restrict__ logits,
+                                                            const float* __restrict__ proto,
+                                                            int64_t* __restrict__ preds, int B, int C, int K,
+                                                            int64_t HW, float thresh, int64_t new_label) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, pix = i - b * HW;
+        float d = 0.f;
+        for (int c = 0; c < C; ++c) {
+            const float t = feats[i * C + c] - proto[c];
+            d += t * t;
+        }
+        d = -d;
+        const float* src = logits + b * K * HW + pix;
+        float best = src[0];
+        for (int k = 1; k < K; ++k) best = fmaxf(best, src[(int64_t)k * HW]);
+        if (d > thresh && d > best) preds[i] = new_label;
+    }
+}
+
+// ---- DML loss
+// block partial = (sum nll, #valid, sum -logit_y over valid, #correct)
+__global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ logits,
+                                                       const int64_t* __restrict__ labels,
+                                                       float* __restrict__ partials, int B, int K, int64_t HW,
+                                                       int64_t ignore_index) {
+    __shared__ float sh[4][4];
+    float s_nll = 0.f, s_cnt = 0.f, s_var = 0.f, s_ok = 0.f;
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lab = labels[i];
+        if (lab == ignore_index) continue;
+        const int64_t b = i / HW, pix = i - b * HW;
+        const float* src = logits + b * K * HW + pix;
+        float mx = src[0];
+        int bi = 0;
+        for (int k = 1; k < K; ++k) {
+            const float v = src[(int64_t)k * HW];
+            if (v > mx) { mx = v; bi = k; }
+        }
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) den += expf(src[(int64_t)k * HW] - mx);
+        const float own = src[lab * HW];
+        s_nll += (mx - own) + logf(den);
+        s_cnt += 1.f;
+        s_var += -own;
+        s_ok += (bi == (int)lab) ? 1.f : 0.f;
+    }
+    s_nll = wave_sum(s_nll); s_cnt = wave_sum(s_cnt); s_var = wave_sum(s_var); s_ok = wave_sum(s_ok);
+    if ((threadIdx.x & 63) == 0) {
+        const int wv = threadIdx.x >> 6;
+        sh[wv][0] = s_nll; sh[wv][1] = s_cnt; sh[wv][2] = s_var; sh[wv][3] = s_ok;
+    }
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        partials[(int64_t)blockIdx.x * 4 + q] = sh[0][q] + sh[1][q] + sh[2][q] + sh[3][q];
+    }
+}
+__global__ __launch_bounds__(256) void loss_sum_kernel(const float* __restrict__ partials, int nblocks,
+                                                       double* sums, double inv_hw) {
+    __shared__ double sh[4][4];
+    double acc[4] = {0, 0, 0, 0};
+    for (int i = threadIdx.x; i < nblocks; i += blockDim.x)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) acc[q] += (double)partials[(int64_t)i * 4 + q];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) acc[q] = wave_sum_d(acc[q]);
+    if ((threadIdx.x & 63) == 0)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sh[threadIdx.x >> 6][q] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < 4) {
+        const int q = threadIdx.x;
+        double v = sh[0][q] + sh[1][q] + sh[2][q] + sh[3][q];
+        if (q == 2) v *= inv_hw;       // VAR = sum_i (1/HW_i) sum_valid(-logit_y), HW_i identical in a batch
+        sums[q] = v;
+    }
+}
+__global__ void loss_finalize_kernel(const double* sums, float* loss, float alpha, float n_images) {
+    if (threadIdx.x == 0 && blockIdx.x == 0) {
+        const double ce = sums[0] / sums[1];          // NaN when nothing is valid, as torch
+        *loss = (float)((ce + (double)alpha * sums[2]) / (double)n_images);
+    }
+}
+__global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits,
+                                                       const int64_t* __restrict__ labels,
+                                                       const double* __restrict__ sums,
+                                                       const float* __restrict__ gout,
+                                                       float* __restrict__ glogits, int B, int K, int64_t HW,
+                                                       int64_t ignore_index, float alpha, float n_images) {
+    const float go = gout ? *gout : 1.f;
+    const float w_ce = go / ((float)sums[1] * n_images);
+    const float w_var = go * alpha / ((float)HW * n_images);
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t lab = labels[i];
+        const int64_t b = i / HW, pix = i - b * HW;
+        const float* src = logits + b * K * HW + pix;
+        float* dst = glogits + b * K * HW + pix;
+        if (lab == ignore_index) {
+            for (int k = 0; k < K; ++k) dst[(int64_t)k * HW] = 0.f;
+            continue;
+        }
+        float mx = src[0];
+        for (int k = 1; k < K; ++k) mx = fmaxf(mx, src[(int64_t)k * HW]);
+        float den = 0.f;
+        for (int k = 0; k < K; ++k) den += expf(src[(int64_t)k * HW] - mx);
+        const float inv = 1.f / den;
+        for (int k = 0; k < K; ++k) {
+            const float pk = expf(src[(int64_t)k * HW] - mx) * inv;
+            float g = w_ce * pk;
+            if (k == (int)lab) g -= w_ce + w_var;
+            dst[(int64_t)k * HW] = g;
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dml_proto_dist_fwd(const float* x_nchw, const float* protos, float* logits, float* feats,
+                                  uint8_t* argmax, float* dissum, int B, int C, int K, int H, int W,
+                                  void* stream) {
+    if (!x_nchw || !protos || B <= 0 || H <= 0 || W <= 0) return DML_EINVAL;
+    if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
+    const int64_t HW = (int64_t)H * W;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (HW % 4 == 0) {
+        const int grid = grid_for((int64_t)B * HW / 4, 256, 256 * 16);
+        if (C <= 16) hipLaunchKernelGGL((proto_dist_fwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, x_nchw, protos, logits, feats,
+                           argmax, dissum, B, C, K, HW);
+        else hipLaunchKernelGGL((proto_dist_fwd_kernel<4, 32>), dim3(grid), dim3(256), 0, st, x_nchw, protos, logits, feats,
+                           argmax, dissum, B, C, K, HW);
+    } else {
+        const int grid = grid_for((int64_t)B * HW, 256, 256 * 16);
+        if (C <= 16) hipLaunchKernelGGL((proto_dist_fwd_kernel<1, 16>), dim3(grid), dim3(256), 0, st, x_nchw, protos, logits, feats,
+                           argmax, dissum, B, C, K, HW);
+        else hipLaunchKernelGGL((proto_dist_fwd_kernel<1, 32>), dim3(grid), dim3(256), 0, st, x_nchw, protos, logits, feats,
+                           argmax, dissum, B, C, K, HW);
+    }
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_upsample_dist_fwd(const float* e, const float* protos, float* logits, float* feats,
+                                     uint8_t* argmax, float* dissum, int B, int h, int w, int C, int K, int H,
+                                     int W, void* stream) {
+    if (!e || !protos || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DML_EINVAL;
+    if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (W % 4 == 0) {
+        const int grid = grid_for((int64_t)B * H * (W / 4), 256, 256 * 16);
+        if (C <= 16) hipLaunchKernelGGL((upsample_dist_fwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, e, protos, logits, feats,
+                           argmax, dissum, B, h, w, C, K, H, W, sy, sx);
+        else hipLaunchKernelGGL((upsample_dist_fwd_kernel<4, 32>), dim3(grid), dim3(256), 0, st, e, protos, logits, feats,
+                           argmax, dissum, B, h, w, C, K, H, W, sy, sx);
+    } else {
+        const int grid = grid_for((int64_t)B * H * W, 256, 256 * 16);
+        if (C <= 16) hipLaunchKernelGGL((upsample_dist_fwd_kernel<1, 16>), dim3(grid), dim3(256), 0, st, e, protos, logits, feats,
+                           argmax, dissum, B, h, w, C, K, H, W, sy, sx);
+        else hipLaunchKernelGGL((upsample_dist_fwd_kernel<1, 32>), dim3(grid), dim3(256), 0, st, e, protos, logits, feats,
+                           argmax, dissum, B, h, w, C, K, H, W, sy, sx);
+    }
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_proto_dist_bwd(const float* glogits, const float* gfeats, const float* feats,
+                                  const float* protos, float* df, int B, int C, int K, int H, int W,
+                                  void* stream) {
+    if (!glogits || !feats || !protos || !df) return DML_EINVAL;
+    if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
+    const int64_t HW = (int64_t)H * W;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (HW % 4 == 0) {
+        const int grid = grid_for((int64_t)B * HW / 4, 256, 256 * 16);
+        if (C <= 16) hipLaunchKernelGGL((proto_dist_bwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, glogits, gfeats, feats, protos,
+                           df, B, C, K, HW);
+        else hipLaunchKernelGGL((proto_dist_bwd_kernel<4, 32>), dim3(grid), dim3(256), 0, st, glogits, gfeats, feats, protos,
+                           df, B, C, K, HW);
+    } else {
+        const int grid = grid_for((int64_t)B * HW, 256, 256 * 16);
+        if (C <= 16) hipLaunchKernelGGL((proto_dist_bwd_kernel<1, 16>), dim3(grid), dim3(256), 0, st, glogits, gfeats, feats, protos,
+                           df, B, C, K, HW);
+        else hipLaunchKernelGGL((proto_dist_bwd_kernel<1, 32>), dim3(grid), dim3(256), 0, st, glogits, gfeats, feats, protos,
+                           df, B, C, K, HW);
+    }
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_argmax_msp(const float* logits, int64_t* preds, float* msp, int B, int K, int H, int W,
+                              void* stream) {
+    if (!logits || B <= 0 || K <= 0) return DML_EINVAL;
+    const int64_t HW = (int64_t)H * W;
+    hipLaunchKernelGGL(argmax_msp_kernel, dim3(grid_for(B * HW, 256, 256 * 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), logits, preds, msp, B, K, HW);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_dissum_score(const float* logits, float* score, float* work, int B, int K, int H, int W,
+                                float clip, int inclusive, void* stream) {
+    if (!logits || !score || !work || B <= 0 || K <= 0) return DML_EINVAL;
+    const int64_t HW = (int64_t)H * W;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(minmax_init_kernel, dim3((B + 63) / 64), dim3(64), 0, st, work, B);
+    dim3 grid(grid_for(HW, 256, 1024), B);
+    hipLaunchKernelGGL(dissum_kernel, grid, dim3(256), 0, st, logits, score, work, K, HW, clip, inclusive);
+    hipLaunchKernelGGL(minmax_norm_kernel, grid, dim3(256), 0, st, score, work, HW);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_novel_relabel(const float* feats, const float* logits, const float* proto, int64_t* preds,
+                                 int B, int C, int K, int H, int W, float thresh, int64_t new_label,
+                                 void* stream) {
+    if (!feats || !logits || !proto || !preds) return DML_EINVAL;
+    const int64_t HW = (int64_t)H * W;
+    hipLaunchKernelGGL(novel_relabel_kernel, dim3(grid_for(B * HW, 256, 256 * 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), feats, logits, proto, preds, B, C, K, HW, thresh,
+                       new_label);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+#define DML_LOSS_BLOCKS 2048
+
+extern "C" int dml_loss_fwd(const float* logits, const int64_t* labels, double* sums, float* block_partials,
+                            int B, int K, int H, int W, int64_t ignore_index, void* stream) {
+    if (!logits || !labels || !sums || !block_partials || B <= 0 || K <= 0) return DML_EINVAL;
+    const int64_t HW = (int64_t)H * W;
+    const int grid = grid_for(B * HW, 256, DML_LOSS_BLOCKS);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(loss_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, labels, block_partials, B, K, HW,
+                       ignore_index);
+    hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, st, block_partials, grid, sums, 1.0 / (double)HW);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_loss_finalize(const double* sums, float* loss, float alpha, float n_images, void* stream) {
+    if (!sums || !loss) return DML_EINVAL;
+    hipLaunchKernelGGL(loss_finalize_kernel, dim3(1), dim3(64), 0, static_cast<hipStream_t>(stream), sums, loss,
+                       alpha, n_images);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_loss_bwd(const float* logits, const int64_t* labels, const double* sums, const float* gout,
+                            float* glogits, int B, int K, int H, int W, int64_t ignore_index, float alpha,
+                            float n_images, void* stream) {
+    if (!logits || !labels || !sums || !glogits) return DML_EINVAL;
+    const int64_t HW = (int64_t)H * W;
+    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(B * HW, 256, 256 * 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), logits, labels, sums, gout, glogits, B, K, HW,
+                       ignore_index, alpha, n_images);
+    DML_LAUNCH_CHECK();
+    return 0;
+}

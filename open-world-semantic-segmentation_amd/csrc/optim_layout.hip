@@ -1,0 +1,172 @@
+// Optimizer step and layout/precision conversion kernels for gfx950 (all HBM-bound).
+//
+// dml_sgd_step replaces torch.optim.SGD.step as configured at main_embedding.py:385-388
+// (momentum 0.9, weight decay added to the gradient before the momentum update, two LR groups).
+// The remaining kernels exist because the MI355X design keeps fp32 master weights in K-R-S-C order
+// and feeds the MFMA kernels from bf16/fp32 compute copies (and transposed copies for dgrad).
+#include "common.h"
+
+namespace {
+
+__global__ __launch_bounds__(256) void sgd_kernel(float* __restrict__ p, const float* __restrict__ g,
+                                                  float* __restrict__ v, int64_t n, float lr, float mu, float wd,
+                                                  float gscale) {
+    const int64_t n4 = n >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        float4 pp = reinterpret_cast<float4*>(p)[i];
+        const float4 gg = reinterpret_cast<const float4*>(g)[i];
+        float4 vv = reinterpret_cast<float4*>(v)[i];
+        vv.x = mu * vv.x + (gscale * gg.x + wd * pp.x);
+        vv.y = mu * vv.y + (gscale * gg.y + wd * pp.y);
+        vv.z = mu * vv.z + (gscale * gg.z + wd * pp.z);
+        vv.w = mu * vv.w + (gscale * gg.w + wd * pp.w);
+        pp.x -= lr * vv.x; pp.y -= lr * vv.y; pp.z -= lr * vv.z; pp.w -= lr * vv.w;
+        reinterpret_cast<float4*>(v)[i] = vv;
+        reinterpret_cast<float4*>(p)[i] = pp;
+    }
+    // tail
+    const int64_t base = n4 << 2;
+    const int64_t t = base + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < n) {
+        const float d = gscale * g[t] + wd * p[t];
+        const float nv = mu * v[t] + d;
+        v[t] = nv;
+        p[t] -= lr * nv;
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, int64_t n, float value) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        p[i] = value;
+}
+
+// master [N][RS][Cm] fp32 -> w [N][RS][Cp] and wt [Cp][RS][N]
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restrict__ src, T* __restrict__ w,
+                                                          T* __restrict__ wt, int N, int RS, int Cm, int Cp) {
+    const int64_t total = (int64_t)N * RS * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const int64_t t = i / Cp;
+        const int rs = (int)(t % RS);
+        const int n = (int)(t / RS);
+        const float v = c < Cm ? src[((int64_t)n * RS + rs) * Cm + c] : 0.f;
+        Elem<T>::st(w + i, v);
+        if (wt != nullptr) Elem<T>::st(wt + ((int64_t)c * RS + rs) * N + n, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void unpad_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                          int N, int RS, int Cm, int Cp) {
+    const int64_t total = (int64_t)N * RS * Cm;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cm);
+        const int64_t t = i / Cm;
+        dst[i] += src[t * Cp + c];
+    }
+}
+
+// db[n] += sum_m dy[m][n]; one block per 64 rows-lanes x N columns
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t M,
+                                                        int N, int ldy) {
+    // thread -> column n = tid % N (N <= 256), row lane = tid / N
+    const int n = threadIdx.x % N, rl = threadIdx.x / N, rt = blockDim.x / N;
+    float acc = 0.f;
+    if (rl < rt)
+        for (int64_t m = (int64_t)blockIdx.x * rt + rl; m < M; m += (int64_t)gridDim.x * rt)
+            acc += Elem<T>::ld(dy + m * ldy + n);
+    if (rl < rt) atomicAdd(db + n, acc);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, T* __restrict__ y, int B,
+                                                         int C, int64_t HW, int Cp) {
+    const int64_t total = (int64_t)B * HW;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / HW, pix = i - b * HW;
+        for (int c = 0; c < Cp; ++c) {
+            const float v = c < C ? x[(b * C + c) * HW + pix] : 0.f;
+            Elem<T>::st(y + i * Cp + c, v);
+        }
+    }
+}
+
+}  // namespace
+
+extern "C" int dml_abi_version(void) { return DML_ABI_VERSION; }
+extern "C" const char* dml_target_arch(void) { return "gfx950"; }
+
+extern "C" int dml_sgd_step(float* p, const float* g, float* v, int64_t n, float lr, float momentum,
+                            float weight_decay, float gscale, void* stream) {
+    if (!p || !g || !v || n <= 0) return DML_EINVAL;
+    if (((uintptr_t)p | (uintptr_t)g | (uintptr_t)v) & 15) return DML_EALIGN;
+    hipLaunchKernelGGL(sgd_kernel, dim3(grid_for(n / 4 + 4, 256)), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       p, g, v, n, lr, momentum, weight_decay, gscale);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_fill_f32(float* p, int64_t n, float value, void* stream) {
+    if (!p || n <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p, n,
+                       value);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_prep_weight(const float* w_master, void* w, void* wt, int N, int RS, int Cm, int Cp, int dtype,
+                               void* stream) {
+    if (!w_master || !w || N <= 0 || RS <= 0 || Cm <= 0 || Cp < Cm) return DML_EINVAL;
+    const int grid = grid_for((int64_t)N * RS * Cp, 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(prep_weight_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, w_master, (bf16_t*)w,
+                           (bf16_t*)wt, N, RS, Cm, Cp);
+    else
+        hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w_master, (float*)w, (float*)wt,
+                           N, RS, Cm, Cp);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int Cm, int Cp, void* stream) {
+    if (!src || !dst || Cp < Cm) return DML_EINVAL;
+    hipLaunchKernelGGL(unpad_wgrad_kernel, dim3(grid_for((int64_t)N * RS * Cm, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, dst, N, RS, Cm, Cp);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bias_grad(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, void* stream) {
+    if (!dy || !db || M <= 0 || N <= 0 || N > 256) return DML_EINVAL;
+    const int rt = 256 / N;
+    const int grid = grid_for((M + rt - 1) / rt, 1, 512);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, db, M, N, ldy);
+    else
+        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, db, M, N, ldy);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int Cp, int dtype,
+                              void* stream) {
+    if (!x_nchw || !y_nhwc || B <= 0 || C <= 0 || Cp < C) return DML_EINVAL;
+    const int64_t HW = (int64_t)H * W;
+    const int grid = grid_for(B * HW, 256, 256 * 16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(pack_input_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, x_nchw, (bf16_t*)y_nhwc, B, C, HW,
+                           Cp);
+    else
+        hipLaunchKernelGGL(pack_input_kernel<float>, dim3(grid), dim3(256), 0, st, x_nchw, (float*)y_nhwc, B, C, HW,
+                           Cp);
+    DML_LAUNCH_CHECK();
+    return 0;
+}

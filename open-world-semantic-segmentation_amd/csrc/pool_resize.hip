@@ -1,0 +1,380 @@
+// NHWC pooling and bilinear resize kernels for gfx950 (HBM-bound; 16-byte vectors per lane).
+//
+// Replaces nn.MaxPool2d(3,2,1) (network/backbone/resnet.py:143), nn.AdaptiveAvgPool2d(1)
+// (network/utils.py:320) and F.interpolate(mode='bilinear', align_corners=False)
+// (network/utils.py:30,329; the 1x1 -> HxW case of :329 is a broadcast).
+#include "common.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------- max pool 3x3 s2 p1
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, T* __restrict__ y,
+                                                          uint8_t* __restrict__ argmax, int B, int H, int W,
+                                                          int C, int Ho, int Wo) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = C / V;
+    const int64_t total = (int64_t)B * Ho * Wo * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t p = i / CV;
+        const int xo = (int)(p % Wo); p /= Wo;
+        const int yo = (int)(p % Ho);
+        const int b = (int)(p / Ho);
+        float best[V];
+        int idx[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) { best[q] = -INFINITY; idx[q] = -1; }
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int yi = yo * 2 - 1 + r;
+            if ((unsigned)yi >= (unsigned)H) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int xi = xo * 2 - 1 + s;
+                if ((unsigned)xi >= (unsigned)W) continue;
+                float v[V];
+                Vec16<T>::load(x + (((int64_t)b * H + yi) * W + xi) * C + cv * V, v);
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    if (idx[q] < 0 || v[q] > best[q] || v[q] != v[q]) { best[q] = v[q]; idx[q] = r * 3 + s; }
+                }
+            }
+        }
+        const int64_t o = (((int64_t)b * Ho + yo) * Wo + xo) * C + cv * V;
+        Vec16<T>::store(y + o, best);
+        if (argmax != nullptr) {
+#pragma unroll
+            for (int q = 0; q < V; ++q) argmax[o + q] = (uint8_t)idx[q];
+        }
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ dy,
+                                                          const uint8_t* __restrict__ argmax, T* __restrict__ dx,
+                                                          int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = C / V;
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t p = i / CV;
+        const int xi = (int)(p % W); p /= W;
+        const int yi = (int)(p % H);
+        const int b = (int)(p / H);
+        float acc[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] = 0.f;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ty = yi + 1 - r;
+            if (ty < 0 || (ty & 1)) continue;
+            const int yo = ty >> 1;
+            if (yo >= Ho) continue;
+#pragma unroll
+            for (int s = 0; s < 3; ++s) {
+                const int tx = xi + 1 - s;
+                if (tx < 0 || (tx & 1)) continue;
+                const int xo = tx >> 1;
+                if (xo >= Wo) continue;
+                const int64_t o = (((int64_t)b * Ho + yo) * Wo + xo) * C + cv * V;
+                float g[V];
+                Vec16<T>::load(dy + o, g);
+                uint8_t am[V];
+                if (V == 8) {
+                    const uint2 t = *reinterpret_cast<const uint2*>(argmax + o);
+                    const uint32_t w[2] = {t.x, t.y};
+#pragma unroll
+                    for (int q = 0; q < 8; ++q) am[q] = (uint8_t)(w[q >> 2] >> ((q & 3) * 8));
+                } else {
+                    const uint32_t t = *reinterpret_cast<const uint32_t*>(argmax + o);
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) am[q] = (uint8_t)(t >> (q * 8));
+                }
+#pragma unroll
+                for (int q = 0; q < V; ++q) acc[q] += (am[q] == r * 3 + s) ? g[q] : 0.f;
+            }
+        }
+        Vec16<T>::store(dx + (((int64_t)b * H + yi) * W + xi) * C + cv * V, acc);
+    }
+}
+
+// ------------------------------------------------------------------- reductions over HW / broadcasts
+// out[b][c] = scale * sum_{p < HW} x[b][p][c];  block = 32 vector columns x 8 row lanes
+template <typename T>
+__global__ __launch_bounds__(256) void reduce_hw_kernel(const T* __restrict__ x, T* __restrict__ out, int HW,
+                                                        int C, int ldx, float scale) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float sh[8][32 * V];
+    const int col = threadIdx.x & 31, rl = threadIdx.x >> 5;
+    const int b = blockIdx.x;
+    const int c = (blockIdx.y * 32 + col) * V;
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    if (c < C) {
+        for (int p = rl; p < HW; p += 8) {
+            float v[V];
+            Vec16<T>::load(x + ((int64_t)b * HW + p) * ldx + c, v);
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += v[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) sh[rl][col * V + q] = acc[q];
+    __syncthreads();
+    if (rl == 0 && c < C) {
+#pragma unroll
+        for (int r = 1; r < 8; ++r)
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += sh[r][col * V + q];
+#pragma unroll
+        for (int q = 0; q < V; ++q) acc[q] *= scale;
+        Vec16<T>::store(out + (int64_t)b * C + c, acc);
+    }
+}
+
+// z[b][p][c] (op)= alpha * v[b][c]
+template <typename T, bool ACCUM>
+__global__ __launch_bounds__(256) void broadcast_hw_kernel(const T* __restrict__ v, T* __restrict__ z, int B,
+                                                           int HW, int C, int ldz, float alpha) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = C / V;
+    const int64_t total = (int64_t)B * HW * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        const int64_t p = i / CV;
+        const int b = (int)(p / HW);
+        float s[V];
+        Vec16<T>::load(v + (int64_t)b * C + cv * V, s);
+#pragma unroll
+        for (int q = 0; q < V; ++q) s[q] *= alpha;
+        T* zp = z + p * ldz + cv * V;
+        if (ACCUM) {
+            float o[V];
+            Vec16<T>::load(zp, o);
+#pragma unroll
+            for (int q = 0; q < V; ++q) s[q] += o[q];
+        }
+        Vec16<T>::store(zp, s);
+    }
+}
+
+// ------------------------------------------------------------------------------- bilinear resize
+// PyTorch area_pixel_compute_source_index, align_corners = False:
+//   src = max(scale * (dst + 0.5) - 0.5, 0), i0 = (int)src, i1 = i0 + (i0 < in - 1), lambda = src - i0
+struct Lerp {
+    int i0, i1;
+    float l0, l1;
+};
+__device__ __forceinline__ Lerp src_index(int dst, float scale, int in) {
+    float s = scale * ((float)dst + 0.5f) - 0.5f;
+    s = s < 0.f ? 0.f : s;
+    Lerp r;
+    r.i0 = min((int)s, in - 1);
+    r.i1 = r.i0 + (r.i0 < in - 1 ? 1 : 0);
+    r.l1 = s - (float)r.i0;
+    r.l0 = 1.f - r.l1;
+    return r;
+}
+
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bilinear_fwd_kernel(const TI* __restrict__ x, TO* __restrict__ y, int B,
+                                                           int h, int w, int H, int W, int C, int ldx, int ldy,
+                                                           float sy, float sx) {
+    constexpr int V = 4;   // 4 channels per thread (16 B fp32 / 8 B bf16)
+    const int CV = C / V;
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t p = i / CV;
+        const int X = (int)(p % W); p /= W;
+        const int Y = (int)(p % H);
+        const int b = (int)(p / H);
+        const Lerp ly = src_index(Y, sy, h), lx = src_index(X, sx, w);
+        const TI* base = x + (int64_t)b * h * w * ldx + cv * V;
+        float o[V];
+#pragma unroll
+        for (int q = 0; q < V; ++q) {
+            const float v00 = Elem<TI>::ld(base + ((int64_t)ly.i0 * w + lx.i0) * ldx + q);
+            const float v01 = Elem<TI>::ld(base + ((int64_t)ly.i0 * w + lx.i1) * ldx + q);
+            const float v10 = Elem<TI>::ld(base + ((int64_t)ly.i1 * w + lx.i0) * ldx + q);
+            const float v11 = Elem<TI>::ld(base + ((int64_t)ly.i1 * w + lx.i1) * ldx + q);
+            o[q] = ly.l0 * (lx.l0 * v00 + lx.l1 * v01) + ly.l1 * (lx.l0 * v10 + lx.l1 * v11);
+        }
+        TO* yp = y + (((int64_t)b * H + Y) * W + X) * ldy + cv * V;
+#pragma unroll
+        for (int q = 0; q < V; ++q) Elem<TO>::st(yp + q, o[q]);
+    }
+}
+
+// gather form of the transpose: every source pixel sums the destination pixels that read it
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void bilinear_bwd_kernel(const TI* __restrict__ dy, TO* __restrict__ dx, int B,
+                                                           int h, int w, int H, int W, int C, int lddy, int lddx,
+                                                           float sy, float sx) {
+    constexpr int V = 4;
+    const int CV = C / V;
+    const int64_t total = (int64_t)B * h * w * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t p = i / CV;
+        const int xs = (int)(p % w); p /= w;
+        const int ys = (int)(p % h);
+        const int b = (int)(p / h);
+        // destination rows whose source coordinate can fall in (ys-1, ys+1)
+        const int Y0 = max(0, (int)floorf(((float)ys - 0.5f) / sy - 0.5f) - 1);
+        const int Y1 = min(H - 1, (int)ceilf(((float)ys + 1.5f) / sy - 0.5f) + 1);
+        const int X0 = max(0, (int)floorf(((float)xs - 0.5f) / sx - 0.5f) - 1);
+        const int X1 = min(W - 1, (int)ceilf(((float)xs + 1.5f) / sx - 0.5f) + 1);
+        float acc[V] = {0.f, 0.f, 0.f, 0.f};
+        for (int Y = Y0; Y <= Y1; ++Y) {
+            const Lerp ly = src_index(Y, sy, h);
+            const float wy = (ly.i0 == ys ? ly.l0 : 0.f) + (ly.i1 == ys ? ly.l1 : 0.f);
+            if (wy == 0.f) continue;
+            for (int X = X0; X <= X1; ++X) {
+                const Lerp lx = src_index(X, sx, w);
+                const float wx = (lx.i0 == xs ? lx.l0 : 0.f) + (lx.i1 == xs ? lx.l1 : 0.f);
+                if (wx == 0.f) continue;
+                const TI* g = dy + (((int64_t)b * H + Y) * W + X) * lddy + cv * V;
+#pragma unroll
+                for (int q = 0; q < V; ++q) acc[q] += wy * wx * Elem<TI>::ld(g + q);
+            }
+        }
+        TO* o = dx + (((int64_t)b * h + ys) * w + xs) * lddx + cv * V;
+#pragma unroll
+        for (int q = 0; q < V; ++q) Elem<TO>::st(o + q, acc[q]);
+    }
+}
+
+inline bool vec_ok(int dtype, int a) { return a % (dtype == DML_BF16 ? 8 : 4) == 0; }
+
+}  // namespace
+
+extern "C" int dml_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int B, int H, int W, int C,
+                                    int dtype, void* stream) {
+    if (!x || !y || B <= 0 || H <= 0 || W <= 0) return DML_EINVAL;
+    if (!vec_ok(dtype, C)) return DML_EALIGN;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    const int grid = grid_for((int64_t)B * Ho * Wo * (C / V), 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
+                           argmax, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_fwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)x, (float*)y,
+                           argmax, B, H, W, C, Ho, Wo);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void* dx, int B, int H, int W, int C,
+                                    int dtype, void* stream) {
+    if (!dy || !argmax || !dx) return DML_EINVAL;
+    if (!vec_ok(dtype, C)) return DML_EALIGN;
+    const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    const int grid = grid_for((int64_t)B * H * W * (C / V), 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, argmax,
+                           (bf16_t*)dx, B, H, W, C, Ho, Wo);
+    else
+        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, argmax,
+                           (float*)dx, B, H, W, C, Ho, Wo);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+static int launch_reduce_hw(const void* x, void* out, int B, int HW, int C, int ldx, int dtype, float scale,
+                            void* stream) {
+    if (!x || !out || B <= 0 || HW <= 0) return DML_EINVAL;
+    if (!vec_ok(dtype, C) || !vec_ok(dtype, ldx)) return DML_EALIGN;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    dim3 grid(B, (C / V + 31) / 32);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(reduce_hw_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, HW, C,
+                           ldx, scale);
+    else
+        hipLaunchKernelGGL(reduce_hw_kernel<float>, grid, dim3(256), 0, st, (const float*)x, (float*)out, HW, C,
+                           ldx, scale);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_global_avgpool_fwd(const void* x, void* y, int B, int HW, int C, int ldx, int dtype,
+                                      void* stream) {
+    return launch_reduce_hw(x, y, B, HW, C, ldx, dtype, 1.0f / (float)HW, stream);
+}
+extern "C" int dml_reduce_hw(const void* dz, void* dv, int B, int HW, int C, int lddz, int dtype, void* stream) {
+    return launch_reduce_hw(dz, dv, B, HW, C, lddz, dtype, 1.0f, stream);
+}
+
+static int launch_broadcast(const void* v, void* z, int B, int HW, int C, int ldz, int dtype, float alpha,
+                            bool accum, void* stream) {
+    if (!v || !z || B <= 0 || HW <= 0) return DML_EINVAL;
+    if (!vec_ok(dtype, C) || !vec_ok(dtype, ldz)) return DML_EALIGN;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    const int grid = grid_for((int64_t)B * HW * (C / V), 256);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+#define GO(T, ACC)                                                                                              \
+    hipLaunchKernelGGL((broadcast_hw_kernel<T, ACC>), dim3(grid), dim3(256), 0, st, (const T*)v, (T*)z, B, HW, C, \
+                       ldz, alpha)
+    if (dtype == DML_BF16) { if (accum) GO(bf16_t, true); else GO(bf16_t, false); }
+    else { if (accum) GO(float, true); else GO(float, false); }
+#undef GO
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dml_broadcast_hw(const void* v, void* z, int B, int HW, int C, int ldz, int dtype, void* stream) {
+    return launch_broadcast(v, z, B, HW, C, ldz, dtype, 1.0f, false, stream);
+}
+extern "C" int dml_avgpool_bwd_add(const void* dv, void* dx, int B, int HW, int C, int lddx, int dtype,
+                                   void* stream) {
+    return launch_broadcast(dv, dx, B, HW, C, lddx, dtype, 1.0f / (float)HW, true, stream);
+}
+
+template <bool BWD>
+static int launch_bilinear(const void* src, void* dst, int B, int h, int w, int H, int W, int C, int ld_src,
+                           int ld_dst, int dtype, int in_f32, int out_f32, void* stream) {
+    if (!src || !dst || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0) return DML_EINVAL;
+    if (C % 4) return DML_EALIGN;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const int64_t items = BWD ? (int64_t)B * h * w * (C / 4) : (int64_t)B * H * W * (C / 4);
+    const int grid = grid_for(items, 256, 256 * 16);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const bool fi = in_f32 || dtype == DML_F32, fo = out_f32 || dtype == DML_F32;
+#define GO(TI, TO)                                                                                           \
+    do {                                                                                                     \
+        if (BWD)                                                                                             \
+            hipLaunchKernelGGL((bilinear_bwd_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)src,  \
+                               (TO*)dst, B, h, w, H, W, C, ld_src, ld_dst, sy, sx);                          \
+        else                                                                                                 \
+            hipLaunchKernelGGL((bilinear_fwd_kernel<TI, TO>), dim3(grid), dim3(256), 0, st, (const TI*)src,  \
+                               (TO*)dst, B, h, w, H, W, C, ld_src, ld_dst, sy, sx);                          \
+    } while (0)
+    if (fi && fo) GO(float, float);
+    else if (fi) GO(float, bf16_t);
+    else if (fo) GO(bf16_t, float);
+    else GO(bf16_t, bf16_t);
+#undef GO
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bilinear_fwd(const void* x, void* y, int B, int h, int w, int H, int W, int C, int ldx, int ldy,
+                                int dtype, int in_f32, int out_f32, void* stream) {
+    return launch_bilinear<false>(x, y, B, h, w, H, W, C, ldx, ldy, dtype, in_f32, out_f32, stream);
+}
+extern "C" int dml_bilinear_bwd(const void* dy, void* dx, int B, int h, int w, int H, int W, int C, int lddy,
+                                int lddx, int dtype, int in_f32, int out_f32, void* stream) {
+    return launch_bilinear<true>(dy, dx, B, h, w, H, W, C, lddy, lddx, dtype, in_f32, out_f32, stream);
+}

@@ -1,0 +1,115 @@
+"""ctypes binding of libdmlnet_hip.so (C ABI declared in include/dmlnet_hip.h).
+
+The library is the product: there is no CPU or eager-PyTorch fallback.  If the shared object is
+missing or an entry point returns non-zero, we raise.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdmlnet_hip.so")
+
+DML_F32, DML_BF16 = 0, 1
+STAT_ROWS = 64
+LOSS_BLOCKS = 2048
+
+c_p = C.c_void_p
+c_i = C.c_int
+c_i64 = C.c_int64
+c_f = C.c_float
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [("x", c_p), ("w", c_p), ("y", c_p), ("bias", c_p), ("stats", c_p),
+                ("pre_scale", c_p), ("pre_shift", c_p),
+                ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32),
+                ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
+                ("pad", C.c_int32), ("dtype", C.c_int32), ("y_f32", C.c_int32), ("accum", C.c_int32),
+                ("mode", C.c_int32), ("pre_relu", C.c_int32)]
+
+
+class WgradDesc(C.Structure):
+    _fields_ = [("x", c_p), ("dy", c_p), ("dw", c_p),
+                ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32),
+                ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
+                ("pad", C.c_int32), ("dtype", C.c_int32), ("splitk", C.c_int32)]
+
+
+_PROTOS = {
+    "dml_abi_version": (c_i, []),
+    "dml_target_arch": (C.c_char_p, []),
+    "dml_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_p]),
+    "dml_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
+    "dml_prep_weight": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_unpad_wgrad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dml_bias_grad": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "dml_pack_input": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "dml_bn_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "dml_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
+    "dml_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.c_uint64, c_p]),
+    "dml_bn_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_f, c_i,
+                                C.POINTER(c_i), c_p]),
+    "dml_bn_bwd_finalize": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
+    "dml_bn_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
+                               c_i, c_i, c_p]),
+    "dml_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_global_avgpool_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_broadcast_hw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_reduce_hw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_avgpool_bwd_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_bilinear_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_bilinear_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_proto_dist_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_upsample_dist_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_proto_dist_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_argmax_msp": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dml_dissum_score": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "dml_novel_relabel": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i64, c_p]),
+    "dml_loss_fwd": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_p]),
+    "dml_loss_finalize": (c_i, [c_p, c_p, c_f, c_f, c_p]),
+    "dml_loss_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_f, c_f, c_p]),
+    "dml_sgd_step": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_p]),
+    "dml_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
+}
+
+EXPORTS = tuple(_PROTOS.keys())
+
+_lib = None
+
+
+class DmlError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libdmlnet_hip.so; raises (never falls back) when it is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise DmlError(
+            "libdmlnet_hip.so not found at %s -- build it with `python -c 'import __graft_entry__ as g; "
+            "g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in _PROTOS.items():
+        fn = getattr(lib, name)          # AttributeError if the header and the library disagree
+        fn.restype = res
+        fn.argtypes = args
+    if lib.dml_abi_version() != 1:
+        raise DmlError("libdmlnet_hip.so ABI version mismatch")
+    _lib = lib
+    return lib
+
+
+_ERR = {-1: "invalid argument", -2: "misaligned / non-vectorisable shape", -3: "unsupported configuration"}
+
+
+def check(rc: int, what: str):
+    if rc != 0:
+        raise DmlError("%s failed: %s (code %d)" % (what, _ERR.get(rc, "hipError"), rc))

@@ -1,0 +1,84 @@
+"""Fused SGD (momentum + weight decay) over the flat parameter buffer.
+
+Same update as torch.optim.SGD as the reference configures it (main_embedding.py:385-388): weight decay is
+added to the gradient before the momentum update; two parameter groups (backbone at 0.1*lr, classifier at
+lr).  One streaming kernel per contiguous range instead of 338 per-tensor updates.
+"""
+from __future__ import annotations
+
+import torch
+
+from . import _lib
+
+
+class FusedSGD(torch.optim.Optimizer):
+    def __init__(self, params, lr=0.01, momentum=0.9, weight_decay=0.0):
+        super().__init__(params, dict(lr=lr, momentum=momentum, weight_decay=weight_decay))
+        self._ranges = None
+        self.grad_scale = 1.0
+
+    @staticmethod
+    def _store_of(p, stores):
+        for st in stores:
+            try:
+                return st, st._index(p)
+            except KeyError:
+                continue
+        return None, -1
+
+    def bind(self, *models):
+        """Tell the optimizer which models' flat stores its parameters live in."""
+        self._stores = [m._engine.store for m in models]
+        self._ranges = None
+        return self
+
+    def _build_ranges(self):
+        ranges = []
+        for gi, group in enumerate(self.param_groups):
+            items = []
+            for p in group["params"]:
+                st, idx = self._store_of(p, self._stores)
+                if st is None:
+                    raise RuntimeError("FusedSGD: parameter does not belong to a bound model")
+                n = (p.numel() + st.ALIGN - 1) // st.ALIGN * st.ALIGN
+                items.append((id(st), st.offsets[idx], n, st))
+            items.sort(key=lambda t: (t[0], t[1]))
+            cur = None
+            for sid, off, n, st in items:
+                if cur is not None and cur[0] is st and cur[1] + cur[2] == off:
+                    cur[2] += n
+                else:
+                    cur = [st, off, n]
+                    ranges.append((gi, cur))
+        self._ranges = ranges
+
+    @torch.no_grad()
+    def step(self, closure=None):
+        loss = closure() if closure is not None else None
+        if not hasattr(self, "_stores"):
+            raise RuntimeError("call FusedSGD.bind(model) once before step()")
+        lib = _lib.load()
+        if self._ranges is None:
+            self._build_ranges()
+        for st in self._stores:
+            if st.flat_p is None:
+                return loss                       # no forward/backward happened yet
+            if st.flat_v is None or st.flat_v.device != st.flat_p.device:
+                st.flat_v = torch.zeros_like(st.flat_p)
+                for p, off in zip(st.params, st.offsets):
+                    self.state[p]["momentum_buffer"] = st._view(st.flat_v, off, p)
+            # gradients that are not views of the flat buffer (foreign autograd use) are folded in
+            for p, gv in zip(st.params, st.grad_views):
+                if p.grad is None:
+                    gv.zero_()
+                elif p.grad.data_ptr() != gv.data_ptr():
+                    gv.copy_(p.grad)
+        for gi, (st, off, n) in self._ranges:
+            g = self.param_groups[gi]
+            stream = torch.cuda.current_stream(st.flat_p.device).cuda_stream
+            _lib.check(lib.dml_sgd_step(st.flat_p.data_ptr() + 4 * off, st.flat_g.data_ptr() + 4 * off,
+                                        st.flat_v.data_ptr() + 4 * off, n, float(g["lr"]), float(g["momentum"]),
+                                        float(g["weight_decay"]), float(self.grad_scale), stream), "dml_sgd_step")
+        for st in self._stores:
+            st.version += 1
+        return loss

@@ -1,0 +1,86 @@
+"""DML losses on the HIP path.
+
+CrossEntropyLoss mirrors the LIVE behaviour of the reference's utils/loss.py:25-42: CE(ignore_index, mean
+over valid pixels) / n; alpha/beta/gamma are accepted and -- exactly as in the reference, whose VAR / Inter /
+Center terms sit behind an early `return` (loss.py:42-82) -- do not change the value.
+DMLLoss is the live DCE + VL loss of anomaly/models/models.py:42-78: CE/n + alpha * VAR/n.
+Both run dml_loss_fwd / dml_loss_bwd (one fused pass each instead of a per-image per-class Python loop).
+"""
+from __future__ import annotations
+
+import torch
+import torch.nn as nn
+
+from dmlnet import _lib
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class _DMLLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logit, target, alpha, ignore_index, group):
+        if not logit.is_cuda:
+            raise RuntimeError("the DML loss runs on the HIP path only (no CPU fallback)")
+        lib = _lib.load()
+        logit = logit.contiguous().float()
+        target = target.contiguous().long()
+        B, K, H, W = logit.shape
+        if target.shape != (B, H, W):
+            raise RuntimeError("target shape %s does not match logits %s" % (tuple(target.shape), tuple(logit.shape)))
+        sums = torch.empty(4, dtype=torch.float64, device=logit.device)
+        part = torch.empty(_lib.LOSS_BLOCKS * 4, dtype=torch.float32, device=logit.device)
+        st = _stream(logit)
+        _lib.check(lib.dml_loss_fwd(logit.data_ptr(), target.data_ptr(), sums.data_ptr(), part.data_ptr(), B, K, H, W,
+                                    int(ignore_index), st), "dml_loss_fwd")
+        n_images = float(B)
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=group if group is not True else None)
+            n_images = float(B * dist.get_world_size(group if group is not True else None))
+        loss = torch.empty((), dtype=torch.float32, device=logit.device)
+        _lib.check(lib.dml_loss_finalize(sums.data_ptr(), loss.data_ptr(), float(alpha), n_images, st),
+                   "dml_loss_finalize")
+        ctx.save_for_backward(logit, target, sums)
+        ctx.cfg = (float(alpha), int(ignore_index), n_images)
+        return loss
+
+    @staticmethod
+    def backward(ctx, gout):
+        logit, target, sums = ctx.saved_tensors
+        alpha, ignore_index, n_images = ctx.cfg
+        lib = _lib.load()
+        B, K, H, W = logit.shape
+        g = torch.empty_like(logit)
+        gout = gout.contiguous().float()
+        _lib.check(lib.dml_loss_bwd(logit.data_ptr(), target.data_ptr(), sums.data_ptr(), gout.data_ptr(),
+                                    g.data_ptr(), B, K, H, W, ignore_index, alpha, n_images, _stream(logit)),
+                   "dml_loss_bwd")
+        return g, None, None, None, None
+
+
+class DMLLoss(nn.Module):
+    """loss = CE/n + alpha*VAR/n, VAR = sum_i (1/HW_i) sum_{valid p} dist^2(p, own prototype).
+
+    `sync` (True or a process group): sums are all-reduced so that every rank sees the loss of the global
+    batch -- the value nn.DataParallel's gather gives the reference (main_embedding.py:466-467)."""
+
+    def __init__(self, alpha=0.01, ignore_index=-1, sync=None):
+        super().__init__()
+        self.alpha, self.ignore_index, self.sync = alpha, ignore_index, sync
+
+    def forward(self, logit, target, features_in=None):
+        return _DMLLossFn.apply(logit, target, self.alpha, self.ignore_index, self.sync)
+
+
+class CrossEntropyLoss(nn.Module):
+    def __init__(self, alpha=0, beta=0, gamma=0, size_average=True, ignore_index=255, sync=None):
+        super().__init__()
+        self.alpha, self.beta, self.gamma = alpha, beta, gamma
+        self.ignore_index, self.size_average, self.sync = ignore_index, size_average, sync
+        if not size_average:
+            raise NotImplementedError("size_average=False is never used by the embedding drivers")
+
+    def forward(self, logit, target, features_in=None):
+        return _DMLLossFn.apply(logit, target, 0.0, self.ignore_index, self.sync)

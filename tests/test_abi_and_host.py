@@ -1,0 +1,139 @@
+"""CPU: the C-ABI library loads and exports every symbol the header declares; host-side logic of the drop-in
+packages (module tree, state_dict contract, optimizer ranges, LR schedule, sharding, bucketing).  No kernels
+are launched here."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+
+def header_symbols():
+    txt = open(os.path.join(H.ROOT, "include", "dmlnet_hip.h")).read()
+    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(dml_\w+)\s*\(", txt, flags=re.M)))
+
+
+def test_library_exports_every_declared_symbol():
+    from dmlnet import _lib
+    assert os.path.exists(_lib.LIB_PATH), "build with __graft_entry__.build()"
+    lib = ctypes.CDLL(_lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 30
+    for s in syms:
+        assert hasattr(lib, s), "missing export " + s
+    assert sorted(_lib.EXPORTS) == syms, "binding and header disagree"
+    lib2 = _lib.load()
+    assert lib2.dml_abi_version() == 1
+    assert lib2.dml_target_arch() == b"gfx950"
+
+
+def test_struct_layout_matches_header():
+    from dmlnet._lib import ConvDesc, WgradDesc
+    assert ctypes.sizeof(ConvDesc) == 7 * 8 + 19 * 4 + 4      # 7 pointers + 19 int32 (+4 tail padding)
+    assert ctypes.sizeof(WgradDesc) == 3 * 8 + 16 * 4
+    assert ConvDesc.B.offset == 56 and ConvDesc.pre_relu.offset == 56 + 18 * 4
+
+
+def test_module_tree_and_state_dict_contract():
+    import network
+    from oracle import dmlnet_ref as O
+    m = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    o = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    assert list(m.state_dict().keys()) == list(o.state_dict().keys())
+    assert H.shapes_of(m) == H.shapes_of(o)
+    assert len(m.state_dict()) == 674
+    assert [k for k, _ in m.named_parameters()] == [k for k, _ in o.named_parameters()]
+    # optimizer groups partition the parameters (main_embedding.py:385-388)
+    nb, nc = sum(p.numel() for p in m.backbone.parameters()), sum(p.numel() for p in m.classifier.parameters())
+    assert nb == 42500160 and nc == 16252528
+    # OS8 variant: dilations as resnet.py:174-191 / modeling.py:8-10
+    m8 = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=8, pretrained_backbone=False)
+    assert m8.backbone.layer3[0].conv2.dilation == (1, 1) and m8.backbone.layer3[1].conv2.dilation == (2, 2)
+    assert m8.backbone.layer4[0].conv2.dilation == (2, 2) and m8.backbone.layer4[1].conv2.dilation == (4, 4)
+    assert m8.classifier.aspp.convs[3][0].dilation == (36, 36)
+    assert m.backbone.layer4[0].conv2.dilation == (1, 1) and m.backbone.layer4[2].conv2.dilation == (2, 2)
+    assert m.classifier.aspp.convs[1][0].padding == (6, 6)
+
+
+def test_out_of_scope_factories_raise():
+    import network
+    for name in ("deeplabv3_resnet50", "deeplabv3plus_resnet101", "deeplabv3plus_mobilenet"):
+        with pytest.raises(NotImplementedError):
+            getattr(network, name)(num_classes=16, output_stride=16)
+    with pytest.raises(NotImplementedError):
+        network.convert_to_separable_conv(torch.nn.Conv2d(3, 3, 3))
+
+
+def test_no_cpu_fallback():
+    """The product path must refuse CPU tensors instead of silently computing somewhere else."""
+    import network
+    import utils
+    m = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    with pytest.raises(RuntimeError, match="ROCm device"):
+        m.eval()(torch.zeros(1, 3, 32, 32))
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        utils.DMLLoss()(torch.zeros(1, 4, 2, 2), torch.zeros(1, 2, 2, dtype=torch.long))
+    with pytest.raises(RuntimeError, match="HIP path only"):
+        utils.dissum_score(torch.zeros(1, 4, 2, 2))
+    # and nothing in the package imports the oracle
+    for root, _, files in os.walk(H.PKG):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(root, f)).read()
+                assert "import oracle" not in src and "from oracle" not in src, f
+
+
+def test_param_store_layout():
+    import network
+    m = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=1))
+    st = m._engine.store
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    st.bind(torch.device("cpu"))                       # flattening itself is device independent
+    assert st.is_bound(torch.device("cpu"))
+    after = m.state_dict()
+    for k in before:
+        assert torch.equal(before[k], after[k]), k
+    w = m.backbone.layer1[0].conv2.weight
+    assert w.shape == (64, 64, 3, 3) and w.stride() == (576, 1, 192, 64)     # K-R-S-C physical order
+    assert st.total % 64 == 0 and st.split == 42500160
+    # loading a checkpoint writes through the views
+    m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=2))
+    off = st.offsets[st._index(w)]
+    assert torch.equal(st.flat_p[off:off + w.numel()].view(64, 3, 3, 64), w.detach().permute(0, 2, 3, 1))
+
+
+def test_fused_sgd_ranges_and_poly_lr():
+    import network
+    import utils
+    from dmlnet.optim import FusedSGD
+    m = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    opt = FusedSGD([{"params": m.backbone.parameters(), "lr": 0.001},
+                    {"params": m.classifier.parameters(), "lr": 0.01}], lr=0.01, momentum=0.9, weight_decay=1e-4).bind(m)
+    opt._build_ranges()
+    st = m._engine.store
+    assert [(gi, r[1], r[2]) for gi, r in opt._ranges] == [(0, 0, st.split), (1, st.split, st.total - st.split)]
+    sched = utils.PolyLR(opt, 100, power=0.9)
+    lrs = []
+    for _ in range(100):
+        sched.step()
+        lrs.append([g["lr"] for g in opt.param_groups])
+    assert lrs[49][1] == pytest.approx(0.01 * 0.5 ** 0.9)
+    assert lrs[49][0] == pytest.approx(0.001 * 0.5 ** 0.9)
+    assert lrs[-1] == [1e-6, 1e-6]
+
+
+def test_shard_and_buckets():
+    from dmlnet.parallel import make_buckets, shard_range
+    assert [shard_range(128, r, 8) for r in (0, 7)] == [(0, 16), (112, 128)]
+    spans = [shard_range(10, r, 4) for r in range(4)]
+    assert spans == [(0, 3), (3, 6), (6, 8), (8, 10)]
+    offs, sizes = [0, 64, 192, 1216], [10, 128, 1000, 64]
+    b = make_buckets(offs, sizes, 1280, 512)
+    assert b[0][0] == 192 and b[0][1] == 1280 and b[-1][0] == 0
+    assert sum(hi - lo for lo, hi, _ in b) == 1280
+    assert sorted(i for _, _, mem in b for i in mem) == [0, 1, 2, 3]

@@ -1,0 +1,235 @@
+"""GPU: the drop-in `network` / `utils` API on the HIP path against the golden vectors minted from the real
+reference (G5, G5b, G8) and against the CPU oracle on fresh seeded inputs.  Tolerance from BASELINE.json:
+1e-3 (relative to the tensor's max magnitude) in fp32 mode.
+"""
+from collections import OrderedDict
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+T = torch.from_numpy
+TOL = 1e-3
+
+
+def relclose(got, ref, tol, what=""):
+    err = (got.detach().double().cpu() - ref.detach().double().cpu()).abs().max().item()
+    scale = ref.detach().double().abs().max().item() + 1e-12
+    assert err <= tol * scale, "%s: max|d|=%.3e scale=%.3e rel=%.3e > %.1e" % (what, err, scale, err / scale, tol)
+
+
+def build(dtype=torch.float32, train=True, seed=1):
+    import network
+    import utils
+    m = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=seed))
+    m.cuda()
+    m.set_compute_dtype(dtype)
+    if train:
+        m.train()
+        m.classifier.aspp.project[3].eval()          # F14: dropout off for parity
+        utils.set_bn_momentum(m.backbone, 0.01)
+    else:
+        m.eval()
+    return m
+
+
+def g5_inputs():
+    img = H.synth_tensor(5, "g5.img", (2, 3, 64, 64)).cuda()
+    lab = H.synth_labels(5, "g5.lab", (2, 64, 64), 16, 255, ignore_rows=3).cuda()
+    return img, lab
+
+
+def test_g5_full_train_step_matches_reference():
+    import utils
+    g = H.load_golden("g5_full_train")
+    m = build()
+    img, lab = g5_inputs()
+    lg, ctr, ft = m(img)
+    assert lg.shape == (2, 16, 64, 64) and ft.shape == (2, 64, 64, 16) and ctr.shape == (16, 16)
+    loss = utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0)(lg, lab, ft)
+    loss.backward()
+    relclose(lg, T(g["logits"]), TOL, "logits")
+    relclose(ft.permute(0, 3, 1, 2), T(g["logits"]) * 0 + ft.detach().cpu().permute(0, 3, 1, 2), TOL, "self")
+    assert abs(loss.item() - float(g["loss"])) <= TOL * abs(float(g["loss"]))
+    grads = OrderedDict((k, p.grad) for k, p in m.named_parameters())
+    names = [str(n) for n in g["grad_names"]]
+    assert names == list(grads.keys())
+    bad = []
+    for (k, gr), cs in zip(grads.items(), g["grad_checksums"]):
+        got = H.checksum(gr)
+        if not np.allclose(got[1:], cs[1:], rtol=5e-3):
+            bad.append((k, got, cs))
+    assert not bad, "gradient checksums differ for %d tensors, first: %r" % (len(bad), bad[:3])
+    for key in ("backbone.bn1.weight", "backbone.layer1.0.conv1.weight", "backbone.layer2.0.downsample.0.weight",
+                "backbone.layer3.5.bn2.bias", "classifier.project.0.weight", "classifier.aspp.project.1.weight",
+                "classifier.classifier.3.weight", "classifier.classifier.3.bias", "backbone.conv1.weight"):
+        ref = T(g["grad__" + key.replace(".", "_")])
+        got = grads[key].detach().cpu()
+        got = got if got.numel() < 70000 else got.contiguous().flatten()[::16]
+        relclose(got.reshape(ref.shape), ref, 3 * TOL, "grad " + key)
+    bufs = dict(m.named_buffers())
+    relclose(bufs["backbone.bn1.running_mean"], T(g["rm_stem"]), TOL, "running_mean stem")
+    relclose(bufs["backbone.bn1.running_var"], T(g["rv_stem"]), TOL, "running_var stem")
+    relclose(bufs["backbone.layer4.2.bn3.running_var"], T(g["rv_l4"]), TOL, "running_var layer4")
+    relclose(bufs["classifier.classifier.1.running_var"], T(g["rv_head"]), TOL, "running_var head")
+    assert int(bufs["backbone.bn1.num_batches_tracked"]) == 1
+
+
+def test_g8_sgd_polylr_trajectory():
+    import utils
+    from dmlnet.optim import FusedSGD
+    t = H.load_golden("g8_trajectory")
+    m = build()
+    img, lab = g5_inputs()
+    lr, total = float(t["lr"]), int(t["total_itrs"])
+    opt = FusedSGD([{"params": m.backbone.parameters(), "lr": 0.1 * lr},
+                    {"params": m.classifier.parameters(), "lr": lr}], lr=lr, momentum=0.9, weight_decay=1e-4).bind(m)
+    sched = utils.PolyLR(opt, total, power=0.9)
+    crit = utils.CrossEntropyLoss(ignore_index=255)
+    losses = []
+    for it in range(6):
+        opt.zero_grad()
+        lg, _, ft = m(img)
+        loss = crit(lg, lab, ft)
+        loss.backward()
+        opt.step()
+        sched.step()
+        losses.append(loss.item())
+    assert np.allclose(losses, t["losses"], rtol=3e-3), (losses, t["losses"].tolist())
+    assert np.allclose([g_["lr"] for g_ in opt.param_groups], t["lrs"][-1], rtol=1e-6)
+    sd = m.state_dict()
+    relclose(sd["classifier.classifier.3.bias"], T(t["b_last"]), 5e-3, "final bias after 6 steps")
+    relclose(sd["backbone.conv1.weight"], T(t["w_stem"]), 5e-3, "stem weight after 6 steps")
+    relclose(sd["backbone.bn1.running_mean"], T(t["rm_stem"]), 5e-3, "stem running mean after 6 steps")
+
+
+def test_g5b_eval_forward_config1():
+    """BASELINE config #1 shape (1x3x256x256 eval forward) on the HIP path."""
+    g = H.load_golden("g5b_full_eval")
+    m = build(train=False)
+    flat, off = T(g["bn_stats"]), 0
+    sd = m.state_dict()
+    for k, v in sd.items():
+        if k.endswith("running_mean") or k.endswith("running_var"):
+            sd[k] = flat[off:off + v.numel()].view_as(v).clone()
+            off += v.numel()
+    m.load_state_dict(sd)
+    with torch.no_grad():
+        lg, ctr, ft = m(H.synth_tensor(5, "g5b.img", (1, 3, 256, 256)).cuda())
+    relclose(lg[:, :, ::4, ::4], T(g["logits_sub"]), TOL, "eval logits")
+    relclose(ft[:, ::4, ::4, :], T(g["feats_sub"]), TOL, "eval features")
+    assert np.allclose(H.checksum(lg), g["logits_checksum"], rtol=2e-3)
+    agree = (lg.argmax(1).to(torch.uint8).cpu() == T(g["argmax"])).float().mean().item()
+    assert agree > 0.995, agree
+    assert torch.equal(ctr.cpu(), T(g["centers"]))
+
+
+def test_against_oracle_fresh_input_all_param_grads():
+    """Non-square input, DML loss with the variance term: every parameter gradient vs the CPU oracle."""
+    import utils
+    from oracle import dmlnet_ref as O
+    m = build(seed=9)
+    o = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    o.load_state_dict(H.synth_state_dict(H.shapes_of(o), seed=9))
+    o.train()
+    o.classifier.aspp.project[3].eval()
+    O.set_bn_momentum(o.backbone, 0.01)
+    img = H.synth_tensor(9, "fresh.img", (3, 3, 96, 128))
+    lab = H.synth_labels(9, "fresh.lab", (3, 96, 128), 16, 255, ignore_frac=0.05)
+    lg, _, ft = m(img.cuda())
+    loss = utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft)
+    loss.backward()
+    olg, _, oft = o(img)
+    oloss = O.dml_loss(olg, lab, alpha=0.01, ignore_index=255)
+    oloss.backward()
+    relclose(lg, olg, TOL, "logits vs oracle")
+    relclose(ft, oft, TOL, "features vs oracle")
+    assert abs(loss.item() - oloss.item()) <= TOL * abs(oloss.item())
+    worst = ("", 0.0)
+    for (k, p), (_, q) in zip(m.named_parameters(), o.named_parameters()):
+        err = (p.grad.detach().cpu().double() - q.grad.double()).abs().max().item()
+        rel = err / (q.grad.abs().max().item() + 1e-12)
+        if rel > worst[1]:
+            worst = (k, rel)
+    assert worst[1] <= 5 * TOL, "worst parameter gradient: %s rel %.3e" % worst
+
+
+def test_features_out_carries_grad_and_eval_no_grad():
+    m = build()
+    img, lab = g5_inputs()
+    lg, _, ft = m(img)
+    assert lg.requires_grad and ft.requires_grad
+    (ft.sum() * 1e-3 + lg.mean()).backward()
+    assert m.backbone.conv1.weight.grad is not None and torch.isfinite(m.backbone.conv1.weight.grad).all()
+    m.eval()
+    with torch.no_grad():
+        lg2, _, _ = m(img)
+    assert not lg2.requires_grad and torch.isfinite(lg2).all()
+    with pytest.raises(ValueError):
+        m.train()
+        m(img[:1])                                   # F12: same failure as the reference at batch 1
+
+
+def test_bf16_mode_tracks_fp32():
+    import utils
+    img, lab = g5_inputs()
+    ref, _, _ = build()(img)
+    m = build(dtype=torch.bfloat16)
+    lg, _, ft = m(img)
+    loss = utils.CrossEntropyLoss(ignore_index=255)(lg, lab, ft)
+    loss.backward()
+    assert torch.isfinite(lg).all()
+    relclose(lg, ref, 0.15, "bf16 logits vs fp32 logits")
+    g = m.classifier.classifier[3].weight.grad
+    assert torch.isfinite(g).all() and g.abs().sum() > 0
+
+
+def test_state_dict_roundtrip_into_oracle():
+    from oracle import dmlnet_ref as O
+    m = build(train=False)
+    sd = m.state_dict()
+    assert len(sd) == 674 and all(v.is_contiguous() for v in sd.values())
+    o = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    o.load_state_dict({k: v.cpu() for k, v in sd.items()})
+    ref = H.synth_state_dict(H.shapes_of(o), seed=1)
+    for k, v in o.state_dict().items():
+        assert torch.equal(v, ref[k]), k
+
+
+@pytest.mark.parametrize("dtype", [torch.bfloat16])
+def test_baseline_size_properties(dtype):
+    """768x768 bs=16 (BASELINE configs[2]) train steps: size-independent properties of the head and loss."""
+    import utils
+    from dmlnet.optim import FusedSGD
+    m = build(dtype=dtype)
+    m.classifier.aspp.project[3].train()             # dropout on, as in the real step
+    g = torch.Generator(device="cpu").manual_seed(1234)
+    img = torch.randn(16, 3, 768, 768, generator=g).cuda()
+    lab = torch.randint(0, 16, (16, 768, 768), generator=g)
+    lab[:, :38] = 255
+    lab = lab.cuda()
+    opt = FusedSGD([{"params": m.backbone.parameters(), "lr": 0.001},
+                    {"params": m.classifier.parameters(), "lr": 0.01}], lr=0.01, momentum=0.9, weight_decay=1e-4).bind(m)
+    crit = utils.DMLLoss(alpha=0.01, ignore_index=255)
+    losses = []
+    for it in range(3):
+        opt.zero_grad()
+        lg, ctr, ft = m(img)
+        loss = crit(lg, lab, ft)
+        loss.backward()
+        opt.step()
+        losses.append(loss.item())
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
+    # F5: logits == -|f|^2 + 6 f_k - 9 for 3*I prototypes; argmax_k logit == argmax_k f
+    f = ft.detach()
+    closed = (-(f * f).sum(-1, keepdim=True) + 6 * f - 9).permute(0, 3, 1, 2)
+    scale = lg.detach().abs().max().item()
+    assert (lg.detach() - closed).abs().max().item() <= 1e-4 * scale
+    assert (lg.detach().argmax(1) == f.argmax(-1)).float().mean().item() > 0.9999
+    gsum = sum(float(p.grad.abs().sum()) for p in m.parameters())
+    assert np.isfinite(gsum) and gsum > 0

@@ -1,0 +1,497 @@
+"""GPU: every C-ABI kernel against a plain PyTorch fp32 reference of the same op (computed on the CPU),
+and against the golden vectors where the reference pins the op (G1, G2, G6, G7).
+
+Tolerances: fp32 kernels 2e-5 relative to the tensor's max magnitude (exact-fp32 MFMA, different summation
+order); bf16 kernels are compared with the reference evaluated on the SAME bf16-rounded inputs, 1e-2
+relative (bf16 output rounding is 2^-8 = 3.9e-3).
+"""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import helpers as H
+
+pytestmark = pytest.mark.gpu
+
+DT = {"f32": (0, torch.float32, 2e-5), "bf16": (1, torch.bfloat16, 1e-2)}
+
+
+@pytest.fixture(scope="module")
+def lib():
+    from dmlnet import _lib
+    return _lib.load()
+
+
+def st():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def chk(rc):
+    assert rc == 0, "kernel returned %d" % rc
+
+
+def nhwc(t, dtype):          # NCHW cpu -> NHWC cuda
+    return t.permute(0, 2, 3, 1).contiguous().to("cuda", dtype)
+
+
+def nchw(t):                 # NHWC cuda -> NCHW cpu float
+    return t.float().cpu().permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(name, shape, scale=1.0):
+    return H.synth_tensor(77, name, shape, scale=scale)
+
+
+def qz(t, dtype):            # round through the storage dtype
+    return t.to(dtype).float()
+
+
+def relclose(got, ref, tol, what=""):
+    err = (got.double() - ref.double()).abs().max().item()
+    scale = ref.double().abs().max().item() + 1e-12
+    assert err <= tol * scale, "%s: max|d|=%.3e scale=%.3e rel=%.3e > %.1e" % (what, err, scale, err / scale, tol)
+
+
+CONV_CASES = [
+    # name, B, H, W, Cin, Cout, k, stride, dil
+    ("1x1", 2, 12, 10, 64, 128, 1, 1, 1),
+    ("1x1_n48", 2, 9, 7, 256, 48, 1, 1, 1),
+    ("1x1_s2", 2, 12, 10, 64, 256, 1, 2, 1),
+    ("3x3", 2, 11, 13, 64, 64, 3, 1, 1),
+    ("3x3_s2", 2, 12, 14, 128, 128, 3, 2, 1),
+    ("3x3_d2", 2, 10, 9, 64, 96, 3, 1, 2),
+    ("3x3_d6", 2, 8, 8, 128, 256, 3, 1, 6),
+    ("3x3_c320", 1, 9, 9, 320, 256, 3, 1, 1),
+    ("7x7_s2_stem", 2, 22, 18, 8, 64, 7, 2, 1),
+    ("1x1_pool_rows", 4, 1, 1, 256, 256, 1, 1, 1),
+]
+
+
+def conv_ref(x, w, k, stride, dil, bias=None):
+    pad = 3 if k == 7 else dil * (k // 2)
+    return F.conv2d(x, w, bias, stride=stride, padding=pad, dilation=dil), pad
+
+
+def make_desc(lib, x, w, y, B, Hi, Wi, Cin, Ho, Wo, Cout, k, stride, dil, pad, dt, mode=0, stats=None, bias=None,
+              y_f32=0, accum=0, ldx=None, ldy=None):
+    from dmlnet._lib import ConvDesc
+    return ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=bias.data_ptr() if bias is not None else None,
+                    stats=stats.data_ptr() if stats is not None else None, pre_scale=None, pre_shift=None,
+                    B=B, Hi=Hi, Wi=Wi, C=Cin, ldx=ldx or Cin, Ho=Ho, Wo=Wo, N=Cout, ldy=ldy or Cout, R=k, S=k,
+                    stride=stride, dil=dil, pad=pad, dtype=dt, y_f32=y_f32, accum=accum, mode=mode, pre_relu=0)
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+@pytest.mark.parametrize("case", CONV_CASES, ids=[c[0] for c in CONV_CASES])
+def test_conv_fwd_dgrad_wgrad(lib, case, dname):
+    name, B, Hh, Ww, Cin, Cout, k, stride, dil = case
+    dt, tdt, tol = DT[dname]
+    x = qz(rnd(name + ".x", (B, Cin, Hh, Ww)), tdt).requires_grad_(True)
+    w = qz(rnd(name + ".w", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5), tdt).requires_grad_(True)
+    y_ref, pad = conv_ref(x, w, k, stride, dil)
+    Ho, Wo = y_ref.shape[2:]
+    gy = qz(rnd(name + ".gy", tuple(y_ref.shape)), tdt)
+    y_ref.backward(gy)
+
+    xd = nhwc(x.detach(), tdt)
+    wd = w.detach().permute(0, 2, 3, 1).contiguous().to("cuda", tdt)          # K R S C
+    wtd = w.detach().permute(1, 2, 3, 0).contiguous().to("cuda", tdt)         # C R S K (dgrad copy)
+    yd = torch.empty((B, Ho, Wo, Cout), device="cuda", dtype=tdt)
+    M = B * Ho * Wo
+    groups = (M + 63) // 64
+    stats = torch.zeros(groups * Cout * 2, device="cuda")
+    d = make_desc(lib, xd, wd, yd, B, Hh, Ww, Cin, Ho, Wo, Cout, k, stride, dil, pad, dt, stats=stats)
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    torch.cuda.synchronize()
+    relclose(nchw(yd), y_ref.detach(), tol, "conv fwd " + name)
+
+    # fused BN statistics: finalize and compare with the batch statistics of the fp32 result
+    sc, sh, mu, inv = (torch.empty(Cout, device="cuda") for _ in range(4))
+    rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
+    chk(lib.dml_bn_finalize(stats.data_ptr(), M, Cout, None, None, rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5,
+                            sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
+    yr = y_ref.detach().double()
+    mean_ref, var_ref = yr.mean(dim=(0, 2, 3)), yr.var(dim=(0, 2, 3), unbiased=False)
+    stol = 1e-4 if dname == "f32" else 2e-2
+    assert (mu.cpu().double() - mean_ref).abs().max() <= stol * (yr.abs().max() + 1e-6)
+    relclose(inv.cpu(), (var_ref + 1e-5).rsqrt().float(), stol, "invstd " + name)
+    if M > 1:
+        relclose(rv.cpu(), (0.9 + 0.1 * yr.var(dim=(0, 2, 3), unbiased=True)).float(), stol, "running_var " + name)
+
+    # data gradient (transposed conv as a gather)
+    if name != "7x7_s2_stem":
+        gyd = nhwc(gy, tdt)
+        dxd = torch.full((B, Hh, Ww, Cin), 7.0, device="cuda", dtype=tdt)
+        dd = make_desc(lib, gyd, wtd, dxd, B, Ho, Wo, Cout, Hh, Ww, Cin, k, stride, dil, pad, dt, mode=1)
+        chk(lib.dml_conv_igemm(C.byref(dd), st()))
+        torch.cuda.synchronize()
+        relclose(nchw(dxd), x.grad, tol, "conv dgrad " + name)
+        # accumulate flag
+        dd.accum = 1
+        chk(lib.dml_conv_igemm(C.byref(dd), st()))
+        torch.cuda.synchronize()
+        relclose(nchw(dxd), 2 * x.grad, 2 * tol, "conv dgrad accum " + name)
+
+    # weight gradient (fp32 atomics into a zeroed buffer)
+    from dmlnet._lib import WgradDesc
+    gyd = nhwc(gy, tdt)
+    dw = torch.zeros((Cout, k, k, Cin), device="cuda")
+    wg = WgradDesc(x=xd.data_ptr(), dy=gyd.data_ptr(), dw=dw.data_ptr(), B=B, Hi=Hh, Wi=Ww, C=Cin, ldx=Cin, Ho=Ho,
+                   Wo=Wo, N=Cout, ldy=Cout, R=k, S=k, stride=stride, dil=dil, pad=pad, dtype=dt, splitk=0)
+    chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+    torch.cuda.synchronize()
+    relclose(dw.cpu().permute(0, 3, 1, 2), w.grad, tol if dname == "f32" else 2e-3, "conv wgrad " + name)
+    wg.splitk = 3
+    dw.zero_()
+    chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+    torch.cuda.synchronize()
+    relclose(dw.cpu().permute(0, 3, 1, 2), w.grad, tol if dname == "f32" else 2e-3, "conv wgrad splitk " + name)
+
+
+def test_conv_bias_f32_out_and_slices(lib):
+    """Final 1x1 with bias writing fp32 from bf16 operands; producer writing into a concat-buffer slice."""
+    B, Hh, Ww, Cin, K = 2, 6, 5, 256, 16
+    x = qz(rnd("fin.x", (B, Cin, Hh, Ww)), torch.bfloat16)
+    w = qz(rnd("fin.w", (K, Cin, 1, 1), scale=0.05), torch.bfloat16)
+    b = rnd("fin.b", (K,), scale=0.1)
+    ref = F.conv2d(x, w, b)
+    xd, wd = nhwc(x, torch.bfloat16), w.permute(0, 2, 3, 1).contiguous().to("cuda", torch.bfloat16)
+    y = torch.empty((B, Hh, Ww, K), device="cuda", dtype=torch.float32)
+    d = make_desc(lib, xd, wd, y, B, Hh, Ww, Cin, Hh, Ww, K, 1, 1, 1, 0, 1, bias=b.cuda(), y_f32=1)
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    torch.cuda.synchronize()
+    relclose(nchw(y), ref, 1e-5, "bias / fp32 out")
+    # input taken from a channel slice (ldx > C), output into a slice (ldy > N)
+    big_in = torch.zeros((B, Hh, Ww, 320), device="cuda", dtype=torch.bfloat16)
+    big_in[..., 64:320] = xd
+    big_out = torch.full((B, Hh, Ww, 48), 5.0, device="cuda", dtype=torch.float32)
+    from dmlnet._lib import ConvDesc
+    d2 = make_desc(lib, big_in, wd, big_out, B, Hh, Ww, Cin, Hh, Ww, K, 1, 1, 1, 0, 1, bias=b.cuda(), y_f32=1,
+                   ldx=320, ldy=48)
+    d2.x = big_in.data_ptr() + 64 * 2
+    d2.y = big_out.data_ptr() + 8 * 4
+    chk(lib.dml_conv_igemm(C.byref(d2), st()))
+    torch.cuda.synchronize()
+    relclose(nchw(big_out[..., 8:24]), ref, 1e-5, "sliced in/out")
+    assert (big_out[..., :8] == 5).all() and (big_out[..., 24:] == 5).all()
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+def test_prep_weight_and_unpad(lib, dname):
+    dt, tdt, _ = DT[dname]
+    N, RS, Cm, Cp = 24, 9, 304, 320
+    w = rnd("pw", (N, RS, Cm)).cuda()
+    out = torch.empty((N, RS, Cp), device="cuda", dtype=tdt)
+    outt = torch.empty((Cp, RS, N), device="cuda", dtype=tdt)
+    chk(lib.dml_prep_weight(w.data_ptr(), out.data_ptr(), outt.data_ptr(), N, RS, Cm, Cp, dt, st()))
+    torch.cuda.synchronize()
+    ref = torch.zeros((N, RS, Cp))
+    ref[..., :Cm] = w.cpu()
+    ref = qz(ref, tdt)
+    assert torch.equal(out.float().cpu(), ref)
+    assert torch.equal(outt.float().cpu(), ref.permute(2, 1, 0).contiguous())
+    g = rnd("pw.g", (N, RS, Cp)).cuda()
+    dst = torch.ones((N, RS, Cm), device="cuda")
+    chk(lib.dml_unpad_wgrad(g.data_ptr(), dst.data_ptr(), N, RS, Cm, Cp, st()))
+    torch.cuda.synchronize()
+    assert torch.allclose(dst.cpu(), 1 + g.cpu()[..., :Cm])
+
+
+def test_pack_input(lib):
+    x = rnd("pk", (2, 3, 7, 9)).cuda()
+    for dt, tdt in ((0, torch.float32), (1, torch.bfloat16)):
+        y = torch.empty((2, 7, 9, 8), device="cuda", dtype=tdt)
+        chk(lib.dml_pack_input(x.data_ptr(), y.data_ptr(), 2, 3, 7, 9, 8, dt, st()))
+        torch.cuda.synchronize()
+        assert torch.equal(y[..., :3].float().cpu(), qz(x.cpu().permute(0, 2, 3, 1), tdt))
+        assert (y[..., 3:] == 0).all()
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+@pytest.mark.parametrize("relu,res,drop", [(1, False, 0.0), (1, True, 0.0), (0, False, 0.0), (1, False, 0.25)])
+def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
+    """bn_stats -> finalize -> apply and the two-pass backward vs F.batch_norm autograd."""
+    dt, tdt, tol = DT[dname]
+    B, Hh, Ww, Cc = 3, 9, 11, 48
+    M = B * Hh * Ww
+    y = qz(rnd("bn.y", (B, Cc, Hh, Ww), 2.0) + 0.5, tdt).requires_grad_(True)
+    r = qz(rnd("bn.r", (B, Cc, Hh, Ww)), tdt).requires_grad_(True) if res else None
+    gamma = (rnd("bn.g", (Cc,)) * 0.2 + 1).requires_grad_(True)
+    beta = (rnd("bn.b", (Cc,)) * 0.1).requires_grad_(True)
+    rm0, rv0 = rnd("bn.rm", (Cc,)) * 0.1, rnd("bn.rv", (Cc,)).abs() + 0.5
+    rm_ref, rv_ref = rm0.clone(), rv0.clone()
+    o = F.batch_norm(y, rm_ref, rv_ref, gamma, beta, training=True, momentum=0.01, eps=1e-5)
+    if res:
+        o = o + r
+    if relu:
+        o = F.relu(o)
+    yd = nhwc(y.detach(), tdt)
+    rd = nhwc(r.detach(), tdt) if res else None
+    zd = torch.empty_like(yd)
+    groups = (M + 63) // 64
+    part = torch.zeros(max(groups, 1100) * Cc * 2, device="cuda")
+    chk(lib.dml_bn_stats(yd.data_ptr(), part.data_ptr(), M, Cc, Cc, dt, st()))
+    sc, sh, mu, inv = (torch.empty(Cc, device="cuda") for _ in range(4))
+    rm, rv, g_d, b_d = rm0.cuda(), rv0.cuda(), gamma.detach().cuda(), beta.detach().cuda()
+    chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, g_d.data_ptr(), b_d.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+                            0.01, 1e-5, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
+    chk(lib.dml_bn_apply(yd.data_ptr(), rd.data_ptr() if res else None, zd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
+                         M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, st()))
+    torch.cuda.synchronize()
+    relclose(rm.cpu(), rm_ref, 1e-4, "running_mean")
+    relclose(rv.cpu(), rv_ref, 1e-4, "running_var")
+    z = nchw(zd)
+    gs = 1.0
+    if drop > 0:
+        keep = (z != 0) | (o.detach() == 0)
+        frac = 1 - (z != 0).float().sum() / ((o.detach() != 0).float().sum() + 1e-9)
+        assert abs(frac.item() - drop) < 0.03, frac
+        gs = 1 / (1 - drop)
+        relclose(z[z != 0], (o.detach() * gs)[z != 0], max(tol, 1e-5), "dropout kept values")
+        mask = (z != 0).float()
+    else:
+        relclose(z, o.detach(), max(tol, 1e-5), "bn apply")
+        mask = None
+    # backward
+    gz = qz(rnd("bn.gz", (B, Cc, Hh, Ww)), tdt)
+    (o * (gz * (mask * gs if mask is not None else 1))).sum().backward()
+    gzd = nhwc(gz, tdt)
+    nblk = C.c_int(0)
+    chk(lib.dml_bn_bwd_reduce(gzd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mu.data_ptr(), inv.data_ptr(),
+                              part.data_ptr(), M, Cc, Cc, Cc, Cc, 1 if (relu or drop > 0) else 0, gs, dt,
+                              C.byref(nblk), st()))
+    coef = torch.empty(3 * Cc, device="cuda")
+    dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
+    chk(lib.dml_bn_bwd_finalize(part.data_ptr(), nblk, M, Cc, g_d.data_ptr(), mu.data_ptr(), inv.data_ptr(),
+                                dg.data_ptr(), db.data_ptr(), coef.data_ptr(), st()))
+    dyd = torch.empty_like(yd)
+    dres = torch.empty_like(yd) if res else None
+    chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zd.data_ptr(), coef.data_ptr(), dyd.data_ptr(),
+                             dres.data_ptr() if res else None, M, Cc, Cc, Cc, Cc, Cc, Cc,
+                             1 if (relu or drop > 0) else 0, gs, 0, dt, st()))
+    torch.cuda.synchronize()
+    btol = 1e-4 if dname == "f32" else 2e-2
+    relclose(dg.cpu(), gamma.grad, btol, "dgamma")
+    relclose(db.cpu(), beta.grad, btol, "dbeta")
+    relclose(nchw(dyd), y.grad, btol, "bn dy")
+    if res:
+        relclose(nchw(dres), r.grad, btol, "bn dres")
+
+
+def test_bn_eval_coeffs(lib):
+    Cc = 40
+    g, b, rm, rv = (rnd("ev" + s, (Cc,)).cuda() for s in "gbmv")
+    rv = rv.abs() + 0.3
+    sc, sh = torch.empty(Cc, device="cuda"), torch.empty(Cc, device="cuda")
+    chk(lib.dml_bn_eval_coeffs(g.data_ptr(), b.data_ptr(), rm.data_ptr(), rv.data_ptr(), 1e-5, sc.data_ptr(),
+                               sh.data_ptr(), Cc, st()))
+    torch.cuda.synchronize()
+    x = rnd("ev.x", (2, Cc, 3, 3))
+    ref = F.batch_norm(x, rm.cpu(), rv.cpu(), g.cpu(), b.cpu(), training=False, eps=1e-5)
+    got = x * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+    relclose(got, ref, 1e-5, "eval bn")
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+def test_maxpool(lib, dname):
+    dt, tdt, tol = DT[dname]
+    B, Hh, Ww, Cc = 2, 13, 10, 16
+    x = qz(rnd("mp.x", (B, Cc, Hh, Ww)), tdt).requires_grad_(True)
+    y = F.max_pool2d(x, 3, 2, 1)
+    gy = qz(rnd("mp.g", tuple(y.shape)), tdt)
+    y.backward(gy)
+    Ho, Wo = y.shape[2:]
+    xd = nhwc(x.detach(), tdt)
+    yd = torch.empty((B, Ho, Wo, Cc), device="cuda", dtype=tdt)
+    am = torch.empty((B, Ho, Wo, Cc), device="cuda", dtype=torch.uint8)
+    chk(lib.dml_maxpool3x3s2_fwd(xd.data_ptr(), yd.data_ptr(), am.data_ptr(), B, Hh, Ww, Cc, dt, st()))
+    dxd = torch.empty_like(xd)
+    gyd = nhwc(gy, tdt)
+    chk(lib.dml_maxpool3x3s2_bwd(gyd.data_ptr(), am.data_ptr(), dxd.data_ptr(), B, Hh, Ww, Cc, dt, st()))
+    torch.cuda.synchronize()
+    assert torch.equal(nchw(yd), y.detach())
+    relclose(nchw(dxd), x.grad, tol, "maxpool bwd")
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+def test_avgpool_broadcast_reduce(lib, dname):
+    dt, tdt, tol = DT[dname]
+    B, HW, Cc, ld = 3, 35, 64, 96
+    x = qz(rnd("ap.x", (B, HW, ld)), tdt)
+    xd = x.to("cuda", tdt)
+    out = torch.empty((B, Cc), device="cuda", dtype=tdt)
+    chk(lib.dml_global_avgpool_fwd(xd.data_ptr() + 16 * xd.element_size(), out.data_ptr(), B, HW, Cc, ld, dt, st()))
+    red = torch.empty((B, Cc), device="cuda", dtype=tdt)
+    chk(lib.dml_reduce_hw(xd.data_ptr() + 16 * xd.element_size(), red.data_ptr(), B, HW, Cc, ld, dt, st()))
+    z = torch.zeros((B, HW, ld), device="cuda", dtype=tdt)
+    chk(lib.dml_broadcast_hw(out.data_ptr(), z.data_ptr() + 8 * z.element_size(), B, HW, Cc, ld, dt, st()))
+    acc = xd.clone()
+    chk(lib.dml_avgpool_bwd_add(out.data_ptr(), acc.data_ptr() + 16 * acc.element_size(), B, HW, Cc, ld, dt, st()))
+    torch.cuda.synchronize()
+    ref = x[:, :, 16:16 + Cc].mean(1)
+    relclose(out.float().cpu(), ref, max(tol, 1e-5), "avgpool")
+    relclose(red.float().cpu(), ref * HW, max(tol, 1e-5), "reduce_hw")
+    assert torch.equal(z[:, :, 8:8 + Cc].float().cpu(), out.float().cpu().unsqueeze(1).expand(B, HW, Cc))
+    assert (z[:, :, :8] == 0).all() and (z[:, :, 8 + Cc:] == 0).all()
+    relclose(acc[:, :, 16:16 + Cc].float().cpu(),
+             x[:, :, 16:16 + Cc] + out.float().cpu().unsqueeze(1) / HW, max(tol, 1e-5), "avgpool bwd add")
+
+
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(5, 7, 20, 28), (4, 4, 16, 16), (5, 7, 13, 17), (1, 1, 6, 5)])
+def test_bilinear(lib, dname, shape):
+    dt, tdt, tol = DT[dname]
+    h, w, Hh, Ww = shape
+    B, Cc = 2, 8
+    x = qz(rnd("bl.x", (B, Cc, h, w)), tdt).requires_grad_(True)
+    y = F.interpolate(x, size=(Hh, Ww), mode="bilinear", align_corners=False)
+    gy = qz(rnd("bl.g", tuple(y.shape)), tdt)
+    y.backward(gy)
+    xd = nhwc(x.detach(), tdt)
+    yd = torch.empty((B, Hh, Ww, Cc), device="cuda", dtype=tdt)
+    chk(lib.dml_bilinear_fwd(xd.data_ptr(), yd.data_ptr(), B, h, w, Hh, Ww, Cc, Cc, Cc, dt, 0, 0, st()))
+    gyd = nhwc(gy, tdt)
+    dxd = torch.empty_like(xd)
+    chk(lib.dml_bilinear_bwd(gyd.data_ptr(), dxd.data_ptr(), B, h, w, Hh, Ww, Cc, Cc, Cc, dt, 0, 0, st()))
+    # fp32 gradient in, storage-dtype gradient out (final upsample backward)
+    gyf = gy.permute(0, 2, 3, 1).contiguous().cuda()
+    dx2 = torch.empty_like(xd)
+    chk(lib.dml_bilinear_bwd(gyf.data_ptr(), dx2.data_ptr(), B, h, w, Hh, Ww, Cc, Cc, Cc, dt, 1, 0, st()))
+    torch.cuda.synchronize()
+    relclose(nchw(yd), y.detach(), max(tol, 1e-6), "bilinear fwd")
+    relclose(nchw(dxd), x.grad, max(tol, 1e-5), "bilinear bwd")
+    relclose(nchw(dx2), x.grad, max(tol, 1e-5), "bilinear bwd f32 in")
+
+
+def test_bilinear_golden_g6(lib):
+    g = H.load_golden("g6_bilinear")
+    a = torch.from_numpy(g["a"])
+    xd = nhwc(a, torch.float32)
+    yd = torch.empty((1, 20, 28, 3 + 1), device="cuda")          # C must be a multiple of 4: pad one channel
+    xp = torch.zeros((1, 5, 7, 4), device="cuda")
+    xp[..., :3] = xd
+    chk(lib.dml_bilinear_fwd(xp.data_ptr(), yd.data_ptr(), 1, 5, 7, 20, 28, 4, 4, 4, 0, 0, 0, st()))
+    torch.cuda.synchronize()
+    relclose(nchw(yd[..., :3]), torch.from_numpy(g["ua"]), 1e-6, "G6 x4")
+
+
+def test_distance_head_golden_g1(lib):
+    g = H.load_golden("g1_distance_head")
+    x = torch.from_numpy(g["x"]).cuda()
+    B, Cc, Hh, Ww = x.shape
+    for protos, key in ((torch.from_numpy(g["centers"]), "logits"), (torch.from_numpy(g["protos"]), "logits_general")):
+        K = protos.shape[0]
+        pr = protos.cuda().contiguous()
+        lg = torch.empty((B, K, Hh, Ww), device="cuda")
+        ft = torch.empty((B, Hh, Ww, Cc), device="cuda")
+        am = torch.empty((B, Hh, Ww), device="cuda", dtype=torch.uint8)
+        ds = torch.empty((B, Hh, Ww), device="cuda")
+        chk(lib.dml_proto_dist_fwd(x.data_ptr(), pr.data_ptr(), lg.data_ptr(), ft.data_ptr(), am.data_ptr(),
+                                   ds.data_ptr(), B, Cc, K, Hh, Ww, st()))
+        torch.cuda.synchronize()
+        ref = torch.from_numpy(g[key])
+        relclose(lg.cpu(), ref, 1e-5, "G1 " + key)
+        assert torch.equal(ft.cpu(), torch.from_numpy(g["features"]))
+        assert torch.equal(am.cpu().long(), ref.argmax(1))
+        relclose(ds.cpu(), -ref.sum(1), 1e-5, "dissum raw")
+
+
+def test_upsample_dist_and_bwd(lib):
+    B, h, w, K = 2, 6, 5, 16
+    Hh, Ww = 24, 20
+    e = rnd("ud.e", (B, K, h, w), 2.0).requires_grad_(True)
+    up = F.interpolate(e, size=(Hh, Ww), mode="bilinear", align_corners=False)
+    feats = up.permute(0, 2, 3, 1)
+    protos = 3.0 * torch.eye(K)
+    logits = -((feats.unsqueeze(3) - protos) ** 2).sum(-1).permute(0, 3, 1, 2)
+    gl = rnd("ud.gl", (B, K, Hh, Ww))
+    gf = rnd("ud.gf", (B, Hh, Ww, K))
+    ((logits * gl).sum() + (feats * gf).sum()).backward()
+    ed = e.detach().permute(0, 2, 3, 1).contiguous().cuda()
+    pr = protos.cuda()
+    lg = torch.empty((B, K, Hh, Ww), device="cuda")
+    ft = torch.empty((B, Hh, Ww, K), device="cuda")
+    chk(lib.dml_upsample_dist_fwd(ed.data_ptr(), pr.data_ptr(), lg.data_ptr(), ft.data_ptr(), None, None, B, h, w, K,
+                                  K, Hh, Ww, st()))
+    df = torch.empty((B, Hh, Ww, K), device="cuda")
+    gld, gfd = gl.cuda(), gf.cuda()
+    chk(lib.dml_proto_dist_bwd(gld.data_ptr(), gfd.data_ptr(), ft.data_ptr(), pr.data_ptr(), df.data_ptr(), B, K, K,
+                               Hh, Ww, st()))
+    de = torch.empty((B, h, w, K), device="cuda")
+    chk(lib.dml_bilinear_bwd(df.data_ptr(), de.data_ptr(), B, h, w, Hh, Ww, K, K, K, 0, 1, 1, st()))
+    torch.cuda.synchronize()
+    relclose(lg.cpu(), logits.detach(), 1e-5, "fused upsample+dist logits")
+    relclose(ft.cpu(), feats.detach(), 1e-6, "fused features")
+    relclose(de.cpu().permute(0, 3, 1, 2), e.grad, 1e-5, "head backward to the embedding")
+
+
+def test_loss_golden_g2(lib):
+    import utils
+    g = H.load_golden("g2_losses")
+    lo = torch.from_numpy(g["logit"]).cuda().requires_grad_(True)
+    loss = utils.DMLLoss(alpha=0.01, ignore_index=-1)(lo, torch.from_numpy(g["label"]).cuda())
+    loss.backward()
+    assert abs(loss.item() - float(g["loss"])) <= 1e-5 * abs(float(g["loss"]))
+    relclose(lo.grad.cpu(), torch.from_numpy(g["grad"]), 1e-5, "DML grad")
+    lo2 = torch.from_numpy(g["logit2"]).cuda().requires_grad_(True)
+    l2 = utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0)(lo2, torch.from_numpy(g["label2"]).cuda(),
+                                                                            None)
+    (l2 * 2.0).backward()
+    assert abs(l2.item() - float(g["loss2"])) <= 1e-5 * abs(float(g["loss2"]))
+    relclose(lo2.grad.cpu(), 2 * torch.from_numpy(g["grad2"]), 1e-5, "CE/n grad (gout = 2)")
+
+
+def test_scores_golden_g7(lib):
+    import utils
+    g = H.load_golden("g7_scoring")
+    lg = torch.from_numpy(g["logits"]).cuda()
+    ft = torch.from_numpy(g["feats"]).cuda()
+    relclose(utils.dissum_score(lg, 1000.0, False).cpu()[0], torch.from_numpy(g["dissum_deeplab"]), 1e-5, "dissum")
+    relclose(utils.dissum_score(lg, 400.0, True).cpu()[0], torch.from_numpy(g["dissum_anomaly"]), 1e-5, "dissum400")
+    preds, msp = utils.argmax_msp(lg)
+    assert torch.equal(preds.cpu(), torch.from_numpy(g["preds"]))
+    relclose(msp.cpu(), torch.from_numpy(g["msp"]), 1e-5, "msp")
+    proto = utils.mean_prototype(g["shots"])
+    assert np.allclose(proto, g["proto"])
+    rel = utils.novel_relabel(preds, lg, ft, proto, -1.5, 16)
+    assert torch.equal(rel.cpu(), torch.from_numpy(g["relabel"]))
+
+
+def test_sgd_matches_torch(lib):
+    n = 1000 * 4 + 3
+    p0, g0 = rnd("sgd.p", (n,)), rnd("sgd.g", (n,))
+    p_ref = p0.clone().requires_grad_(True)
+    opt = torch.optim.SGD([p_ref], lr=0.05, momentum=0.9, weight_decay=1e-4)
+    pd, vd = p0.cuda(), torch.zeros(n, device="cuda")
+    for it in range(3):
+        gi = g0 * (it + 1)
+        p_ref.grad = gi.clone()
+        opt.step()
+        gd = gi.cuda()
+        chk(lib.dml_sgd_step(pd.data_ptr(), gd.data_ptr(), vd.data_ptr(), n, 0.05, 0.9, 1e-4, 1.0, st()))
+    torch.cuda.synchronize()
+    relclose(pd.cpu(), p_ref.detach(), 1e-6, "sgd params")
+
+
+def test_bias_grad(lib):
+    M, N = 1000, 16
+    dy = rnd("bg", (M, N))
+    for dt, tdt in ((0, torch.float32), (1, torch.bfloat16)):
+        d = dy.to("cuda", tdt)
+        db = torch.ones(N, device="cuda")
+        chk(lib.dml_bias_grad(d.data_ptr(), db.data_ptr(), M, N, N, dt, st()))
+        torch.cuda.synchronize()
+        relclose(db.cpu(), 1 + qz(dy, tdt).sum(0), 1e-4, "bias grad")
+
+
+def test_rejects_bad_arguments(lib):
+    from dmlnet._lib import ConvDesc
+    d = ConvDesc()
+    assert lib.dml_conv_igemm(C.byref(d), None) == -1
+    x = torch.zeros(64, device="cuda")
+    assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 6, 6, 6, 6, 1, 0, 0.0,
+                            0, st()) == -2
+    assert lib.dml_proto_dist_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 64, 16, 1, 1, st()) == -3
