@@ -219,7 +219,7 @@ def main():
     save("g4_bottleneck", **g4)
 
     # ------------------------------------------------------------------ G5 full model
-    print("G5 full model (train-mode BN, dropout off) 2x3x64x64")
+    print("G5 full model (train-mode BN, dropout off) 4x3x128x128")
     ref = R.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
     orc = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
     assert list(ref.state_dict().keys()) == list(orc.state_dict().keys()), "state_dict keys differ"
@@ -233,10 +233,19 @@ def main():
         m.train()
         m.classifier.aspp.project[3].eval()
         O.set_bn_momentum(m.backbone, 0.01)
-    img = H.synth_tensor(5, "g5.img", (2, 3, 64, 64))
-    lab = H.synth_labels(5, "g5.lab", (2, 64, 64), 16, 255, ignore_rows=3)
+    img = H.synth_tensor(5, "g5.img", (4, 3, 128, 128))
+    lab = H.synth_labels(5, "g5.lab", (4, 128, 128), 16, 255, ignore_rows=6)
     crit = ref_loss.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0)
+    # fp64 run of the same reference modules = "exact" arithmetic; tells how much of 1e-3 the reference's own
+    # fp32 rounding already uses up on this input
+    ref.double()
+    with torch.no_grad():
+        lg64 = ref(img.double())[0]
+    ref.float()
+    ref.load_state_dict(sd)
     lg, ctr, ft = ref(img)
+    ref_noise = float((lg.detach().double() - lg64).abs().max() / lg64.abs().max())
+    print("  reference fp32 vs fp64 on this input: %.3e (relative to max |logit|)" % ref_noise)
     loss = crit(lg, lab, ft)
     loss.backward()
     olg, octr, oft = orc(img)
@@ -258,14 +267,17 @@ def main():
     extra = {"grad__" + k.replace(".", "_"): (rg[k] if rg[k].numel() < 70000 else rg[k].flatten()[::16])
              for k in keep}
     rb = dict(ref.named_buffers())
-    save("g5_full_train", logits=lg.detach(), loss=loss.detach(),
+    save("g5_full_train", logits=lg.detach()[:, :, ::2, ::2], logits64=lg64[:, :, ::2, ::2].float(),
+         logits_checksum=H.checksum(lg), ref_noise=ref_noise, loss=loss.detach(),
          grad_names=np.array(list(rg.keys())), grad_checksums=np.stack([H.checksum(g) for g in rg.values()]),
          rm_stem=rb["backbone.bn1.running_mean"], rv_stem=rb["backbone.bn1.running_var"],
          rv_l4=rb["backbone.layer4.2.bn3.running_var"], rv_head=rb["classifier.classifier.1.running_var"],
          **extra)
 
     # ---- G8 trajectory: SGD(2 groups) + PolyLR on the same model / batch (main_embedding.py:385-392,458-507)
-    print("G8 6-step SGD/PolyLR trajectory on the full model")
+    print("G8 6-step SGD/PolyLR trajectory on the full model (2x3x64x64)")
+    img = H.synth_tensor(5, "g8.img", (2, 3, 64, 64))
+    lab = H.synth_labels(5, "g8.lab", (2, 64, 64), 16, 255, ignore_rows=3)
     ref.load_state_dict(sd)
     for p in ref.parameters():
         p.grad = None
