@@ -95,23 +95,24 @@ int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (112 instances; train: batch statistics, eval: running statistics).
  * ---------------------------------------------------------------------------------------------- */
-/* Chan-merge the conv epilogue partials -> mean / biased var -> scale = gamma*invstd,
- * shift = beta - mean*scale; updates running stats with the unbiased variance and `momentum`
- * exactly as nn.BatchNorm2d does; saves mean / invstd for the backward. */
+/* Chan-merge the conv epilogue partials -> mean / biased var -> scale = gamma*invstd, shift = beta,
+ * save_mean = mean (required; dml_bn_apply subtracts it before scaling so that low-variance channels do
+ * not cancel); updates running stats with the unbiased variance and `momentum` exactly as
+ * nn.BatchNorm2d does; saves invstd for the backward. */
 int dml_bn_finalize(const float* partials, int64_t M, int N, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 /* Standalone statistics for tensors that were not produced by dml_conv_igemm (writes the same
  * partial format). */
 int dml_bn_stats(const void* y, float* partials, int64_t M, int N, int ldy, int dtype, void* stream);
-/* eval mode: scale/shift from the running statistics. */
+/* eval mode: scale = gamma/sqrt(running_var+eps), shift = beta; pass running_mean as `mean` to dml_bn_apply. */
 int dml_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, int N,
                        void* stream);
-/* z = act(y*scale + shift [+ res]) with optional inverted dropout (network/utils.py:354).
- * y, res, z have independent pitches; y may be float when y_f32 != 0. */
+/* z = act((y - mean)*scale + shift [+ res]) with optional inverted dropout (network/utils.py:354).
+ * y, res, z have independent pitches. */
 int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                 int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype,
+                 const float* mean, int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype,
                  float drop_p, uint64_t drop_seed, void* stream);
 /* backward, pass 1: per-channel sums of g = dz*[z>0]*gscale and g*xhat -> partials[blocks][N][2].
  * returns the number of partial rows through *nblocks (host int). */
@@ -119,11 +120,11 @@ int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float*
                       const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
                       int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream);
 /* backward, pass 1b: fold partials, write dgamma/dbeta (+=) and the per-channel coefficients
- * coef[3][N] with dy = coef0*g + coef1*y + coef2. */
+ * coef[4][N] with dy = coef0*g + coef1*(y - coef3) + coef2  (coef3 = batch mean). */
 int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                         float* coef, void* stream);
-/* backward, pass 2: dy = coef0*g + coef1*y + coef2; optionally dres (+)= g for the identity branch. */
+/* backward, pass 2: dy = coef0*g + coef1*(y - coef3) + coef2; optionally dres (+)= g for the identity branch. */
 int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* coef, void* dy,
                      void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
                      int relu, float gscale, int dres_accum, int dtype, void* stream);

@@ -54,8 +54,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
         const float sc = g * invstd;
         scale[n] = sc;
-        shift[n] = b - (float)mean * sc;
-        if (save_mean) save_mean[n] = (float)mean;
+        shift[n] = b;
+        save_mean[n] = (float)mean;
         if (save_invstd) save_invstd[n] = invstd;
         if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
         if (running_var) {
@@ -90,9 +90,8 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     const int n = blockIdx.x * blockDim.x + threadIdx.x;
     if (n >= N) return;
     const float invstd = 1.0f / sqrtf(rv[n] + eps);
-    const float sc = (gamma ? gamma[n] : 1.f) * invstd;
-    scale[n] = sc;
-    shift[n] = (beta ? beta[n] : 0.f) - rm[n] * sc;
+    scale[n] = (gamma ? gamma[n] : 1.f) * invstd;
+    shift[n] = beta ? beta[n] : 0.f;          // z = (y - running_mean) * scale + shift
 }
 
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
@@ -106,8 +105,8 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
-    const float* __restrict__ shift, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
-    float drop_p, uint64_t drop_seed, FastDiv div_nv) {
+    const float* __restrict__ shift, const float* __restrict__ mean, int64_t M, int N, int ldy, int ldres,
+    int ldz, int relu, float drop_p, uint64_t drop_seed, FastDiv div_nv) {
     constexpr int V = Vec16<T>::N;
     const int NV = N / V;
     const int64_t total = M * NV;
@@ -117,17 +116,20 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
          i += (int64_t)gridDim.x * blockDim.x) {
         const uint32_t m = fdiv((uint32_t)i, div_nv);
         const int c = ((int)((uint32_t)i - m * (uint32_t)NV)) * V;
-        float v[V], sc[V], sh[V];
+        float v[V], sc[V], sh[V], mu[V];
         Vec16<T>::load(y + (int64_t)m * ldy + c, v);
 #pragma unroll
         for (int q = 0; q < V; q += 4) {
             const float4 a = *reinterpret_cast<const float4*>(scale + c + q);
             const float4 b = *reinterpret_cast<const float4*>(shift + c + q);
+            const float4 d = *reinterpret_cast<const float4*>(mean + c + q);
             sc[q] = a.x; sc[q + 1] = a.y; sc[q + 2] = a.z; sc[q + 3] = a.w;
             sh[q] = b.x; sh[q + 1] = b.y; sh[q + 2] = b.z; sh[q + 3] = b.w;
+            mu[q] = d.x; mu[q + 1] = d.y; mu[q + 2] = d.z; mu[q + 3] = d.w;
         }
+        // (y - mean) first: no cancellation between y*scale and mean*scale for low-variance channels
 #pragma unroll
-        for (int q = 0; q < V; ++q) v[q] = v[q] * sc[q] + sh[q];
+        for (int q = 0; q < V; ++q) v[q] = (v[q] - mu[q]) * sc[q] + sh[q];
         if (res != nullptr) {
             float r[V];
             Vec16<T>::load(res + (int64_t)m * ldres + c, r);
@@ -235,8 +237,8 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
         const double g = gamma ? (double)gamma[n] : 1.0, is = save_invstd[n], mu = save_mean[n];
         const double A = g * is;
         const double Bc = -A * is * dgamma_s / (double)M;
-        const double C0 = -A * dbeta_s / (double)M - Bc * mu;
-        coef[n] = (float)A; coef[N + n] = (float)Bc; coef[2 * N + n] = (float)C0;
+        const double C0 = -A * dbeta_s / (double)M;
+        coef[n] = (float)A; coef[N + n] = (float)Bc; coef[2 * N + n] = (float)C0; coef[3 * N + n] = (float)mu;
         if (dgamma) dgamma[n] += (float)dgamma_s;
         if (dbeta) dbeta[n] += (float)dbeta_s;
     }
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
 #pragma unroll
         for (int q = 0; q < V; ++q) {
             g[q] *= gscale;
-            o[q] = coef[c + q] * g[q] + coef[N + c + q] * yy[q] + coef[2 * N + c + q];
+            o[q] = coef[c + q] * g[q] + coef[N + c + q] * (yy[q] - coef[3 * N + c + q]) + coef[2 * N + c + q];
         }
         Vec16<T>::store(dy + (int64_t)m * lddy + c, o);
         if (dres != nullptr) {
@@ -288,7 +290,7 @@ inline bool vec_ok(int dtype, int a) { return a % (dtype == DML_BF16 ? 8 : 4) ==
 extern "C" int dml_bn_finalize(const float* partials, int64_t M, int N, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
-    if (!partials || !scale || !shift || M <= 0 || N <= 0) return DML_EINVAL;
+    if (!partials || !scale || !shift || !save_mean || M <= 0 || N <= 0) return DML_EINVAL;
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
                        static_cast<hipStream_t>(stream), partials, M, N, gamma, beta, running_mean, running_var,
                        momentum, eps, scale, shift, save_mean, save_invstd);
@@ -320,9 +322,9 @@ extern "C" int dml_bn_eval_coeffs(const float* gamma, const float* beta, const f
 }
 
 extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                            int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype, float drop_p,
-                            uint64_t drop_seed, void* stream) {
-    if (!y || !z || !scale || !shift || M <= 0 || N <= 0) return DML_EINVAL;
+                            const float* mean, int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype,
+                            float drop_p, uint64_t drop_seed, void* stream) {
+    if (!y || !z || !scale || !shift || !mean || M <= 0 || N <= 0) return DML_EINVAL;
     if (!vec_ok(dtype, N) || !vec_ok(dtype, ldy) || !vec_ok(dtype, ldz) || (res && !vec_ok(dtype, ldres)))
         return DML_EALIGN;
     if (M >= (1ll << 31)) return DML_EINVAL;
@@ -332,11 +334,11 @@ extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y,
-                           (const bf16_t*)res, (bf16_t*)z, scale, shift, M, N, ldy, ldres, ldz, relu, drop_p,
+                           (const bf16_t*)res, (bf16_t*)z, scale, shift, mean, M, N, ldy, ldres, ldz, relu, drop_p,
                            drop_seed, dv);
     else
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y,
-                           (const float*)res, (float*)z, scale, shift, M, N, ldy, ldres, ldz, relu, drop_p,
+                           (const float*)res, (float*)z, scale, shift, mean, M, N, ldy, ldres, ldz, relu, drop_p,
                            drop_seed, dv);
     DML_LAUNCH_CHECK();
     return 0;

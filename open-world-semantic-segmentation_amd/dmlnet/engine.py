@@ -326,10 +326,12 @@ class Plan:
         M = u.y.M
         u.scale, u.shift = self.fbuf(N), self.fbuf(N)
         g_ptr, b_ptr = bn.weight.data_ptr(), bn.bias.data_ptr()
+        mean_ptr = bn.running_mean.data_ptr()
         if self.training:
             groups = (M + STAT_ROWS - 1) // STAT_ROWS
             assert groups * N * 2 <= self.scratch.numel(), "BN statistics scratch too small"
             u.mean, u.invstd = self.fbuf(N), self.fbuf(N)
+            mean_ptr = u.mean.data_ptr()
             self.conv_fwd(x, conv, u.y, u.w, self.sp)
             args = self.call(self.fwd, lib.dml_bn_finalize, self.sp, M, N, g_ptr, b_ptr,
                              bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
@@ -341,7 +343,7 @@ class Plan:
                       bn.running_var.data_ptr(), float(bn.eps), u.scale.data_ptr(), u.shift.data_ptr(), N)
         u.gscale_slots = []
         u.apply_args = self.call(self.fwd, lib.dml_bn_apply, u.y.ptr, res.ptr if res is not None else None,
-                                 u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), M, N, u.y.ld,
+                                 u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), mean_ptr, M, N, u.y.ld,
                                  res.ld if res is not None else 0, u.z.ld, 1 if relu else 0, self.dt, 0.0, 0)
         if drop is not None and self.training:
             self.drop_units.append(u)
@@ -354,7 +356,7 @@ class Plan:
         N, M = u.conv.out_channels, u.y.M
         bn = u.bn
         dy = self.new(u.y.B, u.y.H, u.y.W, N)
-        coef = self.fbuf(3 * N)
+        coef = self.fbuf(4 * N)
         nblk = C.c_int(0)
         self.keep.append(nblk)
         a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, u.mean.data_ptr(),
@@ -588,8 +590,8 @@ class Engine:
             self.step_count += 1
             for u in plan.drop_units:
                 p = float(u.drop.p) if u.drop.training else 0.0      # F14: dropout module in eval() => off
-                u.apply_args[12] = p
-                u.apply_args[13] = (self.seed + 0x9E3779B97F4A7C15 * self.step_count) & 0xFFFFFFFFFFFFFFFF
+                u.apply_args[13] = p
+                u.apply_args[14] = (self.seed + 0x9E3779B97F4A7C15 * self.step_count) & 0xFFFFFFFFFFFFFFFF
                 for (a, i) in u.gscale_slots:
                     a[i] = 1.0 / (1.0 - p) if p > 0 else 1.0
             self.store.flat_nbt.add_(1)

@@ -239,7 +239,7 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, g_d.data_ptr(), b_d.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                             0.01, 1e-5, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
     chk(lib.dml_bn_apply(yd.data_ptr(), rd.data_ptr() if res else None, zd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                         M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, st()))
+                         mu.data_ptr(), M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, st()))
     torch.cuda.synchronize()
     relclose(rm.cpu(), rm_ref, 1e-4, "running_mean")
     relclose(rv.cpu(), rv_ref, 1e-4, "running_var")
@@ -263,7 +263,7 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     chk(lib.dml_bn_bwd_reduce(gzd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mu.data_ptr(), inv.data_ptr(),
                               part.data_ptr(), M, Cc, Cc, Cc, Cc, 1 if (relu or drop > 0) else 0, gs, dt,
                               C.byref(nblk), st()))
-    coef = torch.empty(3 * Cc, device="cuda")
+    coef = torch.empty(4 * Cc, device="cuda")
     dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
     chk(lib.dml_bn_bwd_finalize(part.data_ptr(), nblk, M, Cc, g_d.data_ptr(), mu.data_ptr(), inv.data_ptr(),
                                 dg.data_ptr(), db.data_ptr(), coef.data_ptr(), st()))
@@ -291,7 +291,7 @@ def test_bn_eval_coeffs(lib):
     torch.cuda.synchronize()
     x = rnd("ev.x", (2, Cc, 3, 3))
     ref = F.batch_norm(x, rm.cpu(), rv.cpu(), g.cpu(), b.cpu(), training=False, eps=1e-5)
-    got = x * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
+    got = (x - rm.cpu().view(1, -1, 1, 1)) * sc.cpu().view(1, -1, 1, 1) + sh.cpu().view(1, -1, 1, 1)
     relclose(got, ref, 1e-5, "eval bn")
 
 
@@ -492,6 +492,6 @@ def test_rejects_bad_arguments(lib):
     d = ConvDesc()
     assert lib.dml_conv_igemm(C.byref(d), None) == -1
     x = torch.zeros(64, device="cuda")
-    assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 6, 6, 6, 6, 1, 0, 0.0,
-                            0, st()) == -2
+    assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 6, 6, 6, 6,
+                            1, 0, 0.0, 0, st()) == -2
     assert lib.dml_proto_dist_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 64, 16, 1, 1, st()) == -3
