@@ -61,7 +61,11 @@ def synth_state_dict(shapes: "OrderedDict[str, tuple]", seed: int = 1) -> "Order
         elif leaf == "running_var":
             a = g.uniform(0.5, 1.5, shape)
         elif leaf == "weight":
-            a = g.uniform(0.5, 1.5, shape)
+            # BN gamma.  The last BN of every residual branch gets a small gamma (as zero_init_residual /
+            # a trained network would): with gamma ~ 1 everywhere a random-init ResNet-101 amplifies fp32
+            # rounding ~5000x through depth and the reference's OWN gradients move by 5-20 % between fp32 and
+            # fp64 (or 8 vs 1 CPU threads), which would make any 1e-3 parity bar meaningless.
+            a = g.uniform(0.05, 0.15, shape) if key.endswith("bn3.weight") else g.uniform(0.5, 1.5, shape)
         elif leaf == "bias":
             # BN beta or the final conv bias (network/utils.py:23)
             a = g.standard_normal(shape) * 0.1 if not key.endswith("classifier.3.bias") \

@@ -38,8 +38,8 @@ def build(dtype=torch.float32, train=True, seed=1):
 
 
 def g5_inputs():
-    img = H.synth_tensor(5, "g5.img", (4, 3, 128, 128)).cuda()
-    lab = H.synth_labels(5, "g5.lab", (4, 128, 128), 16, 255, ignore_rows=6).cuda()
+    img = H.synth_tensor(5, "g5.img", (2, 3, 64, 64)).cuda()
+    lab = H.synth_labels(5, "g5.lab", (2, 64, 64), 16, 255, ignore_rows=3).cuda()
     return img, lab
 
 
@@ -55,16 +55,13 @@ def test_g5_full_train_step_matches_reference():
     m = build()
     img, lab = g5_inputs()
     lg, ctr, ft = m(img)
-    assert lg.shape == (4, 16, 128, 128) and ft.shape == (4, 128, 128, 16) and ctr.shape == (16, 16)
+    assert lg.shape == (2, 16, 64, 64) and ft.shape == (2, 64, 64, 16) and ctr.shape == (16, 16)
     loss = utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0)(lg, lab, ft)
     loss.backward()
-    # The reference's own fp32 result sits g["ref_noise"] (3.2e-4) away from its fp64 evaluation on this input
-    # and moves by ~5e-4 with the CPU thread count (DESIGN.md "parity bar").  Bar: 1e-3 against the exact
-    # (fp64) arithmetic of the reference algorithm, and 1e-3 + that noise against its fp32 run.
-    sub = lg[:, :, ::2, ::2]
-    relclose(sub, T(g["logits64"]), TOL, "logits vs fp64 reference")
-    relclose(sub, T(g["logits"]), TOL + float(g["ref_noise"]), "logits vs fp32 reference")
-    assert np.allclose(H.checksum(lg), g["logits_checksum"], rtol=1e-3)
+    # On these (well-conditioned, helpers.synth_state_dict) weights the reference's own fp32 run sits 3.6e-6
+    # (logits) / 1.5e-4 (worst parameter gradient) away from its fp64 evaluation, so 1e-3 is a real bar.
+    relclose(lg, T(g["logits"]), TOL, "logits vs fp32 reference")
+    relclose(lg, T(g["logits64"]), TOL, "logits vs fp64 reference")
     assert abs(loss.item() - float(g["loss"])) <= TOL * abs(float(g["loss"]))
     grads = OrderedDict((k, p.grad) for k, p in m.named_parameters())
     names = [str(n) for n in g["grad_names"]]
@@ -72,7 +69,7 @@ def test_g5_full_train_step_matches_reference():
     bad = []
     for (k, gr), cs in zip(grads.items(), g["grad_checksums"]):
         got = H.checksum(gr)
-        if not np.allclose(got[1:], cs[1:], rtol=5e-3):
+        if not np.allclose(got[1:], cs[1:], rtol=2e-3):
             bad.append((k, got, cs))
     assert not bad, "gradient checksums differ for %d tensors, first: %r" % (len(bad), bad[:3])
     for key in ("backbone.bn1.weight", "backbone.layer1.0.conv1.weight", "backbone.layer2.0.downsample.0.weight",
@@ -81,7 +78,7 @@ def test_g5_full_train_step_matches_reference():
         ref = T(g["grad__" + key.replace(".", "_")])
         got = grads[key].detach().cpu()
         got = got if got.numel() < 70000 else got.contiguous().flatten()[::16]
-        relclose(got.reshape(ref.shape), ref, 3 * TOL, "grad " + key)
+        relclose(got.reshape(ref.shape), ref, 2 * TOL, "grad " + key)
     bufs = dict(m.named_buffers())
     relclose(bufs["backbone.bn1.running_mean"], T(g["rm_stem"]), TOL, "running_mean stem")
     relclose(bufs["backbone.bn1.running_var"], T(g["rv_stem"]), TOL, "running_var stem")
@@ -110,12 +107,12 @@ def test_g8_sgd_polylr_trajectory():
         opt.step()
         sched.step()
         losses.append(loss.item())
-    assert np.allclose(losses, t["losses"], rtol=5e-3), (losses, t["losses"].tolist())
+    assert np.allclose(losses, t["losses"], rtol=3e-3), (losses, t["losses"].tolist())
     assert np.allclose([g_["lr"] for g_ in opt.param_groups], t["lrs"][-1], rtol=1e-6)
     sd = m.state_dict()
-    relclose(sd["classifier.classifier.3.bias"], T(t["b_last"]), 5e-3, "final bias after 6 steps")
-    relclose(sd["backbone.conv1.weight"], T(t["w_stem"]), 5e-3, "stem weight after 6 steps")
-    relclose(sd["backbone.bn1.running_mean"], T(t["rm_stem"]), 5e-3, "stem running mean after 6 steps")
+    relclose(sd["classifier.classifier.3.bias"], T(t["b_last"]), 2e-3, "final bias after 6 steps")
+    relclose(sd["backbone.conv1.weight"], T(t["w_stem"]), 2e-3, "stem weight after 6 steps")
+    relclose(sd["backbone.bn1.running_mean"], T(t["rm_stem"]), 2e-3, "stem running mean after 6 steps")
 
 
 def test_g5b_eval_forward_config1():
@@ -166,7 +163,7 @@ def test_against_oracle_fresh_input_all_param_grads():
         rel = err / (q.grad.abs().max().item() + 1e-12)
         if rel > worst[1]:
             worst = (k, rel)
-    assert worst[1] <= 5 * TOL, "worst parameter gradient: %s rel %.3e" % worst
+    assert worst[1] <= 3 * TOL, "worst parameter gradient: %s rel %.3e" % worst
 
 
 def test_features_out_carries_grad_and_eval_no_grad():
@@ -194,7 +191,7 @@ def test_bf16_mode_tracks_fp32():
     loss = utils.CrossEntropyLoss(ignore_index=255)(lg, lab, ft)
     loss.backward()
     assert torch.isfinite(lg).all()
-    relclose(lg, ref, 0.15, "bf16 logits vs fp32 logits")
+    relclose(lg, ref, 0.05, "bf16 logits vs fp32 logits")
     g = m.classifier.classifier[3].weight.grad
     assert torch.isfinite(g).all() and g.abs().sum() > 0
 

@@ -131,19 +131,19 @@ def test_state_dict_contract():
 def test_g5_full_train_and_g8_trajectory():
     g = H.load_golden("g5_full_train")
     m = full_model()
-    img = H.synth_tensor(5, "g5.img", (4, 3, 128, 128))
-    lab = H.synth_labels(5, "g5.lab", (4, 128, 128), 16, 255, ignore_rows=6)
+    img = H.synth_tensor(5, "g5.img", (2, 3, 64, 64))
+    lab = H.synth_labels(5, "g5.lab", (2, 64, 64), 16, 255, ignore_rows=3)
     lg, ctr, ft = m(img)
     loss = O.ce_over_n(lg, lab, 255)
     loss.backward()
-    # a different CPU / thread count moves the reference's own fp32 result by ~5e-4 on this net
-    close(lg[:, :, ::2, ::2], T(g["logits"]), 1e-3)
+    close(lg, T(g["logits"]), 1e-4)
+    close(lg, T(g["logits64"]), 1e-4)
     close(loss, T(g["loss"]), 1e-5)
     grads = OrderedDict((k, p.grad) for k, p in m.named_parameters())
     for (k, gr), cs in zip(grads.items(), g["grad_checksums"]):
-        assert np.allclose(H.checksum(gr)[1:], cs[1:], rtol=5e-3), k
+        assert np.allclose(H.checksum(gr)[1:], cs[1:], rtol=1e-3), k
     close(grads["classifier.classifier.3.bias"], T(g["grad__classifier_classifier_3_bias"]), 1e-4)
-    close(grads["backbone.conv1.weight"], T(g["grad__backbone_conv1_weight"]), 3e-3)
+    close(grads["backbone.conv1.weight"], T(g["grad__backbone_conv1_weight"]), 1e-3)
     close(dict(m.named_buffers())["backbone.bn1.running_var"], T(g["rv_stem"]))
     # G8: 6 SGD steps with two LR groups + PolyLR
     t = H.load_golden("g8_trajectory")
@@ -154,7 +154,7 @@ def test_g5_full_train_and_g8_trajectory():
     opt = O.make_optimizer(m, lr=lr, weight_decay=1e-4)
     losses = [float(O.train_step(m, opt, img, lab, it, total, [0.1 * lr, lr],
                                  lambda a, b: O.ce_over_n(a, b, 255))) for it in range(6)]
-    assert np.allclose(losses, t["losses"], rtol=3e-3), (losses, t["losses"])
+    assert np.allclose(losses, t["losses"], rtol=1e-3), (losses, t["losses"])
     assert np.allclose([gp["lr"] for gp in opt.param_groups], t["lrs"][-1], rtol=1e-6)
     close(m.state_dict()["classifier.classifier.3.bias"], T(t["b_last"]), 1e-3)
     close(m.state_dict()["backbone.conv1.weight"], T(t["w_stem"]), 1e-3)
