@@ -1,0 +1,265 @@
+#!/usr/bin/env python3
+"""Headline benchmark: images/sec of one DMLNet train step (DeepLabV3+/ResNet-101 OS16 + pixel-prototype
+distance head + DML loss + SGD), synthetic 768x768 crops, 16 images per GPU (BASELINE.json configs[2];
+configs[3] when launched on 8 ranks).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--dtype bf16|f32] [--batch 16] [--size 768]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+        bench.py --gpus N --steps K --warmup W
+
+Prints ONE JSON line on rank 0.  `value` = global images / (max-over-ranks wall time of exactly K steps),
+inputs resident in HBM.  `roofline` = the dominant kernel class (implicit-GEMM convolution on MFMA):
+algorithmic conv FLOPs of one step / summed duration of its conv launches, measured with HIP events on the
+launch stream in a separate profiled pass right after the timed region.  `cpu_baseline` = the CPU oracle
+(a PyTorch restatement of the reference, kind "port") timed on this box's host cores on a bounded sample.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "open-world-semantic-segmentation_amd")
+for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK = {"bf16": 2.5e15, "f32": 157.3e12}      # dense MFMA peaks, MI355X_MICROARCH.md
+HBM_PEAK = 8.0e12
+
+
+def synth_batch(batch, size, rank, device):
+    g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+    img = torch.randn(batch, 3, size, size, generator=g)
+    lab = torch.randint(0, 16, (batch, size, size), generator=g)
+    lab[:, : max(1, size * 38 // 768)] = 255            # ~5 % ignored pixels
+    return img.to(device), lab.to(device)
+
+
+def conv_flops_of_plan(plan):
+    """Algorithmic FLOPs (2*MAC on the un-padded channel counts) of every conv launch of one train step."""
+    from dmlnet._lib import ConvDesc, WgradDesc
+    import ctypes as C
+    lib = plan.lib
+    total = 0.0
+    per_op = {}
+    for name, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
+        for i, (fn, args) in enumerate(ops):
+            if fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad:
+                d = args[0]._obj
+                # undo the padding of the stem (3->8) and of the decoder concat (304->320)
+                if fn is lib.dml_conv_igemm and d.mode == 1:
+                    # data gradient: same MACs as the forward conv = dY pixels x Cout x taps x Cin
+                    cin = 304 if d.N == 320 else d.N
+                    fl = 2.0 * d.B * d.Hi * d.Wi * d.C * d.R * d.S * cin
+                else:
+                    cin = 3 if d.C == 8 else (304 if d.C == 320 else d.C)
+                    fl = 2.0 * d.B * d.Ho * d.Wo * d.N * d.R * d.S * cin
+                per_op[(name, i)] = fl
+                total += fl
+    return total, per_op
+
+
+def profile_convs(model, engine, step_fn, n_steps):
+    """Re-run `n_steps` steps with a HIP event pair around every conv launch (same stream)."""
+    from dmlnet import engine as E
+    lib = engine.lib
+    records = []
+    orig_run = E.Plan.run
+
+    def timed_run(ops, stream, start=0, stop=None, hook=None):
+        stop = len(ops) if stop is None else stop
+        for i in range(start, stop):
+            fn, args = ops[i]
+            is_conv = fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad
+            if is_conv:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+            rc = fn(*args, stream)
+            if rc:
+                raise RuntimeError("kernel failed rc=%d" % rc)
+            if is_conv:
+                e1.record()
+                records.append((id(ops), i, "wgrad" if fn is lib.dml_conv_wgrad else "igemm", e0, e1))
+            if hook is not None:
+                hook(i)
+
+    E.Plan.run = staticmethod(timed_run)
+    try:
+        for _ in range(n_steps):
+            step_fn()
+        torch.cuda.synchronize()
+    finally:
+        E.Plan.run = orig_run
+    t = {"igemm": 0.0, "wgrad": 0.0}
+    cnt = {"igemm": 0, "wgrad": 0}
+    for _, _, kind, e0, e1 in records:
+        t[kind] += e0.elapsed_time(e1) * 1e-3
+        cnt[kind] += 1
+    return {k: t[k] / n_steps for k in t}, {k: cnt[k] // n_steps for k in cnt}
+
+
+def bench_distance_kernel(batch, size, device):
+    """Standalone pixel->prototype distance kernel (192 B/px algorithmic: 64 read + 64 logits + 64 features)."""
+    from dmlnet import _lib
+    lib = _lib.load()
+    x = torch.randn(batch, 16, size, size, device=device)
+    protos = 3.0 * torch.eye(16, device=device)
+    lg = torch.empty_like(x)
+    ft = torch.empty(batch, size, size, 16, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    args = (x.data_ptr(), protos.data_ptr(), lg.data_ptr(), ft.data_ptr(), None, None, batch, 16, 16, size, size, st)
+    for _ in range(3):
+        lib.dml_proto_dist_fwd(*args)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    n = 20
+    e0.record()
+    for _ in range(n):
+        lib.dml_proto_dist_fwd(*args)
+    e1.record()
+    torch.cuda.synchronize()
+    sec = e0.elapsed_time(e1) * 1e-3 / n
+    bytes_ = 192.0 * batch * size * size
+    return {"kernel": "proto_dist_fwd", "bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK / 1e9,
+            "unit": "GB/s", "frac": bytes_ / sec / HBM_PEAK, "bytes_per_px": 192, "ms": sec * 1e3}
+
+
+def cpu_baseline(size, threads):
+    """The CPU oracle (port of the reference's PyTorch path) on the host cores: 768x768 bs=2 train step."""
+    import helpers as H
+    from oracle import dmlnet_ref as O
+    torch.set_num_threads(threads)
+    bs = 2
+    o = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    o.train()
+    O.set_bn_momentum(o.backbone, 0.01)
+    opt = O.make_optimizer(o, lr=0.01, weight_decay=1e-4)
+    g = torch.Generator().manual_seed(1234)
+    img = torch.randn(bs, 3, size, size, generator=g)
+    lab = torch.randint(0, 16, (bs, size, size), generator=g)
+    lab[:, :38] = 255
+    times = []
+    for it in range(3):
+        t0 = time.perf_counter()
+        O.train_step(o, opt, img, lab, it, 100, [0.001, 0.01], lambda a, b: O.dml_loss(a, b, 0.01, 255))
+        times.append(time.perf_counter() - t0)
+    sec = min(times[1:])
+    return {"value": bs / sec, "unit": "images/sec", "cores": threads, "kind": "port",
+            "sample": "oracle (PyTorch CPU fp32 restatement of the reference) train step, %dx%d bs=%d, "
+                      "best of 2 after 1 warm-up, %.2f s/step" % (size, size, bs, sec)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--batch", type=int, default=16, help="images per GPU")
+    ap.add_argument("--size", type=int, default=768)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-profile", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0)
+    args = ap.parse_args()
+
+    from dmlnet import parallel
+    rank, local, world = parallel.init_from_env()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+
+    import network
+    import utils
+    from dmlnet.optim import FusedSGD
+
+    torch.manual_seed(1)
+    model = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    model.to(device)
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.train()
+    utils.set_bn_momentum(model.backbone, momentum=0.01)                     # main_embedding.py:379
+    lr = 0.01
+    opt = FusedSGD([{"params": model.backbone.parameters(), "lr": 0.1 * lr},
+                    {"params": model.classifier.parameters(), "lr": lr}],
+                   lr=lr, momentum=0.9, weight_decay=1e-4).bind(model)       # main_embedding.py:385-388
+    sched = utils.PolyLR(opt, 30000, power=0.9)
+    crit = utils.DMLLoss(alpha=0.01, ignore_index=255, sync=True if world > 1 else None)
+    if world > 1:
+        model._engine.store.bind(device)
+        model._engine.reducer = parallel.GradReducer(model._engine.store, bucket_mb=32.0, average=False)
+    img, lab = synth_batch(args.batch, args.size, rank, device)
+
+    def step():
+        opt.zero_grad()
+        logits, centers, feats = model(img)
+        loss = crit(logits, lab, feats)
+        loss.backward()
+        opt.step()
+        sched.step()
+        return loss
+
+    for _ in range(args.warmup):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    final_loss = float(loss.item())
+
+    out = None
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        value = args.batch * world * args.steps / elapsed
+        out = {"metric": "images/sec train-step, DeepLabV3+R101 768x768 bs=16; % HBM & MFMA roofline",
+               "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "DMLNet train step: DeepLabV3+/ResNet-101 OS16 fwd+bwd, prototype-distance "
+                                      "head, DML loss (DCE+VL), SGD; %dx%d crops, %d images/GPU, 16 prototypes, "
+                                      "random-init weights" % (args.size, args.size, args.batch),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "final_loss": final_loss}}
+    if world == 1 and not args.no_profile:
+        plan = next(p for k, p in model._engine.plans.items() if k[4])
+        flops, _ = conv_flops_of_plan(plan)
+        tsec, counts = profile_convs(model, model._engine, step, 2)
+        conv_sec = tsec["igemm"] + tsec["wgrad"]
+        n_launch = counts["igemm"] + counts["wgrad"]
+        peak = PEAK[args.dtype]
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (all conv launches of a step)",
+                           "achieved": flops / conv_sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                           "frac": flops / conv_sec / peak, "traffic": None,
+                           "flops_per_step": flops, "launches_per_step": n_launch,
+                           "avg_launch_ms": conv_sec / n_launch * 1e3, "conv_ms_per_step": conv_sec * 1e3,
+                           "igemm_ms_per_step": tsec["igemm"] * 1e3, "wgrad_ms_per_step": tsec["wgrad"] * 1e3,
+                           "whole_step_frac": flops / (elapsed / args.steps) / peak}
+        out["hbm_kernel"] = bench_distance_kernel(args.batch, args.size, device)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
+        out["cpu_baseline"] = cpu_baseline(args.size, threads)
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
