@@ -190,7 +190,7 @@ class Act:
 
 class ConvUnit:
     __slots__ = ("conv", "bn", "x", "y", "z", "relu", "res", "w", "wt", "scale", "shift", "mean", "invstd",
-                 "Cp", "drop", "apply_args", "gscale_slots")
+                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy")
 
 
 class Plan:
@@ -356,6 +356,7 @@ class Plan:
         N, M = u.conv.out_channels, u.y.M
         bn = u.bn
         dy = self.new(u.y.B, u.y.H, u.y.W, N)
+        u.dz, u.dy = dz, dy
         coef = self.fbuf(4 * N)
         nblk = C.c_int(0)
         self.keep.append(nblk)

@@ -1,0 +1,47 @@
+"""Debug helper (GPU box): per-layer activation error of the HIP forward vs the fp64 oracle, next to the fp32
+oracle's own error."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "open-world-semantic-segmentation_amd")]
+import torch
+import helpers as H
+import network
+from oracle import dmlnet_ref as O
+
+shape = (2, 3, 64, 96)
+seed = 11
+torch.set_num_threads(32)
+img = H.synth_tensor(11, "fresh2.img", shape)
+
+def oracle_acts(dtype):
+    o = O.deeplabv3plus_embedding_resnet101(16, 16)
+    o.load_state_dict(H.synth_state_dict(H.shapes_of(o), seed=seed))
+    o = o.to(dtype); o.train(); o.classifier.aspp.project[3].eval()
+    acts = {}
+    for name, mod in o.named_modules():
+        if isinstance(mod, torch.nn.Conv2d):
+            mod.register_forward_hook(lambda m_, i_, out, name=name: acts.__setitem__(name, out.detach().double()))
+    with torch.no_grad():
+        lg, _, _ = o(img.to(dtype))
+    return acts, lg.double()
+
+a64, l64 = oracle_acts(torch.float64)
+a32, l32 = oracle_acts(torch.float32)
+m = network.deeplabv3plus_embedding_resnet101(16, 16, False)
+m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=seed))
+m.cuda().train(); m.classifier.aspp.project[3].eval()
+with torch.no_grad():
+    lg, _, _ = m(img.cuda())
+torch.cuda.synchronize()
+plan = next(iter(m._engine.plans.values()))
+names = {id(mod): n for n, mod in m.named_modules()}
+print("%-40s %10s %10s %10s" % ("conv output", "hip", "ref32", "scale"))
+for u in plan.units:
+    n = names[id(u.conv)]
+    y = u.y
+    t = y.t.float().view(y.B, y.H, y.W, -1)[..., :y.C].permute(0, 3, 1, 2).cpu().double()
+    ref = a64[n]
+    sc = ref.abs().max().item()
+    print("%-40s %10.2e %10.2e %10.2e" % (n, (t - ref).abs().max().item() / sc, (a32[n] - ref).abs().max().item() / sc, sc))
+print("logits: hip %.2e ref32 %.2e" % ((lg.cpu().double() - l64).abs().max().item() / l64.abs().max().item(),
+                                       (l32 - l64).abs().max().item() / l64.abs().max().item()))
