@@ -31,7 +31,9 @@ def act(a):     # Act -> [M, C] double on cpu
     idx = off + torch.arange(M, device=flat.device).unsqueeze(1) * a.ld + torch.arange(a.C, device=flat.device).unsqueeze(0)
     return flat[idx].double().cpu()
 
-print("%-40s %10s %10s %10s" % ("unit", "bn dy", "dgamma", "wgrad"))
+print("%-40s %10s %10s %10s %10s" % ("unit", "bn dy", "dgamma", "wgrad", "dgrad"))
+from collections import Counter
+consumers = Counter(id(u.x.root) for u in plan.units)
 for u in plan.units:
     n = names[id(u.conv)]
     dz, y, z, dy = act(u.dz), act(u.y), act(u.z), act(u.dy)
@@ -54,5 +56,12 @@ for u in plan.units:
     out = F.conv2d(xr, w, None, u.conv.stride, u.conv.padding, u.conv.dilation)
     out.backward(dyn)
     e_w = (u.conv.weight.grad.double().cpu() - w.grad).abs().max().item() / (w.grad.abs().max().item() + 1e-30)
-    flag = " <<<" if max(e_dy, e_dg, e_w) > (1e-4 if dtype == torch.float32 else 2e-2) else ""
-    print("%-40s %10.2e %10.2e %10.2e%s" % (n, e_dy, e_dg, e_w, flag))
+    e_dx = float("nan")
+    if consumers[id(u.x.root)] == 1 and u.x.root.grad is not None and u.x is u.x.root and "layer" in n and "conv1" not in n:
+        xin = torch.zeros((u.x.B, cin, u.x.H, u.x.W), dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin, u.conv.weight.detach().double().cpu().contiguous(), None, u.conv.stride, u.conv.padding,
+                 u.conv.dilation).backward(dyn)
+        got = act(u.x.grad).view(u.x.B, u.x.H, u.x.W, -1).permute(0, 3, 1, 2)[:, :cin]
+        e_dx = (got - xin.grad).abs().max().item() / (xin.grad.abs().max().item() + 1e-30)
+    flag = " <<<" if max(e_dy, e_dg, e_w, e_dx if e_dx == e_dx else 0) > (1e-4 if dtype == torch.float32 else 2e-2) else ""
+    print("%-40s %10.2e %10.2e %10.2e %10.2e%s" % (n, e_dy, e_dg, e_w, e_dx, flag))
