@@ -152,11 +152,27 @@ __global__ __launch_bounds__(256) void upsample_dist_fwd_kernel(const float* __r
             sX = sX < 0.f ? 0.f : sX;
             const int x0 = min((int)sX, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
             const float lx1 = sX - (float)x0, lx0 = 1.f - lx1;
+            if ((C & 3) == 0) {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                if (c < C)
-                    f[c][p] = ly0 * (lx0 * r0[x0 * C + c] + lx1 * r0[x1 * C + c]) +
-                              ly1 * (lx0 * r1[x0 * C + c] + lx1 * r1[x1 * C + c]);
+                for (int c = 0; c < CM; c += 4) {
+                    if (c < C) {
+                        const float4 a = *reinterpret_cast<const float4*>(r0 + x0 * C + c);
+                        const float4 bq = *reinterpret_cast<const float4*>(r0 + x1 * C + c);
+                        const float4 cq = *reinterpret_cast<const float4*>(r1 + x0 * C + c);
+                        const float4 d = *reinterpret_cast<const float4*>(r1 + x1 * C + c);
+                        f[c][p] = ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * cq.x + lx1 * d.x);
+                        f[c + 1][p] = ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * cq.y + lx1 * d.y);
+                        f[c + 2][p] = ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * cq.z + lx1 * d.z);
+                        f[c + 3][p] = ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * cq.w + lx1 * d.w);
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    if (c < C)
+                        f[c][p] = ly0 * (lx0 * r0[x0 * C + c] + lx1 * r0[x1 * C + c]) +
+                                  ly1 * (lx0 * r1[x0 * C + c] + lx1 * r1[x1 * C + c]);
+                }
             }
         }
         const int64_t pix = (int64_t)Y * W + xg * PX;
@@ -212,12 +228,31 @@ __global__ __launch_bounds__(256) void proto_dist_bwd_kernel(const float* __rest
 #pragma unroll
         for (int p = 0; p < PX; ++p) {
             const int64_t o = (b * HW + pix + p) * C;
+            if ((C & 3) == 0) {
 #pragma unroll
-            for (int c = 0; c < CM; ++c) {
-                if (c < C) {
-                    float v = -2.f * (gs[p] * feats[o + c] - gm[c][p]);
-                    if (gfeats != nullptr) v += gfeats[o + c];
-                    df[o + c] = v;
+                for (int c = 0; c < CM; c += 4) {
+                    if (c < C) {
+                        const float4 fv = *reinterpret_cast<const float4*>(feats + o + c);
+                        float4 v;
+                        v.x = -2.f * (gs[p] * fv.x - gm[c][p]);
+                        v.y = -2.f * (gs[p] * fv.y - gm[c + 1][p]);
+                        v.z = -2.f * (gs[p] * fv.z - gm[c + 2][p]);
+                        v.w = -2.f * (gs[p] * fv.w - gm[c + 3][p]);
+                        if (gfeats != nullptr) {
+                            const float4 gq = *reinterpret_cast<const float4*>(gfeats + o + c);
+                            v.x += gq.x; v.y += gq.y; v.z += gq.z; v.w += gq.w;
+                        }
+                        *reinterpret_cast<float4*>(df + o + c) = v;
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int c = 0; c < CM; ++c) {
+                    if (c < C) {
+                        float v = -2.f * (gs[p] * feats[o + c] - gm[c][p]);
+                        if (gfeats != nullptr) v += gfeats[o + c];
+                        df[o + c] = v;
+                    }
                 }
             }
         }

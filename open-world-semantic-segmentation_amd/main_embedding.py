@@ -1,0 +1,123 @@
+#!/usr/bin/env python3
+"""Training driver with the reference's step semantics and argparse surface (main_embedding.py:27-99,331-510
+there), on the MI355X path.  One process per GPU (torchrun); `--synthetic` (the only data source shipped:
+datasets are out of scope) feeds Cityscapes-shaped random crops that stay resident in HBM.
+
+    python main_embedding.py --synthetic --crop_size 768 --batch_size 16 --total_itrs 50 --dtype bf16
+    torchrun --nproc-per-node 8 --master-addr 127.0.0.1 main_embedding.py --synthetic --batch_size 128
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+import torch  # noqa: E402
+
+import network  # noqa: E402
+import utils  # noqa: E402
+from dmlnet import parallel  # noqa: E402
+from dmlnet.optim import FusedSGD  # noqa: E402
+
+
+def get_argparser():
+    p = argparse.ArgumentParser()
+    p.add_argument("--model", default="deeplabv3plus_embedding_resnet101")
+    p.add_argument("--num_classes", type=int, default=16)          # main_embedding.py:335-336 hard-codes 16
+    p.add_argument("--output_stride", type=int, default=16, choices=[8, 16])
+    p.add_argument("--total_itrs", type=int, default=30000)
+    p.add_argument("--lr", type=float, default=0.01)
+    p.add_argument("--lr_policy", default="poly", choices=["poly", "step"])
+    p.add_argument("--step_size", type=int, default=10000)
+    p.add_argument("--weight_decay", type=float, default=1e-4)
+    p.add_argument("--batch_size", type=int, default=16, help="GLOBAL batch size, sharded over the ranks")
+    p.add_argument("--crop_size", type=int, default=768)
+    p.add_argument("--loss_type", default="cross_entropy", choices=["cross_entropy", "dml"])
+    p.add_argument("--alpha", type=float, default=0.01, help="weight of the variance loss for --loss_type dml")
+    p.add_argument("--ckpt", default=None)
+    p.add_argument("--continue_training", action="store_true")
+    p.add_argument("--save_dir", default="checkpoints")
+    p.add_argument("--val_interval", type=int, default=0, help="save a checkpoint every N iterations (0 = never)")
+    p.add_argument("--print_interval", type=int, default=10)
+    p.add_argument("--random_seed", type=int, default=1)
+    p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    return p
+
+
+def main():
+    opts = get_argparser().parse_args()
+    if not opts.synthetic:
+        raise SystemExit("only --synthetic data is available (datasets are outside the hot path)")
+    rank, local, world = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    torch.manual_seed(opts.random_seed)
+
+    model = getattr(network, opts.model)(num_classes=opts.num_classes, output_stride=opts.output_stride,
+                                         pretrained_backbone=False)
+    utils.set_bn_momentum(model.backbone, momentum=0.01)                           # :379
+    model.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32)
+    optimizer = FusedSGD([{"params": model.backbone.parameters(), "lr": 0.1 * opts.lr},
+                          {"params": model.classifier.parameters(), "lr": opts.lr}],
+                         lr=opts.lr, momentum=0.9, weight_decay=opts.weight_decay).bind(model)   # :385-388
+    if opts.lr_policy == "poly":
+        scheduler = utils.PolyLR(optimizer, opts.total_itrs, power=0.9)           # :391-392
+    else:
+        scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=opts.step_size, gamma=0.1)
+    sync = True if world > 1 else None
+    if opts.loss_type == "dml":
+        criterion = utils.DMLLoss(alpha=opts.alpha, ignore_index=255, sync=sync)
+    else:
+        criterion = utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0, sync=sync)   # :401
+
+    cur_itrs, best_score = 0, 0.0
+    if opts.ckpt and os.path.isfile(opts.ckpt):                                    # :421-434
+        ck = torch.load(opts.ckpt, map_location="cpu")
+        model.load_state_dict(ck["model_state"])
+        if opts.continue_training:
+            optimizer.load_state_dict(ck["optimizer_state"])
+            scheduler.load_state_dict(ck["scheduler_state"])
+            cur_itrs, best_score = ck["cur_itrs"], ck["best_score"]
+    model.to(device)
+    model.train()
+    if world > 1:
+        model._engine.store.bind(device)
+        model._engine.reducer = parallel.GradReducer(model._engine.store, bucket_mb=32.0, average=False)
+
+    def save_ckpt(path):                                                           # :404-414
+        torch.save({"cur_itrs": cur_itrs, "model_state": model.state_dict(),
+                    "optimizer_state": optimizer.state_dict(), "scheduler_state": scheduler.state_dict(),
+                    "best_score": best_score}, path)
+
+    lo, hi = parallel.shard_range(opts.batch_size, rank, world)
+    g = torch.Generator().manual_seed(1234 + rank)
+    images = torch.randn(hi - lo, 3, opts.crop_size, opts.crop_size, generator=g).to(device)
+    labels = torch.randint(0, opts.num_classes, (hi - lo, opts.crop_size, opts.crop_size), generator=g)
+    labels[:, : max(1, opts.crop_size * 38 // 768)] = 255
+    labels = labels.to(device)
+
+    interval_loss, t0 = None, time.perf_counter()
+    while cur_itrs < opts.total_itrs:
+        cur_itrs += 1
+        optimizer.zero_grad()
+        outputs, centers, features = model(images)                                 # :466
+        loss = criterion(outputs, labels, features)
+        loss.backward()
+        optimizer.step()
+        interval_loss = loss.detach() if interval_loss is None else interval_loss + loss.detach()
+        if cur_itrs % opts.print_interval == 0:                                    # one D2H sync per interval
+            dt = time.perf_counter() - t0
+            if rank == 0:
+                print("Itrs %d/%d, Loss=%f, %.1f img/s" % (cur_itrs, opts.total_itrs,
+                                                           float(interval_loss) / opts.print_interval,
+                                                           opts.batch_size * opts.print_interval / dt))
+            interval_loss, t0 = None, time.perf_counter()
+        if opts.val_interval and cur_itrs % opts.val_interval == 0 and rank == 0:
+            utils.mkdir(opts.save_dir)
+            save_ckpt(os.path.join(opts.save_dir, "latest_%s_synthetic_os%d.pth" % (opts.model, opts.output_stride)))
+        scheduler.step()                                                           # :507
+
+
+if __name__ == "__main__":
+    main()
