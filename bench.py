@@ -97,10 +97,32 @@ def profile_convs(model, engine, step_fn, n_steps):
         E.Plan.run = orig_run
     t = {"igemm": 0.0, "wgrad": 0.0}
     cnt = {"igemm": 0, "wgrad": 0}
-    for _, _, kind, e0, e1 in records:
-        t[kind] += e0.elapsed_time(e1) * 1e-3
+    per_op = {}
+    for oid, i, kind, e0, e1 in records:
+        dt = e0.elapsed_time(e1) * 1e-3
+        t[kind] += dt
         cnt[kind] += 1
+        per_op[(oid, i)] = per_op.get((oid, i), 0.0) + dt / n_steps
+    profile_convs.per_op = per_op
     return {k: t[k] / n_steps for k in t}, {k: cnt[k] // n_steps for k in cnt}
+
+
+def dump_conv_table(plan, path):
+    """Per-launch table (shape, ms, TFLOP/s) of the profiled pass, for kernel tuning."""
+    lib = plan.lib
+    _, fl = conv_flops_of_plan(plan)
+    rows = []
+    for name, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
+        for i, (fn, args) in enumerate(ops):
+            if fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad:
+                d = args[0]._obj
+                sec = profile_convs.per_op.get((id(ops), i), 0.0)
+                kind = "wgrad" if fn is lib.dml_conv_wgrad else ("dgrad" if d.mode == 1 else "fwd")
+                rows.append(dict(kind=kind, B=d.B, Hi=d.Hi, Wi=d.Wi, C=d.C, Ho=d.Ho, Wo=d.Wo, N=d.N, R=d.R,
+                                 stride=d.stride, dil=d.dil, ms=sec * 1e3,
+                                 tflops=fl[(name, i)] / sec / 1e12 if sec > 0 else 0.0, gflop=fl[(name, i)] / 1e9))
+    with open(path, "w") as f:
+        json.dump(rows, f)
 
 
 def bench_distance_kernel(batch, size, device):
@@ -164,6 +186,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--dump-conv", default=None, help="write a per-launch conv table (json) from the profiled pass")
     args = ap.parse_args()
 
     from dmlnet import parallel
@@ -240,6 +263,8 @@ def main():
         plan = next(p for k, p in model._engine.plans.items() if k[4])
         flops, _ = conv_flops_of_plan(plan)
         tsec, counts = profile_convs(model, model._engine, step, 2)
+        if args.dump_conv:
+            dump_conv_table(plan, args.dump_conv)
         conv_sec = tsec["igemm"] + tsec["wgrad"]
         n_launch = counts["igemm"] + counts["wgrad"]
         peak = PEAK[args.dtype]

@@ -11,6 +11,7 @@
 // that every lane ends up with 4 consecutive output channels of one pixel (8/16-byte stores).
 // The epilogue can emit per-channel BatchNorm partial statistics straight from the accumulators.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -48,6 +49,130 @@ template <> __device__ __forceinline__ int swz_chunk<bf16_t>(int row, int chunk)
 }
 // fp32: 128-byte rows, 8 chunks of 16 B
 template <> __device__ __forceinline__ int swz_chunk<float>(int row, int chunk) { return chunk ^ (row & 7); }
+
+// ------------------------------------------------------------------------------------------------
+// shared epilogue: BN partial statistics, bias, accumulate, fp32 / storage-dtype stores
+// acc[i][j][reg] = out[m = mw0 + j*16 + (lane&15)][n = nw0 + i*16 + (lane>>4)*4 + reg]
+// ------------------------------------------------------------------------------------------------
+template <typename T, int NT, int MT>
+__device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int mw0, const int nw0,
+                                              const int lr, const int lq) {
+    constexpr int TM = MT * 16;
+
+    if (a.stats != nullptr) {
+        const int cnt = min(TM, max(0, a.M - mw0));
+        if (cnt > 0) {
+            const float inv = 1.0f / (float)cnt;
+            const int grp = mw0 / TM;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const bool v = (mw0 + j * 16 + lr) < a.M;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) s[q] += v ? acc[i][j][q] : 0.f;
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) s[q] += __shfl_xor(s[q], o, 64);
+                }
+                float m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const bool v = (mw0 + j * 16 + lr) < a.M;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float dlt = acc[i][j][q] - s[q] * inv;
+                        m2[q] += v ? dlt * dlt : 0.f;
+                    }
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+#pragma unroll
+                    for (int o = 1; o < 16; o <<= 1) m2[q] += __shfl_xor(m2[q], o, 64);
+                }
+                if (lr == 0) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const int n = nw0 + i * 16 + lq * 4 + q;
+                        if (n < a.N) {
+                            float* p = a.stats + ((int64_t)grp * a.N + n) * 2;
+                            p[0] = s[q];
+                            p[1] = m2[q];
+                        }
+                    }
+                }
+            }
+        }
+    }
+
+    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldy & 3) == 0);
+#pragma unroll
+    for (int j = 0; j < MT; ++j) {
+        const int m = mw0 + j * 16 + lr;
+        if (m >= a.M) continue;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const int n = nw0 + i * 16 + lq * 4;
+            if (n >= a.N) continue;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.bias != nullptr) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (n + q < a.N) v[q] += a.bias[n + q];
+            }
+            const int64_t off = (int64_t)m * a.ldy + n;
+            if (a.y_f32) {
+                float* yp = static_cast<float*>(a.y) + off;
+                if (vec_ok) {
+                    if (a.accum) {
+                        const float4 o = *reinterpret_cast<const float4*>(yp);
+                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                    }
+                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
+                }
+            } else if constexpr (sizeof(T) == 4) {
+                float* yp = static_cast<float*>(a.y) + off;
+                if (vec_ok) {
+                    if (a.accum) {
+                        const float4 o = *reinterpret_cast<const float4*>(yp);
+                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                    }
+                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
+                }
+            } else {
+                bf16_t* yp = static_cast<bf16_t*>(a.y) + off;
+                if (vec_ok) {
+                    if (a.accum) {
+                        const uint2 o = *reinterpret_cast<const uint2*>(yp);
+                        v[0] += __uint_as_float(o.x << 16);
+                        v[1] += __uint_as_float(o.x & 0xffff0000u);
+                        v[2] += __uint_as_float(o.y << 16);
+                        v[3] += __uint_as_float(o.y & 0xffff0000u);
+                    }
+                    uint2 pk;
+                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                    *reinterpret_cast<uint2*>(yp) = pk;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.N) yp[q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[q]) + v[q] : v[q]);
+                }
+            }
+        }
+    }
+}
 
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
@@ -244,124 +369,151 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
         cur ^= 1;
     }
 
-    // ---------------------------------------------------------------- epilogue
-    // acc[i][j][reg] = out[m = m0 + wm*64 + j*16 + (lane&15)][n = n0 + wn*TN + i*16 + (lane>>4)*4 + reg]
-    const int mw0 = m0 + wm * TM;
-    const int nw0 = n0 + wn * TN;
+    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+}
 
-    if (a.stats != nullptr) {
-        const int cnt = min(TM, max(0, a.M - mw0));
-        if (cnt > 0) {
-            const float inv = 1.0f / (float)cnt;
-            const int grp = mw0 / TM;
+// ------------------------------------------------------------------------------------------------
+// bf16 forward / data-gradient kernel, LDS-DMA version (requires C % 32 == 0).
+// Operand tiles go HBM -> LDS with buffer_load ... lds (no VGPR round trip, no ds_write): a 4-stage ring,
+// tiles issued 3 K-steps ahead, counted vmcnt waits and ONE barrier per K-step.  Zero padding / masked rows
+// come from the buffer descriptor's bounds check (an out-of-range voffset writes zeros to LDS).  The LDS image
+// is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address.
+// ------------------------------------------------------------------------------------------------
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+template <int BN, int MODE>
+__global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
+                                                                  const uint32_t w_bytes) {
+    typedef bf16_t T;
+    constexpr int BM = 128, NST = 4, LA = 3;
+    constexpr int STAGE = (BM + BN) * BK;          // elements per ring stage
+    constexpr int TM = 64, TN = BN / 2, MT = 4, NT = TN / 16;
+    constexpr int A_I = 2, B_I = BN / 64;           // DMA instructions per wave per tile (1 KiB = 16 rows each)
+    constexpr int NI = A_I + B_I;
+    constexpr uint32_t OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(1024))) T smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk_m = tile / a.nblk_n, blk_n = tile - blk_m * a.nblk_n;
+    const int m0 = blk_m * BM, n0 = blk_n * BN;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)w_bytes, 0x00020000);
+
+    // lane -> (row within a 16-row DMA piece, 16-byte chunk); source chunk carries the XOR swizzle
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
+
+    int a_iy[A_I], a_ix[A_I], a_img[A_I];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                float s[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    const bool v = (mw0 + j * 16 + lr) < a.M;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) s[q] += v ? acc[i][j][q] : 0.f;
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) s[q] += __shfl_xor(s[q], o, 64);
-                }
-                float m2[4] = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    const bool v = (mw0 + j * 16 + lr) < a.M;
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const float dlt = acc[i][j][q] - s[q] * inv;
-                        m2[q] += v ? dlt * dlt : 0.f;
-                    }
-                }
-#pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) m2[q] += __shfl_xor(m2[q], o, 64);
-                }
-                if (lr == 0) {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = nw0 + i * 16 + lq * 4 + q;
-                        if (n < a.N) {
-                            float* p = a.stats + ((int64_t)grp * a.N + n) * 2;
-                            p[0] = s[q];
-                            p[1] = m2[q];
-                        }
-                    }
-                }
+    for (int jj = 0; jj < A_I; ++jj) {
+        const int m = m0 + (wave * A_I + jj) * 16 + prow;
+        if (m < a.M) {
+            const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+            const uint32_t yo = fdiv(rem, a.div_wo);
+            const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+            if (MODE == 0) {
+                a_iy[jj] = (int)yo * a.stride - a.pad;
+                a_ix[jj] = (int)xo * a.stride - a.pad;
+            } else {
+                a_iy[jj] = (int)yo + a.pad;
+                a_ix[jj] = (int)xo + a.pad;
             }
+            a_img[jj] = (int)b * a.Hi;
+        } else {
+            a_iy[jj] = -(1 << 28);
+            a_ix[jj] = -(1 << 28);
+            a_img[jj] = 0;
         }
     }
-
-    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldy & 3) == 0);
+    uint32_t b_off[B_I];
 #pragma unroll
-    for (int j = 0; j < MT; ++j) {
-        const int m = mw0 + j * 16 + lr;
-        if (m >= a.M) continue;
+    for (int jj = 0; jj < B_I; ++jj) {
+        const int n = n0 + (wave * B_I + jj) * 16 + prow;
+        b_off[jj] = n < a.N ? (uint32_t)(((int64_t)n * a.Ktot + lchunk * 8) * 2) : OOB;
+    }
+
+    int ir = 0, is = 0, ic0 = 0;       // filter tap / channel offset of the next tile to issue
+    auto issue = [&](int kt, int stage) {
+        T* sbase = smem + stage * STAGE;
+#pragma unroll
+        for (int jj = 0; jj < A_I; ++jj) {
+            int ys, xs;
+            bool ok = true;
+            if (MODE == 0) {
+                ys = a_iy[jj] + ir * a.dil;
+                xs = a_ix[jj] + is * a.dil;
+            } else {
+                const int ty = a_iy[jj] - ir * a.dil, tx = a_ix[jj] - is * a.dil;
+                if (a.stride == 2) {
+                    ok = ((ty | tx) & 1) == 0;
+                    ys = ty >> 1;
+                    xs = tx >> 1;
+                } else {
+                    ys = ty;
+                    xs = tx;
+                }
+            }
+            ok = ok && ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+            const uint32_t voff = ok ? (uint32_t)((((a_img[jj] + ys) * a.Wi + xs) * a.ldx + ic0 + lchunk * 8) * 2) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + (wave * A_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < B_I; ++jj) {
+            const uint32_t voff = b_off[jj] == OOB ? OOB : b_off[jj] + (uint32_t)(kt * BK * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * BK + (wave * B_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
+        }
+        ic0 += BK;
+        if (ic0 >= a.C) {
+            ic0 = 0;
+            if (++is == a.S) { is = 0; ++ir; }
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int KT = a.Ktot / BK;
+#pragma unroll
+    for (int t = 0; t < LA; ++t)
+        if (t < KT) issue(t, t);
+
+    const int lr = lane & 15, lq = lane >> 4;
+    for (int kt = 0; kt < KT; ++kt) {
+        if (kt + 2 < KT) wait_vmcnt<2 * NI>();
+        else if (kt + 1 < KT) wait_vmcnt<NI>();
+        else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (kt + LA < KT) issue(kt + LA, (kt + LA) % NST);
+        const T* as = smem + (kt % NST) * STAGE + (wm * TM) * BK;
+        const T* bs = smem + (kt % NST) * STAGE + BM * BK + (wn * TN) * BK;
+        mfma_bf16x8 bf[NT], af[MT];
 #pragma unroll
         for (int i = 0; i < NT; ++i) {
-            const int n = nw0 + i * 16 + lq * 4;
-            if (n >= a.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (a.bias != nullptr) {
-#pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (n + q < a.N) v[q] += a.bias[n + q];
-            }
-            const int64_t off = (int64_t)m * a.ldy + n;
-            if (a.y_f32) {
-                float* yp = static_cast<float*>(a.y) + off;
-                if (vec_ok) {
-                    if (a.accum) {
-                        const float4 o = *reinterpret_cast<const float4*>(yp);
-                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-                    }
-                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
-                }
-            } else if constexpr (sizeof(T) == 4) {
-                float* yp = static_cast<float*>(a.y) + off;
-                if (vec_ok) {
-                    if (a.accum) {
-                        const float4 o = *reinterpret_cast<const float4*>(yp);
-                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-                    }
-                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
-                }
-            } else {
-                bf16_t* yp = static_cast<bf16_t*>(a.y) + off;
-                if (vec_ok) {
-                    if (a.accum) {
-                        const uint2 o = *reinterpret_cast<const uint2*>(yp);
-                        v[0] += __uint_as_float(o.x << 16);
-                        v[1] += __uint_as_float(o.x & 0xffff0000u);
-                        v[2] += __uint_as_float(o.y << 16);
-                        v[3] += __uint_as_float(o.y & 0xffff0000u);
-                    }
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(yp) = pk;
-                } else {
-#pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < a.N) yp[q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[q]) + v[q] : v[q]);
-                }
-            }
+            const int row = i * 16 + lr;
+            bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + row * BK + swz_chunk<T>(row, lq) * 8);
         }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int row = j * 16 + lr;
+            af[j] = *reinterpret_cast<const mfma_bf16x8*>(as + row * BK + swz_chunk<T>(row, lq) * 8);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
     }
+    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -546,6 +698,30 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
     ConvArgs a = base;
     const bool aligned = (a.C % BK) == 0;
     a.nblk_m = (a.M + 127) / 128;
+    if constexpr (sizeof(T) == 2) {
+        // LDS-DMA kernel: bf16, K tiles inside one tap, tensors addressable with a 31-bit byte offset
+        // Measured on MI355X (tools/bench_conv.py): the DMA ring wins on large grids with long K loops (decoder
+        // 3x3 304->256 @192^2: 771 vs 711 TFLOP/s) and loses ~10 % where only ~2 blocks/CU exist (its 64 KB of
+        // LDS allows 2 blocks/CU vs 5 for the register-staged kernel).  DML_CONV_DMA=1 / DML_CONV_V1=1 force one.
+        static const bool use_v1 = getenv("DML_CONV_V1") != nullptr;
+        static const bool force_dma = getenv("DML_CONV_DMA") != nullptr;
+        const bool big = (int64_t)a.nblk_m * ((a.N + 127) / 128) >= 2048 && a.Ktot / BK >= 32;
+        const int64_t xb = ((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx * 2 + (int64_t)a.C * 2;
+        const int64_t wb = (int64_t)a.N * a.Ktot * 2;
+        if (!use_v1 && (big || force_dma) && aligned && a.N > 32 && xb < (1ll << 31) && wb < (1ll << 31)) {
+            if (a.N > 64) {
+                a.nblk_n = (a.N + 127) / 128;
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st,
+                                   a, (uint32_t)xb, (uint32_t)wb);
+            } else {
+                a.nblk_n = 1;
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<64, MODE>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
+                                   (uint32_t)xb, (uint32_t)wb);
+            }
+            DML_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     auto go = [&](auto bn_tag, auto al_tag) {
         constexpr int BN = decltype(bn_tag)::value;
         constexpr bool AL = decltype(al_tag)::value;

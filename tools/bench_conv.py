@@ -1,0 +1,49 @@
+"""Micro-benchmark (GPU box): conv kernels on the headline shapes; sweeps wgrad split-K and epilogue options."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path[:0] = [ROOT, os.path.join(ROOT, "open-world-semantic-segmentation_amd")]
+import torch
+from dmlnet import _lib
+from dmlnet._lib import ConvDesc, WgradDesc
+lib = _lib.load()
+st = torch.cuda.current_stream().cuda_stream
+bf = torch.bfloat16
+
+def timeit(fn, n=20):
+    for _ in range(3): fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n): fn()
+    e1.record(); torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / n * 1e-3
+
+SHAPES = [  # B, H, W, C, N, k, dil
+    (16, 48, 48, 256, 256, 3, 1), (16, 48, 48, 1024, 256, 1, 1), (16, 48, 48, 256, 1024, 1, 1),
+    (16, 192, 192, 320, 256, 3, 1), (16, 48, 48, 2048, 256, 3, 12), (16, 192, 192, 64, 256, 1, 1),
+    (16, 96, 96, 128, 512, 1, 1), (16, 48, 48, 512, 512, 3, 2)]
+which = sys.argv[1] if len(sys.argv) > 1 else "all"
+for (B, H, W, Cc, N, k, dil) in SHAPES:
+    pad = dil * (k // 2)
+    x = torch.randn(B, H, W, Cc, device="cuda").to(bf)
+    w = (torch.randn(N, k, k, Cc, device="cuda") * 0.05).to(bf)
+    y = torch.empty(B, H, W, N, device="cuda", dtype=bf)
+    dy = torch.randn(B, H, W, N, device="cuda").to(bf)
+    M = B * H * W
+    stats = torch.empty((M + 63) // 64 * N * 2, device="cuda")
+    fl = 2.0 * M * N * k * k * Cc
+    line = "B%d %dx%d C%d->N%d k%d d%d | " % (B, H, W, Cc, N, k, dil)
+    if which in ("all", "fwd"):
+        for use_stats in (True, False):
+            d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=stats.data_ptr() if use_stats else None,
+                         pre_scale=None, pre_shift=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k,
+                         stride=1, dil=dil, pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
+            t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
+            line += "fwd%s %.1fus %.0fTF | " % ("+st" if use_stats else "", t * 1e6, fl / t / 1e12)
+    if which in ("all", "wgrad"):
+        dw = torch.zeros(N, k, k, Cc, device="cuda")
+        for sk in (0, 4, 8, 16, 32, 64):
+            wg = WgradDesc(x=x.data_ptr(), dy=dy.data_ptr(), dw=dw.data_ptr(), B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N,
+                           ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1, splitk=sk)
+            t = timeit(lambda: lib.dml_conv_wgrad(C.byref(wg), st))
+            line += "wg sk%d %.1fus %.0fTF | " % (sk, t * 1e6, fl / t / 1e12)
+    print(line)
