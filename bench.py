@@ -262,7 +262,9 @@ def main():
     if world == 1 and not args.no_profile:
         plan = next(p for k, p in model._engine.plans.items() if k[4])
         flops, _ = conv_flops_of_plan(plan)
+        model._engine.overlap_wgrad = False          # profiled pass: every conv launch alone on one stream
         tsec, counts = profile_convs(model, model._engine, step, 2)
+        model._engine.overlap_wgrad = True
         if args.dump_conv:
             dump_conv_table(plan, args.dump_conv)
         conv_sec = tsec["igemm"] + tsec["wgrad"]

@@ -15,6 +15,7 @@ from __future__ import annotations
 
 import ctypes as C
 import itertools
+import os
 from typing import List, Optional
 
 import torch
@@ -212,6 +213,8 @@ class Plan:
         self.seed_slots = []           # (args_list, index)
         self.prepped_version = None
         self.param_last_op = {}        # param index -> index of the last backward op that adds to its gradient
+        self.side = {}                 # backward op index -> True if it must first wait for the main stream
+        self._side_events = None
         self.drop_units = []
         # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
         # of this network; backward: <= ~1100*N*2)
@@ -296,6 +299,7 @@ class Plan:
         Cm = conv.in_channels
         gptr = self.e.store.grad_ptr_of(conv.weight)
         tmp = None
+        first = len(self.bwd)
         if Cp != Cm:
             tmp = self.fbuf(conv.out_channels * kh * kw * Cp)
             self.call(self.bwd, self.lib.dml_fill_f32, tmp.data_ptr(), tmp.numel(), 0.0)
@@ -306,6 +310,10 @@ class Plan:
         self.call(self.bwd, self.lib.dml_conv_wgrad, C.byref(dsc))
         if tmp is not None:
             self.call(self.bwd, self.lib.dml_unpad_wgrad, tmp.data_ptr(), gptr, conv.out_channels, kh * kw, Cm, Cp)
+        # weight gradients only feed the optimizer: they run on a side stream, next to the HBM-bound BN backward
+        # and the data gradient of the following layers (Plan.run_backward)
+        for i in range(first, len(self.bwd)):
+            self.side[i] = (i == first)
         self.mark_grad(conv.weight)
 
     def mark_grad(self, p):
@@ -516,6 +524,35 @@ class Plan:
                 _lib.check(rc, fn.__name__)
         self.prepped_version = key
 
+    def run_backward(self, hook=None):
+        """Replay the backward plan: weight gradients on the engine's side stream, everything else on the
+        caller's current stream; joined at the end."""
+        main = torch.cuda.current_stream(self.device)
+        if not self.e.overlap_wgrad or not self.side:
+            Plan.run(self.bwd, main.cuda_stream, hook=hook)
+            return
+        side = self.e.side_stream(self.device)
+        if self._side_events is None:
+            self._side_events = {i: torch.cuda.Event() for i, f in self.side.items() if f}
+        side.wait_stream(main)
+        ms, ss = main.cuda_stream, side.cuda_stream
+        sidemap, events = self.side, self._side_events
+        for i, (fn, args) in enumerate(self.bwd):
+            flag = sidemap.get(i)
+            if flag is None:
+                rc = fn(*args, ms)
+            else:
+                if flag:
+                    ev = events[i]
+                    ev.record(main)
+                    side.wait_event(ev)
+                rc = fn(*args, ss)
+            if rc:
+                _lib.check(rc, getattr(fn, "__name__", "kernel") + " (bwd op %d)" % i)
+            if hook is not None:
+                hook(i)
+        main.wait_stream(side)
+
     @staticmethod
     def run(ops, stream, start=0, stop=None, hook=None):
         stop = len(ops) if stop is None else stop
@@ -538,8 +575,15 @@ class Engine:
         self.plans = {}
         self._protos = {}
         self.reducer = None             # parallel.GradReducer, attached for multi-GPU runs
+        self.overlap_wgrad = os.environ.get("DML_OVERLAP_WGRAD", "1") != "0"
+        self._side = {}
         self.step_count = 0
         self.seed = 0x5DEECE66D
+
+    def side_stream(self, device):
+        if device not in self._side:
+            self._side[device] = torch.cuda.Stream(device=device)
+        return self._side[device]
 
     def prototypes(self, k: int) -> torch.Tensor:
         """centers = 3 * I_K (network/utils.py:103-106); built once per device instead of every forward."""
@@ -617,5 +661,5 @@ class Engine:
         if self.reducer is not None:
             self.reducer.run_backward(plan, stream)
         else:
-            Plan.run(plan.bwd, stream)
+            plan.run_backward()
         self.store.end_backward()

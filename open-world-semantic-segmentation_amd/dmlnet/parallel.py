@@ -67,9 +67,8 @@ class GradReducer:
         return self._sched[key]
 
     def run_backward(self, plan, stream):
-        from .engine import Plan
         if self.world == 1:
-            Plan.run(plan.bwd, stream)
+            plan.run_backward()
             return
         dev = self.store.flat_g.device
         if self.comm_stream is None:
@@ -81,16 +80,16 @@ class GradReducer:
         def hook(i):
             for b in sched.get(i, ()):
                 lo, hi, _ = self.buckets[b]
-                ev = torch.cuda.Event()
-                ev.record(cur)
-                self.comm_stream.wait_event(ev)
+                self.comm_stream.wait_stream(cur)
+                if plan.e.overlap_wgrad:
+                    self.comm_stream.wait_stream(plan.e.side_stream(dev))      # weight gradients run there
                 with torch.cuda.stream(self.comm_stream):
                     seg = flat_g[lo:hi]
                     dist.all_reduce(seg, group=self.group)
                     if self.average:
                         seg.div_(self.world)
 
-        Plan.run(plan.bwd, stream, hook=hook)
+        plan.run_backward(hook=hook)
         cur.wait_stream(self.comm_stream)
 
 
