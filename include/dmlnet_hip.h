@@ -83,6 +83,14 @@ int dml_conv_wgrad(const DmlWgradDesc* d, void* stream);
  * the transposed copy wt[Cp][RS][N] used by the data gradient. */
 int dml_prep_weight(const float* w_master, void* w, void* wt, int N, int RS, int Cm, int Cp, int dtype,
                     void* stream);
+/* The same for every convolution of a model in one launch; `descs_device` is a DEVICE array. */
+typedef struct DmlPrepDesc {
+    const float* src;     /* master [N][RS][Cm] */
+    void* w;              /* [N][RS][Cp] */
+    void* wt;             /* [Cp][RS][N] or NULL */
+    int32_t N, RS, Cm, Cp;
+} DmlPrepDesc;
+int dml_prep_weights(const DmlPrepDesc* descs_device, int count, int dtype, void* stream);
 /* dst[N][RS][Cm] += src[N][RS][Cp] (drops the padding channels of a padded weight gradient). */
 int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int Cm, int Cp, void* stream);
 /* bias gradient: db[n] += sum_m dy[m][n]  (network/utils.py:23) */

@@ -25,30 +25,40 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ partials, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* scale, float* shift, float* save_mean, float* save_invstd) {
-    __shared__ double sh[3][FIN_SL][FIN_CH];
+    __shared__ double sh[FIN_SL][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
     const int64_t G = (M + DML_STAT_ROWS - 1) / DML_STAT_ROWS;
-    Moments acc = {0.0, 0.0, 0.0};
-    if (n < N) {
-        for (int64_t g = sl; g < G; g += FIN_SL) {
-            const int64_t rows = min((int64_t)DML_STAT_ROWS, M - g * DML_STAT_ROWS);
-            const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
-            merge(acc, (double)rows, (double)p.x / (double)rows, (double)p.y);
-        }
-    }
-    sh[0][sl][ch] = acc.n; sh[1][sl][ch] = acc.mean; sh[2][sl][ch] = acc.m2;
+    const int last_rows = (int)(M - (G - 1) * DML_STAT_ROWS);
+    // pass 1: exact total sum -> global mean
+    double s = 0.0;
+    if (n < N)
+        for (int64_t g = sl; g < G; g += FIN_SL) s += (double)partials[(g * N + n) * 2];
+    sh[sl][ch] = s;
     __syncthreads();
-    for (int s = FIN_SL / 2; s > 0; s >>= 1) {
-        if (sl < s) {
-            Moments a = {sh[0][sl][ch], sh[1][sl][ch], sh[2][sl][ch]};
-            merge(a, sh[0][sl + s][ch], sh[1][sl + s][ch], sh[2][sl + s][ch]);
-            sh[0][sl][ch] = a.n; sh[1][sl][ch] = a.mean; sh[2][sl][ch] = a.m2;
+    for (int k = FIN_SL / 2; k > 0; k >>= 1) {
+        if (sl < k) sh[sl][ch] += sh[sl + k][ch];
+        __syncthreads();
+    }
+    const double gmean = sh[0][ch] / (double)M;
+    __syncthreads();
+    // pass 2 (partials are L2-hot): M2 = sum_g [ M2_g + n_g (mean_g - mean)^2 ]  (Chan et al., no cancellation)
+    double q = 0.0;
+    if (n < N)
+        for (int64_t g = sl; g < G; g += FIN_SL) {
+            const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
+            const double rows = g == G - 1 ? (double)last_rows : (double)DML_STAT_ROWS;
+            const double d = (double)p.x / rows - gmean;
+            q += (double)p.y + rows * d * d;
         }
+    sh[sl][ch] = q;
+    __syncthreads();
+    for (int k = FIN_SL / 2; k > 0; k >>= 1) {
+        if (sl < k) sh[sl][ch] += sh[sl + k][ch];
         __syncthreads();
     }
     if (sl == 0 && n < N) {
-        const double mean = sh[1][0][ch], m2 = sh[2][0][ch], cnt = sh[0][0][ch];
+        const double mean = gmean, m2 = sh[0][ch], cnt = (double)M;
         const double var_b = m2 / cnt;
         const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
         const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;

@@ -58,6 +58,27 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restric
     }
 }
 
+// all convolutions of a model in ONE launch: blockIdx.y selects the descriptor
+template <typename T>
+__global__ __launch_bounds__(256) void prep_weights_kernel(const DmlPrepDesc* __restrict__ descs) {
+    const DmlPrepDesc d = descs[blockIdx.y];
+    const float* __restrict__ src = d.src;
+    T* __restrict__ w = static_cast<T*>(d.w);
+    T* __restrict__ wt = static_cast<T*>(d.wt);
+    const int N = d.N, RS = d.RS, Cm = d.Cm, Cp = d.Cp;
+    const int64_t total = (int64_t)N * RS * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % Cp);
+        const int64_t t = i / Cp;
+        const int rs = (int)(t % RS);
+        const int n = (int)(t / RS);
+        const float v = c < Cm ? src[((int64_t)n * RS + rs) * Cm + c] : 0.f;
+        Elem<T>::st(w + i, v);
+        if (wt != nullptr) Elem<T>::st(wt + ((int64_t)c * RS + rs) * N + n, v);
+    }
+}
+
 __global__ __launch_bounds__(256) void unpad_wgrad_kernel(const float* __restrict__ src, float* __restrict__ dst,
                                                           int N, int RS, int Cm, int Cp) {
     const int64_t total = (int64_t)N * RS * Cm;
@@ -130,6 +151,16 @@ extern "C" int dml_prep_weight(const float* w_master, void* w, void* wt, int N, 
     else
         hipLaunchKernelGGL(prep_weight_kernel<float>, dim3(grid), dim3(256), 0, st, w_master, (float*)w, (float*)wt,
                            N, RS, Cm, Cp);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_prep_weights(const DmlPrepDesc* descs_device, int count, int dtype, void* stream) {
+    if (!descs_device || count <= 0) return DML_EINVAL;
+    dim3 grid(256, count);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16) hipLaunchKernelGGL(prep_weights_kernel<bf16_t>, grid, dim3(256), 0, st, descs_device);
+    else hipLaunchKernelGGL(prep_weights_kernel<float>, grid, dim3(256), 0, st, descs_device);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -39,12 +39,18 @@ class WgradDesc(C.Structure):
                 ("pad", C.c_int32), ("dtype", C.c_int32), ("splitk", C.c_int32)]
 
 
+class PrepDesc(C.Structure):
+    _fields_ = [("src", c_p), ("w", c_p), ("wt", c_p), ("N", C.c_int32), ("RS", C.c_int32), ("Cm", C.c_int32),
+                ("Cp", C.c_int32)]
+
+
 _PROTOS = {
     "dml_abi_version": (c_i, []),
     "dml_target_arch": (C.c_char_p, []),
     "dml_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_p]),
     "dml_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
     "dml_prep_weight": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_prep_weights": (c_i, [c_p, c_i, c_i, c_p]),
     "dml_unpad_wgrad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dml_bias_grad": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_pack_input": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

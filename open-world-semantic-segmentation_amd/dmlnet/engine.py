@@ -213,6 +213,7 @@ class Plan:
         self.seed_slots = []           # (args_list, index)
         self.prepped_version = None
         self.param_last_op = {}        # param index -> index of the last backward op that adds to its gradient
+        self.prep_table = None
         self.side = {}                 # backward op index -> True if it must first wait for the main stream
         self._side_events = None
         self.drop_units = []
@@ -268,8 +269,8 @@ class Plan:
         w = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device)
         wt = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device) if need_wt else None
         self.keep += [w, wt]
-        self.call(self.prep, self.lib.dml_prep_weight, conv.weight.data_ptr(), w.data_ptr(),
-                  wt.data_ptr() if wt is not None else None, N, kh * kw, Cm, Cp, self.dt)
+        self.prep.append((conv.weight.data_ptr(), w.data_ptr(), wt.data_ptr() if wt is not None else 0, N, kh * kw,
+                          Cm, Cp))
         return w, wt
 
     def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None):
@@ -518,10 +519,14 @@ class Plan:
         key = (st.version, sum(p._version for p in st.params))
         if key == self.prepped_version:
             return
-        for fn, args in self.prep:
-            rc = fn(*args, stream)
-            if rc:
-                _lib.check(rc, fn.__name__)
+        if self.prep_table is None:
+            arr = (_lib.PrepDesc * len(self.prep))()
+            for i, (src, w, wt, N, RS, Cm, Cp) in enumerate(self.prep):
+                arr[i] = _lib.PrepDesc(src, w, wt or None, N, RS, Cm, Cp)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.prep_table = raw.to(self.device)
+        _lib.check(self.lib.dml_prep_weights(self.prep_table.data_ptr(), len(self.prep), self.dt, stream),
+                   "dml_prep_weights")
         self.prepped_version = key
 
     def run_backward(self, hook=None):

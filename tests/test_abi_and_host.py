@@ -36,6 +36,8 @@ def test_struct_layout_matches_header():
     assert ctypes.sizeof(ConvDesc) == 7 * 8 + 19 * 4 + 4      # 7 pointers + 19 int32 (+4 tail padding)
     assert ctypes.sizeof(WgradDesc) == 3 * 8 + 16 * 4
     assert ConvDesc.B.offset == 56 and ConvDesc.pre_relu.offset == 56 + 18 * 4
+    from dmlnet._lib import PrepDesc
+    assert ctypes.sizeof(PrepDesc) == 40
 
 
 def test_module_tree_and_state_dict_contract():
