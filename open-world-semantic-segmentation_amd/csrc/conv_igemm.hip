@@ -177,7 +177,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
 // ------------------------------------------------------------------------------------------------
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
-template <typename T, int BN, bool ALIGNED, int MODE>
+template <typename T, int BN, bool ALIGNED, int MODE, int ABL = 0>   // ABL: tuning ablations (tools/bench_conv.py)
 __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = 128;
     constexpr int VEC = Elem<T>::VEC;
@@ -320,7 +320,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     int cur = 0;
     for (int kt = 0; kt < KT; ++kt) {
         const bool has_next = kt + 1 < KT;
-        if (has_next) {
+        if (has_next && ABL != 1) {
             advance();
             load_tiles(kt + 1, tap_r, tap_s, c0);
         }
@@ -338,11 +338,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
                 const int row = j * 16 + lr;
                 af[j] = *reinterpret_cast<const mfma_bf16x8*>(as + row * BK + swz_chunk<T>(row, lq) * 8);
             }
+            if constexpr (ABL == 2) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(bf[i]));
 #pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
+                for (int j = 0; j < MT; ++j) asm volatile("" ::"v"(af[j]));
+            } else {
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
+            }
         } else {
 #pragma unroll
             for (int kk = 0; kk < BK / 4; ++kk) {
@@ -369,6 +376,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
         cur ^= 1;
     }
 
+    // Cut the accumulators' live ranges here: without it hipcc keeps the MFMA results un-tied through the
+    // branchy epilogue and re-copies all 64 AGPRs (v_accvgpr_mov + s_nop) in EVERY K step (-35 % throughput).
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
     conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
 }
 
@@ -513,6 +526,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
             for (int j = 0; j < MT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
     }
+    // Cut the accumulators' live ranges here: without it hipcc keeps the MFMA results un-tied through the
+    // branchy epilogue and re-copies all 64 AGPRs (v_accvgpr_mov + s_nop) in EVERY K step (-35 % throughput).
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
     conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
 }
 
@@ -775,6 +794,26 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if (d->dtype == DML_BF16)
         return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
     return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
+}
+
+// tuning aid (not part of the ABI header): the bf16 128x128 forward kernel with parts removed
+extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream) {
+    ConvArgs a;
+    a.x = d->x; a.w = d->w; a.y = d->y; a.bias = nullptr; a.stats = d->stats;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
+    a.M = d->B * d->Ho * d->Wo; a.Ktot = d->R * d->S * d->C; a.y_f32 = 0; a.accum = 0;
+    a.nblk_m = (a.M + 127) / 128; a.nblk_n = (a.N + 127) / 128;
+    a.div_wo = make_fastdiv((uint32_t)d->Wo); a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+    a.div_c = make_fastdiv((uint32_t)d->C);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(a.nblk_m * a.nblk_n);
+    if (abl == 0) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 0>), grid, dim3(NTHREADS), 0, st, a);
+    else if (abl == 1) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 1>), grid, dim3(NTHREADS), 0, st, a);
+    else hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 2>), grid, dim3(NTHREADS), 0, st, a);
+    DML_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {

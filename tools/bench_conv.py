@@ -39,6 +39,16 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
                          stride=1, dil=dil, pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
             line += "fwd%s %.1fus %.0fTF | " % ("+st" if use_stats else "", t * 1e6, fl / t / 1e12)
+    if which == "abl":
+        import ctypes
+        lib.dml_debug_conv_ablate.restype = ctypes.c_int
+        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]
+        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, pre_scale=None, pre_shift=None,
+                     B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
+                     y_f32=0, accum=0, mode=0, pre_relu=0)
+        for abl, nm in ((0, "full"), (1, "no-global/no-ldswrite"), (2, "no-mfma")):
+            t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), abl, st))
+            line += "%s %.1fus (%.0fTF-equiv) | " % (nm, t * 1e6, fl / t / 1e12)
     if which in ("all", "wgrad"):
         dw = torch.zeros(N, k, k, Cc, device="cuda")
         for sk in (0, 4, 8, 16, 32, 64):
