@@ -69,12 +69,15 @@ int dml_conv_igemm(const DmlConvDesc* d, void* stream);
 typedef struct DmlWgradDesc {
     const void* x;        /* conv input [B,Hi,Wi,C], pitch ldx                                           */
     const void* dy;       /* output gradient [B,Ho,Wo,N], pitch ldy                                      */
-    float* dw;            /* fp32 weight gradient [N][R][S][C], accumulated with atomics (+=)            */
+    float* dw;            /* fp32 weight gradient [N][R][S][Cm], accumulated (+=): atomics, or via `ws`  */
     int32_t B, Hi, Wi, C, ldx;
     int32_t Ho, Wo, N, ldy;
     int32_t R, S, stride, dil, pad;
     int32_t dtype;
     int32_t splitk;       /* number of slices of the pixel dimension (>=1); 0 = pick automatically      */
+    int32_t Cm;           /* un-padded input channels of dw ([N][R][S][Cm]); 0 = C.  Cm < C needs `ws`        */
+    float* ws;            /* optional workspace: slices store partials [splitk][N][R*S*C] with plain stores  */
+    int64_t ws_elems;     /* and a second kernel folds them into dw (no fp32 atomics); capacity in floats     */
 } DmlWgradDesc;
 
 int dml_conv_wgrad(const DmlWgradDesc* d, void* stream);

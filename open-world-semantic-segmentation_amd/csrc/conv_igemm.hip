@@ -551,6 +551,7 @@ struct WgradArgs {
     int M, Ktot;
     int nblk_n, nblk_k;
     int slab_tiles;   // K tiles (of 32 pixels) per split
+    float* ws;        // optional split-K workspace [splits][N][Ktot]: plain stores instead of atomics
     FastDiv div_wo, div_howo, div_c;
 };
 
@@ -628,8 +629,17 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
             const int row = prow + j * RPP;
-            *reinterpret_cast<uint4*>(Ys(buf) + row * PITCH + vcol * VEC) = y_reg[j];
-            *reinterpret_cast<uint4*>(Xs(buf) + row * PITCH + vcol * VEC) = x_reg[j];
+            int off;
+            if constexpr (sizeof(T) == 2) {
+                // bf16: 16-column sub-tiles [col/16][k'][16] (1056-byte pitch), k rows stored with bits 2/3 swapped:
+                // conflict-free for ds_read_b64_tr_b16 (2 x 32 lanes, 64 banks) and for these 16-byte writes
+                const int prow_ = (row & 0x13) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 3);
+                off = (vcol >> 1) * 528 + prow_ * 16 + (vcol & 1) * 8;
+            } else {
+                off = row * PITCH + vcol * VEC;
+            }
+            *reinterpret_cast<uint4*>(Ys(buf) + off) = y_reg[j];
+            *reinterpret_cast<uint4*>(Xs(buf) + off) = x_reg[j];
         }
     };
 
@@ -650,25 +660,27 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
     for (int t = tile_beg; t < tile_end; ++t) {
         const bool has_next = t + 1 < tile_end;
         if (has_next) load_tiles(t + 1);
-        const T* ys = Ys(cur) + wn * 64;
-        const T* xs = Xs(cur) + wk * 64;
+        const T* ys = Ys(cur) + (sizeof(T) == 2 ? wn * 4 * 528 : wn * 64);
+        const T* xs = Xs(cur) + (sizeof(T) == 2 ? wk * 4 * 528 : wk * 64);
         if constexpr (sizeof(T) == 2) {
             // A[i = n][k = pixel]: lanes of a 16-group address the 4 x 16 block (rows k0..k0+3,
             // cols 16*i..) in 8-byte pieces: lane L -> row L/4, cols 4*(L%4)..; the hardware
             // returns to lane i the 4 k-values of column i.
             mfma_bf16x8 af[NT], bfr[MT];
-            const int trow = lr >> 2, tcol = (lr & 3) * 4;
+            // k rows 8*lq + (lr>>2) (+4 for the second read) at their swapped positions inside a sub-tile
+            const int p_lo = ((lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4)) * 16 + (lr & 3) * 4;
+            const int p_hi = p_lo + 8 * 16;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
-                const bf16x4 lo = lds_tr16_b64(ys + (lq * 8 + trow) * PITCH + i * 16 + tcol);
-                const bf16x4 hi = lds_tr16_b64(ys + (lq * 8 + 4 + trow) * PITCH + i * 16 + tcol);
+                const bf16x4 lo = lds_tr16_b64(ys + i * 528 + p_lo);
+                const bf16x4 hi = lds_tr16_b64(ys + i * 528 + p_hi);
                 bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 af[i] = __builtin_bit_cast(mfma_bf16x8, v);
             }
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
-                const bf16x4 lo = lds_tr16_b64(xs + (lq * 8 + trow) * PITCH + j * 16 + tcol);
-                const bf16x4 hi = lds_tr16_b64(xs + (lq * 8 + 4 + trow) * PITCH + j * 16 + tcol);
+                const bf16x4 lo = lds_tr16_b64(xs + j * 528 + p_lo);
+                const bf16x4 hi = lds_tr16_b64(xs + j * 528 + p_hi);
                 bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
                 bfr[j] = __builtin_bit_cast(mfma_bf16x8, v);
             }
@@ -707,9 +719,32 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 const int k = kc0 + wk * 64 + j * 16 + lr;
-                if (k < a.Ktot) atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q]);
+                if (k < a.Ktot) {
+                    if (a.ws != nullptr)
+                        a.ws[((int64_t)blockIdx.y * a.N + n) * a.Ktot + k] = acc[i][j][q];
+                    else
+                        atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q]);
+                }
             }
         }
+}
+
+// dw[n][rs][c < Cm] += sum_s ws[s][n][rs][c]   (fp32 atomics on the L2 are ~10x more expensive per byte than this)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
+                                                           int splits, int64_t NRS, int Cm, int Cp) {
+    const int64_t total = NRS * Cm;
+    const int64_t plane = NRS * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+         i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t src = i;
+        if (Cm != Cp) {
+            const int64_t t = i / Cm;
+            src = t * Cp + (i - t * Cm);
+        }
+        float acc = 0.f;
+        for (int sidx = 0; sidx < splits; ++sidx) acc += ws[sidx * plane + src];
+        dw[i] += acc;
+    }
 }
 
 template <typename T, int MODE>
@@ -835,15 +870,29 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
     const int tiles = (a.M + BK - 1) / BK;
+    const int cm = d->Cm > 0 ? d->Cm : d->C;
+    if (cm > d->C) return DML_EINVAL;
+    if (cm != d->C && !d->ws) return DML_EINVAL;      // dropping padded channels needs the workspace path
+    const int64_t plane = (int64_t)a.N * a.Ktot;
+    // small weight tensors: the reduce pass would be latency-bound and atomic contention is low -> atomics
+    const bool use_ws = d->ws != nullptr && (plane >= 65536 || cm != d->C);
     int splitk = d->splitk;
     if (splitk <= 0) {
-        // aim for >= 4 workgroups per CU, but keep >= 8 K tiles (256 pixels) per slice
         const int base = a.nblk_n * a.nblk_k;
-        splitk = (1024 + base - 1) / base;
+        if (use_ws) {
+            // measured (tools/bench_conv.py): >= 512 workgroups and ~48 K tiles per workgroup
+            splitk = (512 + base - 1) / base;
+            if (tiles / 48 > splitk) splitk = tiles / 48;
+        } else {
+            splitk = (1024 + base - 1) / base;
+        }
         const int cap = (tiles + 7) / 8;
         if (splitk > cap) splitk = cap;
         if (splitk < 1) splitk = 1;
     }
+    if (use_ws && (int64_t)splitk * plane > d->ws_elems) splitk = (int)(d->ws_elems / plane);
+    if (use_ws && splitk < 1) return DML_EINVAL;
+    a.ws = use_ws ? d->ws : nullptr;
     if (splitk > tiles) splitk = tiles > 0 ? tiles : 1;
     a.slab_tiles = (tiles + splitk - 1) / splitk;
     splitk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
@@ -853,6 +902,11 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);
     else
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
+    if (use_ws) {
+        const int64_t nrs = (int64_t)a.N * a.R * a.S;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256)), dim3(256), 0, st, d->ws, d->dw, splitk,
+                           nrs, cm, d->C);
+    }
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -36,7 +36,8 @@ class WgradDesc(C.Structure):
                 ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32),
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
-                ("pad", C.c_int32), ("dtype", C.c_int32), ("splitk", C.c_int32)]
+                ("pad", C.c_int32), ("dtype", C.c_int32), ("splitk", C.c_int32), ("Cm", C.c_int32),
+                ("ws", c_p), ("ws_elems", C.c_int64)]
 
 
 class PrepDesc(C.Structure):

@@ -222,6 +222,8 @@ class Plan:
         self.scratch = torch.empty(max(B * H * W // 2 + 16384, 1100 * 2048 * 2 + 65536), dtype=torch.float32,
                                    device=self.device)
         self.sp = self.scratch.data_ptr()
+        # split-K partials of the weight gradients (one launch at a time uses it: all of them run on one stream)
+        self.wgrad_ws = torch.empty(40 * (1 << 20) if training else 1, dtype=torch.float32, device=self.device)
         self.build()
         self.bytes = sum(t.numel() * t.element_size() for t in self.keep if isinstance(t, torch.Tensor))
 
@@ -301,16 +303,11 @@ class Plan:
         gptr = self.e.store.grad_ptr_of(conv.weight)
         tmp = None
         first = len(self.bwd)
-        if Cp != Cm:
-            tmp = self.fbuf(conv.out_channels * kh * kw * Cp)
-            self.call(self.bwd, self.lib.dml_fill_f32, tmp.data_ptr(), tmp.numel(), 0.0)
-        dsc = WgradDesc(x=x.ptr, dy=dy.ptr, dw=tmp.data_ptr() if tmp is not None else gptr, B=x.B, Hi=x.H,
-                        Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo, N=conv.out_channels, ldy=dy.ld, R=kh, S=kw,
-                        stride=s, dil=d, pad=p, dtype=self.dt, splitk=0)
+        dsc = WgradDesc(x=x.ptr, dy=dy.ptr, dw=gptr, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
+                        N=conv.out_channels, ldy=dy.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, splitk=0,
+                        Cm=Cm, ws=self.wgrad_ws.data_ptr(), ws_elems=self.wgrad_ws.numel())
         self.keep.append(dsc)
         self.call(self.bwd, self.lib.dml_conv_wgrad, C.byref(dsc))
-        if tmp is not None:
-            self.call(self.bwd, self.lib.dml_unpad_wgrad, tmp.data_ptr(), gptr, conv.out_channels, kh * kw, Cm, Cp)
         # weight gradients only feed the optimizer: they run on a side stream, next to the HBM-bound BN backward
         # and the data gradient of the following layers (Plan.run_backward)
         for i in range(first, len(self.bwd)):

@@ -149,6 +149,21 @@ def test_conv_fwd_dgrad_wgrad(lib, case, dname):
     chk(lib.dml_conv_wgrad(C.byref(wg), st()))
     torch.cuda.synchronize()
     relclose(dw.cpu().permute(0, 3, 1, 2), w.grad, tol if dname == "f32" else 2e-3, "conv wgrad splitk " + name)
+    # workspace path: partial tiles with plain stores + reduce kernel (no atomics); also drops padded channels
+    ws = torch.empty(6 * dw.numel(), device="cuda")
+    for sk in (0, 4):
+        wg.splitk, wg.ws, wg.ws_elems = sk, ws.data_ptr(), ws.numel()
+        dw.fill_(1.0)
+        chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+        torch.cuda.synchronize()
+        relclose(dw.cpu().permute(0, 3, 1, 2) - 1.0, w.grad, tol if dname == "f32" else 2e-3, "conv wgrad ws " + name)
+    if Cin >= 8:
+        cm = Cin - 5
+        dwc = torch.zeros((Cout, k, k, cm), device="cuda")
+        wg.splitk, wg.Cm, wg.dw = 0, cm, dwc.data_ptr()
+        chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+        torch.cuda.synchronize()
+        relclose(dwc.cpu().permute(0, 3, 1, 2), w.grad[:, :cm], tol if dname == "f32" else 2e-3, "conv wgrad Cm " + name)
 
 
 def test_conv_bias_f32_out_and_slices(lib):

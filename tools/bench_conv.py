@@ -56,4 +56,11 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
                            ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1, splitk=sk)
             t = timeit(lambda: lib.dml_conv_wgrad(C.byref(wg), st))
             line += "wg sk%d %.1fus %.0fTF | " % (sk, t * 1e6, fl / t / 1e12)
+        ws = torch.empty(40 << 20, device="cuda")
+        for sk in (0, 8, 16, 32, 64):
+            wg = WgradDesc(x=x.data_ptr(), dy=dy.data_ptr(), dw=dw.data_ptr(), B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N,
+                           ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1, splitk=sk, Cm=0, ws=ws.data_ptr(),
+                           ws_elems=ws.numel())
+            t = timeit(lambda: lib.dml_conv_wgrad(C.byref(wg), st))
+            line += "WS sk%d %.1fus %.0fTF | " % (sk, t * 1e6, fl / t / 1e12)
     print(line)
