@@ -730,10 +730,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
 }
 
 // dw[n][rs][c < Cm] += sum_s ws[s][n][rs][c]   (fp32 atomics on the L2 are ~10x more expensive per byte than this)
+// blockIdx.y walks chunks of 16 splits so that a small weight tensor with hundreds of splits stays parallel.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
                                                            int splits, int64_t NRS, int Cm, int Cp) {
     const int64_t total = NRS * Cm;
     const int64_t plane = NRS * Cp;
+    const int s0 = blockIdx.y * 16, s1 = min(splits, s0 + 16);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         int64_t src = i;
@@ -742,8 +744,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             src = t * Cp + (i - t * Cm);
         }
         float acc = 0.f;
-        for (int sidx = 0; sidx < splits; ++sidx) acc += ws[sidx * plane + src];
-        dw[i] += acc;
+        for (int sidx = s0; sidx < s1; ++sidx) acc += ws[sidx * plane + src];
+        if (gridDim.y == 1) dw[i] += acc;
+        else atomicAdd(dw + i, acc);
     }
 }
 
@@ -904,8 +907,8 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
     if (use_ws) {
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256)), dim3(256), 0, st, d->ws, d->dw, splitk,
-                           nrs, cm, d->C);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), (splitk + 15) / 16), dim3(256), 0, st,
+                           d->ws, d->dw, splitk, nrs, cm, d->C);
     }
     DML_LAUNCH_CHECK();
     return 0;
