@@ -56,7 +56,7 @@ template <> __device__ __forceinline__ int swz_chunk<float>(int row, int chunk) 
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NT, int MT>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int mw0, const int nw0,
-                                              const int lr, const int lq) {
+                                              const int lr, const int lq, const bool do_store = true) {
     constexpr int TM = MT * 16;
 
     if (a.stats != nullptr) {
@@ -108,6 +108,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
         }
     }
 
+    if (!do_store) return;
     const bool vec_ok = ((a.N & 3) == 0) && ((a.ldy & 3) == 0);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
@@ -170,6 +171,105 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         if (n + q < a.N) yp[q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[q]) + v[q] : v[q]);
                 }
             }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Output through LDS: the MFMA layout gives every lane 4 channels of one pixel (8-byte stores scattered over 16
+// rows per instruction, which is what bounds the small-K 1x1 convolutions).  Staging the tile in LDS turns
+// them into 16-byte-per-lane stores (and accumulate loads) of whole rows.  Two 64-row halves reuse the
+// operand ring, which is free after the K loop.
+// ------------------------------------------------------------------------------------------------
+template <typename OT> __device__ __forceinline__ uint4 add_vec16(uint4 a, uint4 b);
+template <> __device__ __forceinline__ uint4 add_vec16<float>(uint4 a, uint4 b) {
+    return make_uint4(__float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x)),
+                      __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y)),
+                      __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z)),
+                      __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w)));
+}
+template <> __device__ __forceinline__ uint4 add_vec16<bf16_t>(uint4 a, uint4 b) {
+    const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
+    uint32_t r[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const float lo = __uint_as_float(x[i] << 16) + __uint_as_float(y[i] << 16);
+        const float hi = __uint_as_float(x[i] & 0xffff0000u) + __uint_as_float(y[i] & 0xffff0000u);
+        r[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
+    }
+    return make_uint4(r[0], r[1], r[2], r[3]);
+}
+
+template <typename OT, int BN, int NT, int MT>
+__device__ __forceinline__ void conv_store_staged(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int m0, const int n0,
+                                                  const int wm, const int wn, const int lr, const int lq,
+                                                  void* smem_raw) {
+    constexpr int TN = NT * 16;
+    constexpr int OV = 16 / (int)sizeof(OT);      // elements per 16-byte vector
+    constexpr int PO = BN + OV;                    // LDS pitch: +16 B keeps rows 16-byte aligned, spreads banks
+    constexpr int CPR = BN / OV;                   // 16-byte chunks per row
+    constexpr int RPP = NTHREADS / CPR;            // rows per pass
+    OT* sm = reinterpret_cast<OT*>(smem_raw);
+    const int tid = threadIdx.x;
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        if (wm == h) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+#pragma unroll
+                for (int i = 0; i < NT; ++i) {
+                    const int n = n0 + wn * TN + i * 16 + lq * 4;
+                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                    if (a.bias != nullptr) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < a.N) v[q] += a.bias[n + q];
+                    }
+                    OT* dst = sm + (j * 16 + lr) * PO + wn * TN + i * 16 + lq * 4;
+                    if constexpr (sizeof(OT) == 4) {
+                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
+                    } else {
+                        uint2 pk;
+                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
+                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
+                        *reinterpret_cast<uint2*>(dst) = pk;
+                    }
+                }
+        }
+        __syncthreads();
+        const int ch = tid % CPR;
+        const int n = n0 + ch * OV;
+        for (int r = tid / CPR; r < 64; r += RPP) {
+            const int m = m0 + h * 64 + r;
+            if (m < a.M && n < a.N) {
+                uint4 v = *reinterpret_cast<const uint4*>(sm + r * PO + ch * OV);
+                OT* yp = static_cast<OT*>(a.y) + (int64_t)m * a.ldy + n;
+                if (a.accum) v = add_vec16<OT>(v, *reinterpret_cast<const uint4*>(yp));
+                *reinterpret_cast<uint4*>(yp) = v;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// stats + store; picks the staged path when rows are 16-byte addressable
+template <typename T, int BN, int NT, int MT, int SMEM_BYTES>
+__device__ __forceinline__ void conv_finish(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int m0, const int n0,
+                                            const int wm, const int wn, const int lr, const int lq, void* smem_raw) {
+    constexpr int TM = MT * 16, TN = NT * 16;
+    const bool out_f32 = a.y_f32 || sizeof(T) == 4;
+    const int ov = out_f32 ? 4 : 8;
+    const bool rows_ok = (a.N % ov) == 0 && (a.ldy % ov) == 0 && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
+    constexpr bool fits_f32 = 64 * (BN + 4) * 4 <= SMEM_BYTES;
+    constexpr bool fits_b16 = 64 * (BN + 8) * 2 <= SMEM_BYTES;
+    const bool staged = rows_ok && (out_f32 ? fits_f32 : fits_b16);
+    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq, !staged);
+    if (staged) {
+        if (out_f32) {
+            if constexpr (fits_f32) conv_store_staged<float, BN, NT, MT>(acc, a, m0, n0, wm, wn, lr, lq, smem_raw);
+        } else {
+            if constexpr (fits_b16 && sizeof(T) == 2)
+                conv_store_staged<bf16_t, BN, NT, MT>(acc, a, m0, n0, wm, wn, lr, lq, smem_raw);
         }
     }
 }
@@ -382,7 +482,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
-    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+    conv_finish<T, BN, NT, MT, (int)sizeof(T) * 2 * (BM + BN) * BK>(acc, a, m0, n0, wm, wn, lr, lq, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -532,7 +632,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
-    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+    __syncthreads();      // every wave is done reading the ring before it is reused for the output tile
+    conv_finish<T, BN, NT, MT, (int)sizeof(T) * NST * STAGE>(acc, a, m0, n0, wm, wn, lr, lq, smem);
 }
 
 // ------------------------------------------------------------------------------------------------
