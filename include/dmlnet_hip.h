@@ -121,13 +121,15 @@ int dml_bn_eval_coeffs(const float* gamma, const float* beta, const float* runni
                        const float* running_var, float eps, float* scale, float* shift, int N,
                        void* stream);
 /* z = act((y - mean)*scale + shift [+ res]) with optional inverted dropout (network/utils.py:354).
- * y, res, z have independent pitches. */
+ * y, res, z have independent pitches.  `mask` (optional, DML_BF16 only): one bit per element, z > 0, packed as
+ * mask[m*(N/8) + c/8] bit c%8 -- the backward passes then read 1 byte instead of 16 bytes of z. */
 int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                 const float* mean, int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype,
-                 float drop_p, uint64_t drop_seed, void* stream);
-/* backward, pass 1: per-channel sums of g = dz*[z>0]*gscale and g*xhat -> partials[blocks][N][2].
+                 const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
+                 int dtype, float drop_p, uint64_t drop_seed, void* stream);
+/* backward, pass 1: per-channel sums of g = dz*[z>0]*gscale and g*xhat -> partials[blocks][N][2]
+ * ([z>0] from `mask` when given, else from z).
  * returns the number of partial rows through *nblocks (host int). */
-int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* save_mean,
+int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* save_mean,
                       const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
                       int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream);
 /* backward, pass 1b: fold partials, write dgamma/dbeta (+=) and the per-channel coefficients
@@ -136,7 +138,7 @@ int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, co
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                         float* coef, void* stream);
 /* backward, pass 2: dy = coef0*g + coef1*(y - coef3) + coef2; optionally dres (+)= g for the identity branch. */
-int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* coef, void* dy,
+int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* coef, void* dy,
                      void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
                      int relu, float gscale, int dres_accum, int dtype, void* stream);
 

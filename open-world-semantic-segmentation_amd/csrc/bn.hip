@@ -115,8 +115,8 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(
     const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ mean, int64_t M, int N, int ldy, int ldres,
-    int ldz, int relu, float drop_p, uint64_t drop_seed, FastDiv div_nv) {
+    const float* __restrict__ shift, const float* __restrict__ mean, uint8_t* __restrict__ mask, int64_t M, int N,
+    int ldy, int ldres, int ldz, int relu, float drop_p, uint64_t drop_seed, FastDiv div_nv) {
     constexpr int V = Vec16<T>::N;
     const int NV = N / V;
     const int64_t total = M * NV;
@@ -156,6 +156,13 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
                 v[q] = drop_keep(drop_seed, (uint64_t)m * N + c + q, thresh) ? v[q] * keep_scale : 0.f;
         }
         Vec16<T>::store(z + (int64_t)m * ldz + c, v);
+        if (V == 8 && mask != nullptr) {
+            // one bit per element (z > 0): the backward passes read this byte instead of 16 bytes of z
+            uint32_t bits = 0;
+#pragma unroll
+            for (int q = 0; q < V; ++q) bits |= (v[q] > 0.f ? 1u : 0u) << q;
+            mask[i] = (uint8_t)bits;
+        }
     }
 }
 
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
 constexpr int RED_COLS = 64;   // vector columns per block
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
-    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z,
+    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const uint8_t* __restrict__ mask,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* __restrict__ partials,
     int64_t M, int N, int lddz, int ldy, int ldz, int relu, float gscale, int rows_per_block, int chv, int rt) {
     constexpr int V = Vec16<T>::N;
@@ -188,10 +195,16 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
             Vec16<T>::load(dz + m * lddz + c, g);
             Vec16<T>::load(y + m * ldy + c, yy);
             if (relu) {
-                float zz[V];
-                Vec16<T>::load(z + m * ldz + c, zz);
+                if (V == 8 && mask != nullptr) {
+                    const uint32_t bits = mask[m * NV + v];
 #pragma unroll
-                for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
+                    for (int q = 0; q < V; ++q) g[q] = (bits >> q) & 1u ? g[q] : 0.f;
+                } else {
+                    float zz[V];
+                    Vec16<T>::load(z + m * ldz + c, zz);
+#pragma unroll
+                    for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
+                }
             }
 #pragma unroll
             for (int q = 0; q < V; ++q) {
@@ -256,9 +269,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
 
 template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const float* __restrict__ coef,
-    T* __restrict__ dy, T* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres, int relu,
-    float gscale, int dres_accum, FastDiv div_nv) {
+    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const uint8_t* __restrict__ mask,
+    const float* __restrict__ coef, T* __restrict__ dy, T* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy,
+    int lddres, int relu, float gscale, int dres_accum, FastDiv div_nv) {
     constexpr int V = Vec16<T>::N;
     const int NV = N / V;
     const int64_t total = M * NV;
@@ -270,10 +283,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
         Vec16<T>::load(dz + (int64_t)m * lddz + c, g);
         Vec16<T>::load(y + (int64_t)m * ldy + c, yy);
         if (relu) {
-            float zz[V];
-            Vec16<T>::load(z + (int64_t)m * ldz + c, zz);
+            if (V == 8 && mask != nullptr) {
+                const uint32_t bits = mask[i];
 #pragma unroll
-            for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
+                for (int q = 0; q < V; ++q) g[q] = (bits >> q) & 1u ? g[q] : 0.f;
+            } else {
+                float zz[V];
+                Vec16<T>::load(z + (int64_t)m * ldz + c, zz);
+#pragma unroll
+                for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
+            }
         }
 #pragma unroll
         for (int q = 0; q < V; ++q) {
@@ -332,8 +351,8 @@ extern "C" int dml_bn_eval_coeffs(const float* gamma, const float* beta, const f
 }
 
 extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
-                            const float* mean, int64_t M, int N, int ldy, int ldres, int ldz, int relu, int dtype,
-                            float drop_p, uint64_t drop_seed, void* stream) {
+                            const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
+                            int dtype, float drop_p, uint64_t drop_seed, void* stream) {
     if (!y || !z || !scale || !shift || !mean || M <= 0 || N <= 0) return DML_EINVAL;
     if (!vec_ok(dtype, N) || !vec_ok(dtype, ldy) || !vec_ok(dtype, ldz) || (res && !vec_ok(dtype, ldres)))
         return DML_EALIGN;
@@ -344,22 +363,23 @@ extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y,
-                           (const bf16_t*)res, (bf16_t*)z, scale, shift, mean, M, N, ldy, ldres, ldz, relu, drop_p,
+                           (const bf16_t*)res, (bf16_t*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p,
                            drop_seed, dv);
     else
         hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y,
-                           (const float*)res, (float*)z, scale, shift, mean, M, N, ldy, ldres, ldz, relu, drop_p,
+                           (const float*)res, (float*)z, scale, shift, mean, nullptr, M, N, ldy, ldres, ldz, relu, drop_p,
                            drop_seed, dv);
     DML_LAUNCH_CHECK();
     return 0;
 }
 
-extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const float* save_mean,
+extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* save_mean,
                                  const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
                                  int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream) {
     if (!dz || !y || !save_mean || !save_invstd || !partials || !nblocks || M <= 0 || N <= 0) return DML_EINVAL;
-    if (relu && !z) return DML_EINVAL;
-    if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || (relu && !vec_ok(dtype, ldz)))
+    if (dtype != DML_BF16) mask = nullptr;
+    if (relu && !z && !mask) return DML_EINVAL;
+    if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || (relu && !mask && !vec_ok(dtype, ldz)))
         return DML_EALIGN;
     const int V = dtype == DML_BF16 ? 8 : 4;
     const int NV = N / V;
@@ -375,11 +395,11 @@ extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz,
-                           (const bf16_t*)y, (const bf16_t*)z, save_mean, save_invstd, partials, M, N, lddz, ldy,
+                           (const bf16_t*)y, (const bf16_t*)z, mask, save_mean, save_invstd, partials, M, N, lddz, ldy,
                            ldz, relu, gscale, (int)rpb, chv, rt);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz,
-                           (const float*)y, (const float*)z, save_mean, save_invstd, partials, M, N, lddz, ldy,
+                           (const float*)y, (const float*)z, nullptr, save_mean, save_invstd, partials, M, N, lddz, ldy,
                            ldz, relu, gscale, (int)rpb, chv, rt);
     DML_LAUNCH_CHECK();
     return 0;
@@ -396,13 +416,14 @@ extern "C" int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M
     return 0;
 }
 
-extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const float* coef, void* dy,
+extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* coef, void* dy,
                                 void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
                                 int relu, float gscale, int dres_accum, int dtype, void* stream) {
     if (!dz || !y || !coef || !dy || M <= 0 || N <= 0) return DML_EINVAL;
-    if (relu && !z) return DML_EINVAL;
+    if (dtype != DML_BF16) mask = nullptr;
+    if (relu && !z && !mask) return DML_EINVAL;
     if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || !vec_ok(dtype, lddy) ||
-        (relu && !vec_ok(dtype, ldz)) || (dres && !vec_ok(dtype, lddres)))
+        (relu && !mask && !vec_ok(dtype, ldz)) || (dres && !vec_ok(dtype, lddres)))
         return DML_EALIGN;
     if (M >= (1ll << 31)) return DML_EINVAL;
     const int V = dtype == DML_BF16 ? 8 : 4;
@@ -411,11 +432,11 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz,
-                           (const bf16_t*)y, (const bf16_t*)z, coef, (bf16_t*)dy, (bf16_t*)dres, M, N, lddz, ldy,
+                           (const bf16_t*)y, (const bf16_t*)z, mask, coef, (bf16_t*)dy, (bf16_t*)dres, M, N, lddz, ldy,
                            ldz, lddy, lddres, relu, gscale, dres_accum, dv);
     else
         hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz,
-                           (const float*)y, (const float*)z, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
+                           (const float*)y, (const float*)z, nullptr, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
                            lddy, lddres, relu, gscale, dres_accum, dv);
     DML_LAUNCH_CHECK();
     return 0;

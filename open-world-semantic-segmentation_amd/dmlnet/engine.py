@@ -191,7 +191,7 @@ class Act:
 
 class ConvUnit:
     __slots__ = ("conv", "bn", "x", "y", "z", "relu", "res", "w", "wt", "scale", "shift", "mean", "invstd",
-                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy")
+                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy", "mask")
 
 
 class Plan:
@@ -348,8 +348,14 @@ class Plan:
             self.call(self.fwd, lib.dml_bn_eval_coeffs, g_ptr, b_ptr, bn.running_mean.data_ptr(),
                       bn.running_var.data_ptr(), float(bn.eps), u.scale.data_ptr(), u.shift.data_ptr(), N)
         u.gscale_slots = []
+        # ReLU bitmask (bf16 training): the two BN backward passes read 1 byte per 8 elements instead of z
+        u.mask = None
+        if self.training and relu and self.dtype == torch.bfloat16:
+            u.mask = torch.empty(M * (N // 8), dtype=torch.uint8, device=self.device)
+            self.keep.append(u.mask)
+        mask_ptr = u.mask.data_ptr() if u.mask is not None else None
         u.apply_args = self.call(self.fwd, lib.dml_bn_apply, u.y.ptr, res.ptr if res is not None else None,
-                                 u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), mean_ptr, M, N, u.y.ld,
+                                 u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), mean_ptr, mask_ptr, M, N, u.y.ld,
                                  res.ld if res is not None else 0, u.z.ld, 1 if relu else 0, self.dt, 0.0, 0)
         if drop is not None and self.training:
             self.drop_units.append(u)
@@ -366,7 +372,8 @@ class Plan:
         coef = self.fbuf(4 * N)
         nblk = C.c_int(0)
         self.keep.append(nblk)
-        a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, u.mean.data_ptr(),
+        mk = u.mask.data_ptr() if u.mask is not None else None
+        a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, mk, u.mean.data_ptr(),
                        u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if u.relu else 0, 1.0,
                        self.dt, C.byref(nblk))
         self.call(self.bwd, lib.dml_bn_bwd_finalize, self.sp, nblk, M, N, bn.weight.data_ptr(),
@@ -374,11 +381,11 @@ class Plan:
                   st.grad_ptr_of(bn.bias), coef.data_ptr())
         self.mark_grad(bn.weight)
         self.mark_grad(bn.bias)
-        a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, coef.data_ptr(), dy.ptr,
+        a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, mk, coef.data_ptr(), dy.ptr,
                        dres.ptr if dres is not None else None, M, N, dz.ld, u.y.ld, u.z.ld, dy.ld,
                        dres.ld if dres is not None else 0, 1 if u.relu else 0, 1.0,
                        1 if dres_accum else 0, self.dt)
-        u.gscale_slots += [(a1, 12), (a3, 14)]
+        u.gscale_slots += [(a1, 13), (a3, 15)]
         self.conv_wgrad(u.x, dy, u.conv, u.Cp)
         if need_dgrad:
             self.conv_dgrad(dy, u.conv, u.wt, u.x)
@@ -637,8 +644,8 @@ class Engine:
             self.step_count += 1
             for u in plan.drop_units:
                 p = float(u.drop.p) if u.drop.training else 0.0      # F14: dropout module in eval() => off
-                u.apply_args[13] = p
-                u.apply_args[14] = (self.seed + 0x9E3779B97F4A7C15 * self.step_count) & 0xFFFFFFFFFFFFFFFF
+                u.apply_args[14] = p
+                u.apply_args[15] = (self.seed + 0x9E3779B97F4A7C15 * self.step_count) & 0xFFFFFFFFFFFFFFFF
                 for (a, i) in u.gscale_slots:
                     a[i] = 1.0 / (1.0 - p) if p > 0 else 1.0
             self.store.flat_nbt.add_(1)

@@ -253,8 +253,10 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     rm, rv, g_d, b_d = rm0.cuda(), rv0.cuda(), gamma.detach().cuda(), beta.detach().cuda()
     chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, g_d.data_ptr(), b_d.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                             0.01, 1e-5, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
+    bitmask = torch.zeros(M * Cc // 8, device="cuda", dtype=torch.uint8) if dname == "bf16" else None
+    mk = bitmask.data_ptr() if bitmask is not None else None
     chk(lib.dml_bn_apply(yd.data_ptr(), rd.data_ptr() if res else None, zd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                         mu.data_ptr(), M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, st()))
+                         mu.data_ptr(), mk, M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, st()))
     torch.cuda.synchronize()
     relclose(rm.cpu(), rm_ref, 1e-4, "running_mean")
     relclose(rv.cpu(), rv_ref, 1e-4, "running_var")
@@ -275,7 +277,8 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     (o * (gz * (mask * gs if mask is not None else 1))).sum().backward()
     gzd = nhwc(gz, tdt)
     nblk = C.c_int(0)
-    chk(lib.dml_bn_bwd_reduce(gzd.data_ptr(), yd.data_ptr(), zd.data_ptr(), mu.data_ptr(), inv.data_ptr(),
+    zarg = None if mk else zd.data_ptr()          # with the bitmask the backward never touches z
+    chk(lib.dml_bn_bwd_reduce(gzd.data_ptr(), yd.data_ptr(), zarg, mk, mu.data_ptr(), inv.data_ptr(),
                               part.data_ptr(), M, Cc, Cc, Cc, Cc, 1 if (relu or drop > 0) else 0, gs, dt,
                               C.byref(nblk), st()))
     coef = torch.empty(4 * Cc, device="cuda")
@@ -284,7 +287,7 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
                                 dg.data_ptr(), db.data_ptr(), coef.data_ptr(), st()))
     dyd = torch.empty_like(yd)
     dres = torch.empty_like(yd) if res else None
-    chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zd.data_ptr(), coef.data_ptr(), dyd.data_ptr(),
+    chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zarg, mk, coef.data_ptr(), dyd.data_ptr(),
                              dres.data_ptr() if res else None, M, Cc, Cc, Cc, Cc, Cc, Cc,
                              1 if (relu or drop > 0) else 0, gs, 0, dt, st()))
     torch.cuda.synchronize()
@@ -507,6 +510,6 @@ def test_rejects_bad_arguments(lib):
     d = ConvDesc()
     assert lib.dml_conv_igemm(C.byref(d), None) == -1
     x = torch.zeros(64, device="cuda")
-    assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), 4, 6, 6, 6, 6,
-                            1, 0, 0.0, 0, st()) == -2
+    assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 6, 6, 6,
+                            6, 1, 0, 0.0, 0, st()) == -2
     assert lib.dml_proto_dist_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 64, 16, 1, 1, st()) == -3

@@ -37,7 +37,7 @@ consumers = Counter(id(u.x.root) for u in plan.units)
 for u in plan.units:
     n = names[id(u.conv)]
     dz, y, z, dy = act(u.dz), act(u.y), act(u.z), act(u.dy)
-    g = dz * (z > 0) if u.relu else dz
+    g = dz * (z > 0) if u.relu else dz          # (the kernels read the same predicate from the bitmask in bf16)
     mu, inv = u.mean.double().cpu(), u.invstd.double().cpu()
     xhat = (y - mu) * inv
     gam = u.bn.weight.detach().double().cpu()
