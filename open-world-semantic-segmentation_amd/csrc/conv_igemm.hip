@@ -703,6 +703,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
     const int tiles_total = (a.M + BK - 1) / BK;
     const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
 
+    const bool lin1x1 = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
     uint4 y_reg[LD], x_reg[LD];
     auto load_tiles = [&](int t) {
 #pragma unroll
@@ -711,7 +712,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
             uint4 yv = make_uint4(0, 0, 0, 0), xv = make_uint4(0, 0, 0, 0);
             if (m < a.M) {
                 if (yn_ok) yv = *reinterpret_cast<const uint4*>(DY + (int64_t)m * a.ldy + yn);
-                if (kc_ok) {
+                if (kc_ok && lin1x1) {
+                    xv = *reinterpret_cast<const uint4*>(X + (int64_t)m * a.ldx + xc);      // 1x1 stride 1: source pixel = m
+                } else if (kc_ok) {
                     const uint32_t b = fdiv((uint32_t)m, a.div_howo);
                     const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
                     const uint32_t yo = fdiv(rem, a.div_wo);
