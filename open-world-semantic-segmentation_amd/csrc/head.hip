@@ -118,6 +118,92 @@ __global__ __launch_bounds__(256) void proto_dist_fwd_kernel(const float* __rest
     }
 }
 
+// ---- standalone head, K = C = 16 fast path (the reference's configuration).  Per lane: 4 consecutive pixels,
+// 16-byte loads of the 16 channel planes, 16-byte stores of the 16 logit planes; the NHWC copy of the features is
+// transposed through a per-wave 16 KB LDS image (XOR-swizzled 16-byte chunks) so that every store instruction
+// writes 1 KB of consecutive addresses instead of 64 scattered 16-byte pieces.  Prototypes are read with a
+// wave-uniform index (scalar loads), no LDS, no block barrier.
+__global__ __launch_bounds__(256) void proto_dist_fwd_c16_kernel(const float* __restrict__ x,
+                                                                 const float* __restrict__ protos,
+                                                                 float* __restrict__ logits,
+                                                                 float* __restrict__ feats,
+                                                                 uint8_t* __restrict__ argmax,
+                                                                 float* __restrict__ dissum, int B, int64_t HW) {
+    constexpr int C = 16, K = 16;
+    __shared__ __attribute__((aligned(16))) float4 stage[4][1024];      // per wave: 256 px x 64 B
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t groups_per_img = HW / 4;
+    const int64_t total = (int64_t)B * groups_per_img;
+    const int64_t wave_first = ((int64_t)blockIdx.x * 4 + wave) * 64;    // first pixel group of this wave
+    const int64_t i = wave_first + lane;
+    const bool active = i < total;
+    const int64_t ic = active ? i : total - 1;
+    const int64_t b = ic / groups_per_img;
+    const int64_t pix = (ic - b * groups_per_img) * 4;
+    float f[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c) {
+        const float4 t = *reinterpret_cast<const float4*>(x + (b * C + c) * HW + pix);
+        f[c][0] = t.x; f[c][1] = t.y; f[c][2] = t.z; f[c][3] = t.w;
+    }
+    if (feats != nullptr) {
+        float4* st = stage[wave];
+#pragma unroll
+        for (int p = 0; p < 4; ++p)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int chunk = p * 4 + c4;                             // 16-byte chunk inside the lane's 256 B
+                st[lane * 16 + (chunk ^ (lane & 15))] =
+                    make_float4(f[c4 * 4][p], f[c4 * 4 + 1][p], f[c4 * 4 + 2][p], f[c4 * 4 + 3][p]);
+            }
+        __builtin_amdgcn_wave_barrier();
+        // a wave's 256 pixels are contiguous in NHWC only if they belong to one image: handle per 16-byte chunk
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+            const int q = j * 64 + lane;                                  // chunk index in the wave's 16 KB image
+            const int r = q >> 4;                                         // source lane (row of 256 B)
+            const float4 v = st[r * 16 + ((q & 15) ^ (r & 15))];
+            const int64_t grp = wave_first + r;                           // pixel group that row came from
+            if (grp < total) {
+                const int64_t gb = grp / groups_per_img;
+                const int64_t gpix = (grp - gb * groups_per_img) * 4;
+                float* dst = feats + (gb * HW + gpix) * C + (q & 15) * 4;
+                *reinterpret_cast<float4*>(dst) = v;
+            }
+        }
+    }
+    float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sum[4] = {0.f, 0.f, 0.f, 0.f};
+    int bi[4] = {0, 0, 0, 0};
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float m = protos[k * C + c];                            // wave-uniform -> scalar load
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float t = f[c][p] - m;
+                d[p] += t * t;
+            }
+        }
+#pragma unroll
+        for (int p = 0; p < 4; ++p) {
+            d[p] = -d[p];
+            sum[p] += d[p];
+            if (d[p] > best[p]) { best[p] = d[p]; bi[p] = k; }
+        }
+        if (logits != nullptr && active)
+            *reinterpret_cast<float4*>(logits + (b * K + k) * HW + pix) = make_float4(d[0], d[1], d[2], d[3]);
+    }
+    if (active) {
+        if (argmax != nullptr)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) argmax[b * HW + pix + p] = (uint8_t)bi[p];
+        if (dissum != nullptr)
+            *reinterpret_cast<float4*>(dissum + b * HW + pix) = make_float4(-sum[0], -sum[1], -sum[2], -sum[3]);
+    }
+}
+
 // ---- fused: bilinear upsample of the low-resolution embedding e[B,h,w,C] + head at [H,W]
 template <int PX, int CM>
 __global__ __launch_bounds__(256) void upsample_dist_fwd_kernel(const float* __restrict__ e,
@@ -468,7 +554,11 @@ extern "C" int dml_proto_dist_fwd(const float* x_nchw, const float* protos, floa
     if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
     const int64_t HW = (int64_t)H * W;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (HW % 4 == 0) {
+    if (HW % 4 == 0 && C == 16 && K == 16) {
+        const int64_t groups = (int64_t)B * HW / 4;
+        hipLaunchKernelGGL(proto_dist_fwd_c16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, x_nchw,
+                           protos, logits, feats, argmax, dissum, B, HW);
+    } else if (HW % 4 == 0) {
         const int grid = grid_for((int64_t)B * HW / 4, 256, 256 * 16);
         if (C <= 16) hipLaunchKernelGGL((proto_dist_fwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, x_nchw, protos, logits, feats,
                            argmax, dissum, B, C, K, HW);
