@@ -118,6 +118,160 @@ __global__ __launch_bounds__(256) void proto_dist_fwd_kernel(const float* __rest
     }
 }
 
+// ---- per-wave NHWC <-> "4 pixels per lane" transposition through a 16 KB LDS image (C = 16 floats per pixel).
+// Lane l owns pixel groups wave_first + l (4 pixels = 256 B = 16 chunks of 16 B).  Global accesses are issued so
+// that lane l touches chunk j*64 + l of the wave's contiguous 16 KB: 1 KB of consecutive bytes per instruction.
+__device__ __forceinline__ void wave_store_nhwc16(float4* st, const float (&f)[16][4], float* __restrict__ dst,
+                                                  int lane, int64_t wave_first, int64_t total) {
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4)
+            st[lane * 16 + ((p * 4 + c4) ^ (lane & 15))] =
+                make_float4(f[c4 * 4][p], f[c4 * 4 + 1][p], f[c4 * 4 + 2][p], f[c4 * 4 + 3][p]);
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = j * 64 + lane, r = q >> 4;
+        const float4 v = st[r * 16 + ((q & 15) ^ (r & 15))];
+        if (wave_first + r < total) *reinterpret_cast<float4*>(dst + (wave_first + r) * 64 + (q & 15) * 4) = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+}
+__device__ __forceinline__ void wave_load_nhwc16(float4* st, float (&f)[16][4], const float* __restrict__ src,
+                                                 int lane, int64_t wave_first, int64_t total) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+        const int q = j * 64 + lane, r = q >> 4;
+        float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (wave_first + r < total) v = *reinterpret_cast<const float4*>(src + (wave_first + r) * 64 + (q & 15) * 4);
+        st[r * 16 + ((q & 15) ^ (r & 15))] = v;
+    }
+    __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int p = 0; p < 4; ++p)
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 v = st[lane * 16 + ((p * 4 + c4) ^ (lane & 15))];
+            f[c4 * 4][p] = v.x; f[c4 * 4 + 1][p] = v.y; f[c4 * 4 + 2][p] = v.z; f[c4 * 4 + 3][p] = v.w;
+        }
+    __builtin_amdgcn_wave_barrier();
+}
+
+// ---- fused upsample + head, K = C = 16: one pixel group per lane, features stored through the LDS transpose
+__global__ __launch_bounds__(256) void upsample_dist_fwd_c16_kernel(const float* __restrict__ e,
+                                                                    const float* __restrict__ protos,
+                                                                    float* __restrict__ logits,
+                                                                    float* __restrict__ feats, int B, int h, int w,
+                                                                    int H, int W, float sy, float sx) {
+    constexpr int C = 16, K = 16;
+    __shared__ __attribute__((aligned(16))) float4 stage[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int WG = W / 4;
+    const int64_t HW = (int64_t)H * W, groups_per_img = HW / 4, total = (int64_t)B * groups_per_img;
+    const int64_t wave_first = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int64_t i = wave_first + lane;
+    const bool active = i < total;
+    const int64_t ic = active ? i : total - 1;
+    const int b = (int)(ic / groups_per_img);
+    const int64_t g = ic - (int64_t)b * groups_per_img;
+    const int Y = (int)(g / WG), xg = (int)(g - (int64_t)Y * WG);
+    float sY = sy * ((float)Y + 0.5f) - 0.5f;
+    sY = sY < 0.f ? 0.f : sY;
+    const int y0 = min((int)sY, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+    const float ly1 = sY - (float)y0, ly0 = 1.f - ly1;
+    const float* r0 = e + ((int64_t)b * h + y0) * w * C;
+    const float* r1 = e + ((int64_t)b * h + y1) * w * C;
+    float f[C][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int X = xg * 4 + p;
+        float sX = sx * ((float)X + 0.5f) - 0.5f;
+        sX = sX < 0.f ? 0.f : sX;
+        const int x0 = min((int)sX, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float lx1 = sX - (float)x0, lx0 = 1.f - lx1;
+#pragma unroll
+        for (int c = 0; c < C; c += 4) {
+            const float4 a = *reinterpret_cast<const float4*>(r0 + x0 * C + c);
+            const float4 bq = *reinterpret_cast<const float4*>(r0 + x1 * C + c);
+            const float4 cq = *reinterpret_cast<const float4*>(r1 + x0 * C + c);
+            const float4 d = *reinterpret_cast<const float4*>(r1 + x1 * C + c);
+            f[c][p] = ly0 * (lx0 * a.x + lx1 * bq.x) + ly1 * (lx0 * cq.x + lx1 * d.x);
+            f[c + 1][p] = ly0 * (lx0 * a.y + lx1 * bq.y) + ly1 * (lx0 * cq.y + lx1 * d.y);
+            f[c + 2][p] = ly0 * (lx0 * a.z + lx1 * bq.z) + ly1 * (lx0 * cq.z + lx1 * d.z);
+            f[c + 3][p] = ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * cq.w + lx1 * d.w);
+        }
+    }
+    if (feats != nullptr) wave_store_nhwc16(stage[wave], f, feats, lane, wave_first, total);
+    const int64_t pix = g * 4;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float m = protos[k * C + c];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float t = f[c][p] - m;
+                d[p] += t * t;
+            }
+        }
+        if (logits != nullptr && active)
+            *reinterpret_cast<float4*>(logits + ((int64_t)b * K + k) * HW + pix) = make_float4(-d[0], -d[1], -d[2], -d[3]);
+    }
+}
+
+// ---- backward of the head, K = C = 16: df = -2 sum_k g_k (f - m_k) (+ gfeats); NHWC tensors through the transpose
+__global__ __launch_bounds__(256) void proto_dist_bwd_c16_kernel(const float* __restrict__ glogits,
+                                                                 const float* __restrict__ gfeats,
+                                                                 const float* __restrict__ feats,
+                                                                 const float* __restrict__ protos,
+                                                                 float* __restrict__ df, int B, int64_t HW) {
+    constexpr int C = 16, K = 16;
+    __shared__ __attribute__((aligned(16))) float4 stage[4][1024];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int64_t groups_per_img = HW / 4, total = (int64_t)B * groups_per_img;
+    const int64_t wave_first = ((int64_t)blockIdx.x * 4 + wave) * 64;
+    const int64_t i = wave_first + lane;
+    const bool active = i < total;
+    const int64_t ic = active ? i : total - 1;
+    const int64_t b = ic / groups_per_img;
+    const int64_t pix = (ic - b * groups_per_img) * 4;
+    float gs[4] = {0.f, 0.f, 0.f, 0.f};
+    float o[C][4];
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[c][p] = 0.f;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        const float4 t = *reinterpret_cast<const float4*>(glogits + (b * K + k) * HW + pix);
+        const float g[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+        for (int p = 0; p < 4; ++p) gs[p] += g[p];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float m = protos[k * C + c];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) o[c][p] += g[p] * m;              // sum_k g_k m_kc
+        }
+    }
+    float f[C][4];
+    wave_load_nhwc16(stage[wave], f, feats, lane, wave_first, total);
+#pragma unroll
+    for (int c = 0; c < C; ++c)
+#pragma unroll
+        for (int p = 0; p < 4; ++p) o[c][p] = -2.f * (gs[p] * f[c][p] - o[c][p]);
+    if (gfeats != nullptr) {
+        wave_load_nhwc16(stage[wave], f, gfeats, lane, wave_first, total);
+#pragma unroll
+        for (int c = 0; c < C; ++c)
+#pragma unroll
+            for (int p = 0; p < 4; ++p) o[c][p] += f[c][p];
+    }
+    wave_store_nhwc16(stage[wave], o, df, lane, wave_first, total);
+}
+
 // ---- standalone head, K = C = 16 fast path (the reference's configuration).  Per lane: 4 consecutive pixels,
 // 16-byte loads of the 16 channel planes, 16-byte stores of the 16 logit planes; the NHWC copy of the features is
 // transposed through a per-wave 16 KB LDS image (XOR-swizzled 16-byte chunks) so that every store instruction
@@ -582,7 +736,11 @@ extern "C" int dml_upsample_dist_fwd(const float* e, const float* protos, float*
     if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (W % 4 == 0) {
+    if (W % 4 == 0 && C == 16 && K == 16 && argmax == nullptr && dissum == nullptr) {
+        const int64_t groups = (int64_t)B * H * (W / 4);
+        hipLaunchKernelGGL(upsample_dist_fwd_c16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, e,
+                           protos, logits, feats, B, h, w, H, W, sy, sx);
+    } else if (W % 4 == 0) {
         const int grid = grid_for((int64_t)B * H * (W / 4), 256, 256 * 16);
         if (C <= 16) hipLaunchKernelGGL((upsample_dist_fwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, e, protos, logits, feats,
                            argmax, dissum, B, h, w, C, K, H, W, sy, sx);
@@ -606,7 +764,11 @@ extern "C" int dml_proto_dist_bwd(const float* glogits, const float* gfeats, con
     if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
     const int64_t HW = (int64_t)H * W;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (HW % 4 == 0) {
+    if (HW % 4 == 0 && C == 16 && K == 16) {
+        const int64_t groups = (int64_t)B * HW / 4;
+        hipLaunchKernelGGL(proto_dist_bwd_c16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, glogits,
+                           gfeats, feats, protos, df, B, HW);
+    } else if (HW % 4 == 0) {
         const int grid = grid_for((int64_t)B * HW / 4, 256, 256 * 16);
         if (C <= 16) hipLaunchKernelGGL((proto_dist_bwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, glogits, gfeats, feats, protos,
                            df, B, C, K, HW);
