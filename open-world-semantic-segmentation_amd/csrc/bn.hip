@@ -21,6 +21,7 @@ __device__ __forceinline__ void merge(Moments& a, double nb, double meanb, doubl
 
 // partials[g][n] = (sum, M2 about the group mean) over rows [64 g, 64 g + 64)
 constexpr int FIN_CH = 4, FIN_SL = 64;
+template <int FIN_CH, int FIN_SL>      // channels x group-slices per 256-thread block
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ partials, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
@@ -320,9 +321,17 @@ extern "C" int dml_bn_finalize(const float* partials, int64_t M, int N, const fl
                                float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
     if (!partials || !scale || !shift || !save_mean || M <= 0 || N <= 0) return DML_EINVAL;
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), partials, M, N, gamma, beta, running_mean, running_var,
-                       momentum, eps, scale, shift, save_mean, save_invstd);
+    // many row groups (large feature maps): one channel per block, 256 slices, so that no thread walks more than
+    // G/256 partials (the 192x192 layers have G = 9216 and as few as 64 channels)
+    const int64_t G = (M + DML_STAT_ROWS - 1) / DML_STAT_ROWS;
+    if (G >= 2048)
+        hipLaunchKernelGGL((bn_finalize_kernel<1, 256>), dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream),
+                           partials, M, N, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                           save_mean, save_invstd);
+    else
+        hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), partials, M, N, gamma, beta, running_mean, running_var,
+                           momentum, eps, scale, shift, save_mean, save_invstd);
     DML_LAUNCH_CHECK();
     return 0;
 }
