@@ -601,32 +601,49 @@ __global__ __launch_bounds__(256) void novel_relabel_kernel(const float* __restr
 
 // ---- DML loss
 // block partial = (sum nll, #valid, sum -logit_y over valid, #correct)
+template <int PX>
 __global__ __launch_bounds__(256) void loss_fwd_kernel(const float* __restrict__ logits,
                                                        const int64_t* __restrict__ labels,
                                                        float* __restrict__ partials, int B, int K, int64_t HW,
                                                        int64_t ignore_index) {
     __shared__ float sh[4][4];
     float s_nll = 0.f, s_cnt = 0.f, s_var = 0.f, s_ok = 0.f;
-    const int64_t total = (int64_t)B * HW;
+    const int64_t gpi = HW / PX, total = (int64_t)B * gpi;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t lab = labels[i];
-        if (lab == ignore_index) continue;
-        const int64_t b = i / HW, pix = i - b * HW;
+        const int64_t b = i / gpi, pix = (i - b * gpi) * PX;
+        int64_t lab[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) lab[p] = labels[b * HW + pix + p];
         const float* src = logits + b * K * HW + pix;
-        float mx = src[0];
-        int bi = 0;
-        for (int k = 1; k < K; ++k) {
-            const float v = src[(int64_t)k * HW];
-            if (v > mx) { mx = v; bi = k; }
+        float mx[PX], own[PX], den[PX];
+        int bi[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) { mx[p] = -INFINITY; own[p] = 0.f; den[p] = 0.f; bi[p] = 0; }
+        for (int k = 0; k < K; ++k) {
+            float v[PX];
+            if constexpr (PX == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)k * HW);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                v[0] = src[(int64_t)k * HW];
+            }
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                // online log-sum-exp: one pass over the K planes
+                if (v[p] > mx[p]) { den[p] = den[p] * expf(mx[p] - v[p]) + 1.f; mx[p] = v[p]; bi[p] = k; }
+                else den[p] += expf(v[p] - mx[p]);
+                if ((int64_t)k == lab[p]) own[p] = v[p];
+            }
         }
-        float den = 0.f;
-        for (int k = 0; k < K; ++k) den += expf(src[(int64_t)k * HW] - mx);
-        const float own = src[lab * HW];
-        s_nll += (mx - own) + logf(den);
-        s_cnt += 1.f;
-        s_var += -own;
-        s_ok += (bi == (int)lab) ? 1.f : 0.f;
+#pragma unroll
+        for (int p = 0; p < PX; ++p) {
+            if (lab[p] == ignore_index) continue;
+            s_nll += (mx[p] - own[p]) + logf(den[p]);
+            s_cnt += 1.f;
+            s_var += -own[p];
+            s_ok += (bi[p] == (int)lab[p]) ? 1.f : 0.f;
+        }
     }
     s_nll = wave_sum(s_nll); s_cnt = wave_sum(s_cnt); s_var = wave_sum(s_var); s_ok = wave_sum(s_ok);
     if ((threadIdx.x & 63) == 0) {
@@ -665,6 +682,7 @@ __global__ void loss_finalize_kernel(const double* sums, float* loss, float alph
         *loss = (float)((ce + (double)alpha * sums[2]) / (double)n_images);
     }
 }
+template <int PX>
 __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__ logits,
                                                        const int64_t* __restrict__ labels,
                                                        const double* __restrict__ sums,
@@ -674,27 +692,50 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     const float go = gout ? *gout : 1.f;
     const float w_ce = go / ((float)sums[1] * n_images);
     const float w_var = go * alpha / ((float)HW * n_images);
-    const int64_t total = (int64_t)B * HW;
+    const int64_t gpi = HW / PX, total = (int64_t)B * gpi;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t lab = labels[i];
-        const int64_t b = i / HW, pix = i - b * HW;
+        const int64_t b = i / gpi, pix = (i - b * gpi) * PX;
+        int64_t lab[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) lab[p] = labels[b * HW + pix + p];
         const float* src = logits + b * K * HW + pix;
         float* dst = glogits + b * K * HW + pix;
-        if (lab == ignore_index) {
-            for (int k = 0; k < K; ++k) dst[(int64_t)k * HW] = 0.f;
-            continue;
-        }
-        float mx = src[0];
-        for (int k = 1; k < K; ++k) mx = fmaxf(mx, src[(int64_t)k * HW]);
-        float den = 0.f;
-        for (int k = 0; k < K; ++k) den += expf(src[(int64_t)k * HW] - mx);
-        const float inv = 1.f / den;
+        float mx[PX], den[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) { mx[p] = -INFINITY; den[p] = 0.f; }
         for (int k = 0; k < K; ++k) {
-            const float pk = expf(src[(int64_t)k * HW] - mx) * inv;
-            float g = w_ce * pk;
-            if (k == (int)lab) g -= w_ce + w_var;
-            dst[(int64_t)k * HW] = g;
+            float v[PX];
+            if constexpr (PX == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)k * HW);
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                v[0] = src[(int64_t)k * HW];
+            }
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                if (v[p] > mx[p]) { den[p] = den[p] * expf(mx[p] - v[p]) + 1.f; mx[p] = v[p]; }
+                else den[p] += expf(v[p] - mx[p]);
+            }
+        }
+        float inv[PX];
+#pragma unroll
+        for (int p = 0; p < PX; ++p) inv[p] = lab[p] == ignore_index ? 0.f : w_ce / den[p];
+        for (int k = 0; k < K; ++k) {
+            float v[PX], g[PX];
+            if constexpr (PX == 4) {
+                const float4 t = *reinterpret_cast<const float4*>(src + (int64_t)k * HW);   // L2-resident re-read
+                v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+            } else {
+                v[0] = src[(int64_t)k * HW];
+            }
+#pragma unroll
+            for (int p = 0; p < PX; ++p) {
+                g[p] = expf(v[p] - mx[p]) * inv[p];
+                if ((int64_t)k == lab[p] && lab[p] != ignore_index) g[p] -= w_ce + w_var;
+            }
+            if constexpr (PX == 4) *reinterpret_cast<float4*>(dst + (int64_t)k * HW) = make_float4(g[0], g[1], g[2], g[3]);
+            else dst[(int64_t)k * HW] = g[0];
         }
     }
 }
@@ -826,10 +867,15 @@ extern "C" int dml_loss_fwd(const float* logits, const int64_t* labels, double* 
                             int B, int K, int H, int W, int64_t ignore_index, void* stream) {
     if (!logits || !labels || !sums || !block_partials || B <= 0 || K <= 0) return DML_EINVAL;
     const int64_t HW = (int64_t)H * W;
-    const int grid = grid_for(B * HW, 256, DML_LOSS_BLOCKS);
+    const bool v4 = (HW % 4) == 0;
+    const int grid = grid_for(B * HW / (v4 ? 4 : 1), 256, DML_LOSS_BLOCKS);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(loss_fwd_kernel, dim3(grid), dim3(256), 0, st, logits, labels, block_partials, B, K, HW,
-                       ignore_index);
+    if (v4)
+        hipLaunchKernelGGL(loss_fwd_kernel<4>, dim3(grid), dim3(256), 0, st, logits, labels, block_partials, B, K, HW,
+                           ignore_index);
+    else
+        hipLaunchKernelGGL(loss_fwd_kernel<1>, dim3(grid), dim3(256), 0, st, logits, labels, block_partials, B, K, HW,
+                           ignore_index);
     hipLaunchKernelGGL(loss_sum_kernel, dim3(1), dim3(256), 0, st, block_partials, grid, sums, 1.0 / (double)HW);
     DML_LAUNCH_CHECK();
     return 0;
@@ -848,9 +894,14 @@ extern "C" int dml_loss_bwd(const float* logits, const int64_t* labels, const do
                             float n_images, void* stream) {
     if (!logits || !labels || !sums || !glogits) return DML_EINVAL;
     const int64_t HW = (int64_t)H * W;
-    hipLaunchKernelGGL(loss_bwd_kernel, dim3(grid_for(B * HW, 256, 256 * 16)), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), logits, labels, sums, gout, glogits, B, K, HW,
-                       ignore_index, alpha, n_images);
+    if (HW % 4 == 0)
+        hipLaunchKernelGGL(loss_bwd_kernel<4>, dim3(grid_for(B * HW / 4, 256, 256 * 32)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), logits, labels, sums, gout, glogits, B, K, HW,
+                           ignore_index, alpha, n_images);
+    else
+        hipLaunchKernelGGL(loss_bwd_kernel<1>, dim3(grid_for(B * HW, 256, 256 * 32)), dim3(256), 0,
+                           static_cast<hipStream_t>(stream), logits, labels, sums, gout, glogits, B, K, HW,
+                           ignore_index, alpha, n_images);
     DML_LAUNCH_CHECK();
     return 0;
 }
