@@ -638,7 +638,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
 
 // ------------------------------------------------------------------------------------------------
 // weight-gradient kernel: dw[n][kc] += sum_m dy[m][n] * x[src(m, tap(kc))][c(kc)]
-// tile 128 (n) x 128 (kc), K loop over 32-pixel slabs, split over the pixel dimension (blockIdx.y).
+// tile 128 (n) x 128 (kc), K loop over 32-pixel slabs, split over the pixel dimension.
 // Both operands are "K-major" in memory (pixel rows, channel contiguous): the bf16 fragments are
 // read with the gfx950 LDS transpose read ds_read_b64_tr_b16, the fp32 ones need no transpose.
 // ------------------------------------------------------------------------------------------------
@@ -682,7 +682,12 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 1, wk = wave & 1;
-    const int blk_n = blockIdx.x % a.nblk_n, blk_k = blockIdx.x / a.nblk_n;
+    // 1-D grid, XCD-aware: every (n, kc) tile of one pixel slab runs on the same XCD, so the dy / x slabs are
+    // fetched into that XCD's L2 once instead of once per XCD (PMC: 363 MB fetched per launch before, see DESIGN)
+    const int ntile = a.nblk_n * a.nblk_k;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntile, tile_id = logical - split * ntile;
+    const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
     const int n0 = blk_n * TILE, kc0 = blk_k * TILE;
 
     const T* __restrict__ X = static_cast<const T*>(a.x);
@@ -699,7 +704,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
     const int yn = n0 + vcol * VEC;
     const bool yn_ok = yn < a.N;
 
-    const int tile_beg = blockIdx.y * a.slab_tiles;
+    const int tile_beg = split * a.slab_tiles;
     const int tiles_total = (a.M + BK - 1) / BK;
     const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
 
@@ -825,7 +830,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
                 const int k = kc0 + wk * 64 + j * 16 + lr;
                 if (k < a.Ktot) {
                     if (a.ws != nullptr)
-                        a.ws[((int64_t)blockIdx.y * a.N + n) * a.Ktot + k] = acc[i][j][q];
+                        a.ws[((int64_t)split * a.N + n) * a.Ktot + k] = acc[i][j][q];
                     else
                         atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q]);
                 }
@@ -1004,7 +1009,7 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     a.slab_tiles = (tiles + splitk - 1) / splitk;
     splitk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    dim3 grid(a.nblk_n * a.nblk_k, splitk);
+    dim3 grid(a.nblk_n * a.nblk_k * splitk);
     if (d->dtype == DML_BF16)
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);
     else
