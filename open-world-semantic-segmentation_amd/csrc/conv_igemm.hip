@@ -844,7 +844,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                            int splits, int64_t NRS, int Cm, int Cp) {
     const int64_t total = NRS * Cm;
     const int64_t plane = NRS * Cp;
-    const int s0 = blockIdx.y * 16, s1 = min(splits, s0 + 16);
+    const int s0 = gridDim.y == 1 ? 0 : blockIdx.y * 16, s1 = gridDim.y == 1 ? splits : min(splits, s0 + 16);
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         int64_t src = i;
@@ -1016,8 +1016,10 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
     if (use_ws) {
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), (splitk + 15) / 16), dim3(256), 0, st,
-                           d->ws, d->dw, splitk, nrs, cm, d->C);
+        // chunk the splits over blockIdx.y (atomic combine) only for small tensors with very many splits (stem)
+        const int ychunks = (nrs * cm < 65536 && splitk > 64) ? (splitk + 15) / 16 : 1;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), ychunks), dim3(256), 0, st, d->ws, d->dw,
+                           splitk, nrs, cm, d->C);
     }
     DML_LAUNCH_CHECK();
     return 0;

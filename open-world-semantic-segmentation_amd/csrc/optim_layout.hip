@@ -58,24 +58,43 @@ __global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restric
     }
 }
 
-// all convolutions of a model in ONE launch: blockIdx.y selects the descriptor
+// all convolutions of a model in ONE launch: blockIdx.y selects the descriptor.  32 x 32 (n x c) tiles go through
+// LDS so that BOTH copies are written with consecutive addresses (the naive scatter into wt[c][rs][n] cost 7x
+// its bytes in partial-sector writes).
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weights_kernel(const DmlPrepDesc* __restrict__ descs) {
+    __shared__ float tile[32][33];
     const DmlPrepDesc d = descs[blockIdx.y];
     const float* __restrict__ src = d.src;
     T* __restrict__ w = static_cast<T*>(d.w);
     T* __restrict__ wt = static_cast<T*>(d.wt);
     const int N = d.N, RS = d.RS, Cm = d.Cm, Cp = d.Cp;
-    const int64_t total = (int64_t)N * RS * Cp;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const int c = (int)(i % Cp);
-        const int64_t t = i / Cp;
-        const int rs = (int)(t % RS);
-        const int n = (int)(t / RS);
-        const float v = c < Cm ? src[((int64_t)n * RS + rs) * Cm + c] : 0.f;
-        Elem<T>::st(w + i, v);
-        if (wt != nullptr) Elem<T>::st(wt + ((int64_t)c * RS + rs) * N + n, v);
+    const int tn = (N + 31) / 32, tc = (Cp + 31) / 32;
+    const int ntiles = tn * tc * RS;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
+    for (int t = blockIdx.x; t < ntiles; t += gridDim.x) {
+        const int rs = t % RS;
+        const int tt = t / RS;
+        const int c0 = (tt % tc) * 32, n0 = (tt / tc) * 32;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int n = n0 + ty + j * 8, c = c0 + tx;
+            float v = 0.f;
+            if (n < N && c < Cp) {
+                if (c < Cm) v = src[((int64_t)n * RS + rs) * Cm + c];
+                Elem<T>::st(w + ((int64_t)n * RS + rs) * Cp + c, v);
+            }
+            tile[ty + j * 8][tx] = v;
+        }
+        __syncthreads();
+        if (wt != nullptr) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int c = c0 + ty + j * 8, n = n0 + tx;
+                if (c < Cp && n < N) Elem<T>::st(wt + ((int64_t)c * RS + rs) * N + n, tile[tx][ty + j * 8]);
+            }
+        }
+        __syncthreads();
     }
 }
 
