@@ -397,6 +397,14 @@ class Plan:
         bb, head = m.backbone, m.classifier
         K = head.classifier[3].out_channels
         self.K = K
+        if K % self.vec or K > 32:
+            raise NotImplementedError(
+                "num_classes=%d: the MI355X path needs the embedding dimension to be a multiple of %d (16-byte channel "
+                "vectors in %s) and <= 32; the reference's drivers use 16 (main_embedding.py:336)" % (K, self.vec, self.dtype))
+        for mod in itertools.chain(bb.modules(), head.modules()):
+            if isinstance(mod, nn.BatchNorm2d) and mod.training != self.training:
+                raise NotImplementedError("BatchNorm2d modules in a different mode than the model (fix_bn) are not "
+                                          "supported on the MI355X path")
 
         # input packing NCHW fp32 -> NHWC (8 ch)
         x_in = self.new(B, H, W, _PAD_CIN)
