@@ -109,8 +109,9 @@ int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W
 /* Chan-merge the conv epilogue partials -> mean / biased var -> scale = gamma*invstd, shift = beta,
  * save_mean = mean (required; dml_bn_apply subtracts it before scaling so that low-variance channels do
  * not cancel); updates running stats with the unbiased variance and `momentum` exactly as
- * nn.BatchNorm2d does; saves invstd for the backward. */
-int dml_bn_finalize(const float* partials, int64_t M, int N, const float* gamma, const float* beta,
+ * nn.BatchNorm2d does; saves invstd for the backward.  `partials` is scratch: the call may fold it in place
+ * (large feature maps), so it is not valid input for a second call. */
+int dml_bn_finalize(float* partials, int64_t M, int N, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 /* Standalone statistics for tensors that were not produced by dml_conv_igemm (writes the same

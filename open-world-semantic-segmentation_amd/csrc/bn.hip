@@ -313,25 +313,94 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
     }
 }
 
+// Large feature maps (G >= 2048 row groups): two coalesced stages instead of one strided walk per channel.
+// Stage 1: block (channel tile of 64, chunk of R groups) reads its rows 512 B per wave and folds them to three
+// fp64 sums per channel -- S = sum s_g, Q = sum M2_g, P = sum s_g^2 / n_g -- which it writes IN PLACE over the
+// first three rows of its own chunk (row = N float2 = N doubles; nobody else reads those columns of those rows).
+// Stage 2: per channel, sum the chunks: M2 = Q + P - S^2 / M (fp64: the cancellation costs ~1e-16 * mean^2/var).
+constexpr int FIN2_MAXCHUNK = 128;
+__global__ __launch_bounds__(256) void bn_fold_partials_kernel(float* partials, int64_t G, int N, int R, int NC,
+                                                               int last_rows) {
+    __shared__ double sh[3][4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int64_t g0 = (int64_t)blockIdx.y * R;
+    const int64_t g1 = (int)blockIdx.y == NC - 1 ? G : g0 + R;
+    double S = 0.0, Q = 0.0, P = 0.0;
+    if (n < N)
+        for (int64_t g = g0 + rl; g < g1; g += 4) {
+            const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
+            const double rows = g == G - 1 ? (double)last_rows : (double)DML_STAT_ROWS;
+            S += (double)p.x;
+            Q += (double)p.y;
+            P += (double)p.x * (double)p.x / rows;
+        }
+    sh[0][rl][c] = S;
+    sh[1][rl][c] = Q;
+    sh[2][rl][c] = P;
+    __syncthreads();     // every read of this block's rows is done before they are overwritten
+    if (rl < 3 && n < N) {
+        const double v = sh[rl][0][c] + sh[rl][1][c] + sh[rl][2][c] + sh[rl][3][c];
+        reinterpret_cast<double*>(partials)[(g0 + rl) * N + n] = v;
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_finalize_folded_kernel(
+    const float* __restrict__ partials, int64_t M, int N, int R, int NC, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
+    float* scale, float* shift, float* save_mean, float* save_invstd) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double* f = reinterpret_cast<const double*>(partials);
+    double S = 0.0, Q = 0.0, P = 0.0;
+    for (int ck = 0; ck < NC; ++ck) {
+        const int64_t g0 = (int64_t)ck * R;
+        S += f[(g0 + 0) * N + n];
+        Q += f[(g0 + 1) * N + n];
+        P += f[(g0 + 2) * N + n];
+    }
+    const double cnt = (double)M, mean = S / cnt;
+    double m2 = Q + (P - S * mean);
+    if (m2 < 0.0) m2 = 0.0;
+    const double var_b = m2 / cnt;
+    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+    const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
+    scale[n] = g * invstd;
+    shift[n] = b;
+    save_mean[n] = (float)mean;
+    if (save_invstd) save_invstd[n] = invstd;
+    if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+    if (running_var) {
+        const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
+    }
+}
+
+
 inline bool vec_ok(int dtype, int a) { return a % (dtype == DML_BF16 ? 8 : 4) == 0; }
 
 }  // namespace
 
-extern "C" int dml_bn_finalize(const float* partials, int64_t M, int N, const float* gamma, const float* beta,
+extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
     if (!partials || !scale || !shift || !save_mean || M <= 0 || N <= 0) return DML_EINVAL;
-    // many row groups (large feature maps): one channel per block, 256 slices, so that no thread walks more than
-    // G/256 partials (the 192x192 layers have G = 9216 and as few as 64 channels)
     const int64_t G = (M + DML_STAT_ROWS - 1) / DML_STAT_ROWS;
-    if (G >= 2048)
-        hipLaunchKernelGGL((bn_finalize_kernel<1, 256>), dim3(N), dim3(256), 0, static_cast<hipStream_t>(stream),
-                           partials, M, N, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
-                           save_mean, save_invstd);
-    else
-        hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0,
-                           static_cast<hipStream_t>(stream), partials, M, N, gamma, beta, running_mean, running_var,
-                           momentum, eps, scale, shift, save_mean, save_invstd);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (G >= 2048) {
+        // large feature maps (the 192x192 layers have G = 9216 and as few as 64 channels): fold, then finish
+        if ((reinterpret_cast<uintptr_t>(partials) & 7) != 0) return DML_EALIGN;
+        const int R = (int)((G + FIN2_MAXCHUNK - 1) / FIN2_MAXCHUNK);      // >= 16 rows per chunk
+        const int NC = (int)(G / R);                                         // the last chunk takes the remainder
+        const int last_rows = (int)(M - (G - 1) * DML_STAT_ROWS);
+        hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((N + 63) / 64, NC), dim3(256), 0, st, partials, G, N, R, NC,
+                           last_rows);
+        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partials, M, N, R, NC,
+                           gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    } else {
+        hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, st, partials, M, N, gamma,
+                           beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+    }
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -24,6 +24,14 @@ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
     u += 0x7fffu + ((u >> 16) & 1u);
     return (bf16_t)(u >> 16);
 }
+// two floats -> packed bf16 pair (lo in bits 0-15), round-to-nearest-even: one v_cvt_pk_bf16_f32 on gfx950
+__device__ __forceinline__ uint32_t pack_bf16x2(float lo, float hi) {
+    typedef __bf16 bf16x2_hw __attribute__((ext_vector_type(2)));
+    typedef float f32x2_hw __attribute__((ext_vector_type(2)));
+    const f32x2_hw v = {lo, hi};
+    const bf16x2_hw b = __builtin_convertvector(v, bf16x2_hw);
+    return __builtin_bit_cast(uint32_t, b);
+}
 
 template <typename T> struct Elem;
 template <> struct Elem<float> {
@@ -64,7 +72,7 @@ template <> struct Vec16<bf16_t> {
         uint32_t w[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i)
-            w[i] = (uint32_t)f32_to_bf16(v[2 * i]) | ((uint32_t)f32_to_bf16(v[2 * i + 1]) << 16);
+            w[i] = pack_bf16x2(v[2 * i], v[2 * i + 1]);
         *reinterpret_cast<uint4*>(p) = make_uint4(w[0], w[1], w[2], w[3]);
     }
 };

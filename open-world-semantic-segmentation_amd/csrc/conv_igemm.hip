@@ -33,6 +33,7 @@ struct ConvArgs {
     int y_f32, accum;
     int nblk_n, nblk_m;
     FastDiv div_wo, div_howo, div_c;
+    float* dbg;      // tuning builds only (ABL == 3): per-wave phase timings
 };
 
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
@@ -51,19 +52,47 @@ template <> __device__ __forceinline__ int swz_chunk<bf16_t>(int row, int chunk)
 template <> __device__ __forceinline__ int swz_chunk<float>(int row, int chunk) { return chunk ^ (row & 7); }
 
 // ------------------------------------------------------------------------------------------------
+// Weight-tile row order.  MFMA tile i of a wave's TN = 16 NT channels does not take channels 16 i .. 16 i + 15:
+// its row rho = 4 g + e (g = rho >> 2 is the accumulator's lane group, e the register) is channel
+// g * (4 NT) + 4 i + e, so that after NT tiles every lane holds CL = 4 NT CONSECUTIVE channels of one pixel and the
+// epilogue stores whole 16-byte vectors straight from the accumulators (a wave writes full 128-byte rows; no
+// LDS staging, no barriers).  In LDS the tile stays in plain channel order; the fragment read just picks row
+// b_row(i, rho), and the chunk swizzle is keyed on rho (recovered from the row by b_rho) so the bank pattern of
+// the fragment reads is the conflict-free one of swz_chunk.
+// ------------------------------------------------------------------------------------------------
+template <int NT> __device__ __forceinline__ int b_row(int i, int rho) { return (rho >> 2) * (4 * NT) + i * 4 + (rho & 3); }
+template <int NT> __device__ __forceinline__ int b_rho(int row) { return ((row / (4 * NT)) & 3) * 4 + (row & 3); }
+
+template <int CTRL> __device__ __forceinline__ float dpp_mov(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+// sum over the 16 lanes of a DPP row (every lane gets the total): quad xor 1, xor 2, half mirror, row mirror
+__device__ __forceinline__ float row16_sum(float v) {
+    v += dpp_mov<0xB1>(v);
+    v += dpp_mov<0x4E>(v);
+    v += dpp_mov<0x141>(v);
+    v += dpp_mov<0x140>(v);
+    return v;
+}
+
+// ------------------------------------------------------------------------------------------------
 // shared epilogue: BN partial statistics, bias, accumulate, fp32 / storage-dtype stores
-// acc[i][j][reg] = out[m = mw0 + j*16 + (lane&15)][n = nw0 + i*16 + (lane>>4)*4 + reg]
+// acc[i][j][e] = out[m = mw0 + j*16 + (lane&15)][n = nw0 + (lane>>4)*4*NT + i*4 + e]
 // ------------------------------------------------------------------------------------------------
 template <typename T, int NT, int MT>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int mw0, const int nw0,
-                                              const int lr, const int lq, const bool do_store = true) {
+                                              const int lr, const int lq) {
     constexpr int TM = MT * 16;
+    constexpr int CL = NT * 4;
+    const int nl = nw0 + lq * CL;                 // first channel of this lane
 
     if (a.stats != nullptr) {
         const int cnt = min(TM, max(0, a.M - mw0));
         if (cnt > 0) {
             const float inv = 1.0f / (float)cnt;
             const int grp = mw0 / TM;
+            float* sp = a.stats + ((int64_t)grp * a.N + nl) * 2;
+            const bool pair_ok = (a.N & 1) == 0;
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -74,10 +103,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                     for (int q = 0; q < 4; ++q) s[q] += v ? acc[i][j][q] : 0.f;
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) s[q] += __shfl_xor(s[q], o, 64);
-                }
+                for (int q = 0; q < 4; ++q) s[q] = row16_sum(s[q]);
                 float m2[4] = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
@@ -89,187 +115,106 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                     }
                 }
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-#pragma unroll
-                    for (int o = 1; o < 16; o <<= 1) m2[q] += __shfl_xor(m2[q], o, 64);
-                }
+                for (int q = 0; q < 4; ++q) m2[q] = row16_sum(m2[q]);
                 if (lr == 0) {
+                    const int n = nl + i * 4;
+                    if (pair_ok && n + 3 < a.N) {
+                        float4* p4 = reinterpret_cast<float4*>(sp + i * 8);
+                        p4[0] = make_float4(s[0], m2[0], s[1], m2[1]);
+                        p4[1] = make_float4(s[2], m2[2], s[3], m2[3]);
+                    } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        const int n = nw0 + i * 16 + lq * 4 + q;
-                        if (n < a.N) {
-                            float* p = a.stats + ((int64_t)grp * a.N + n) * 2;
-                            p[0] = s[q];
-                            p[1] = m2[q];
-                        }
+                        for (int q = 0; q < 4; ++q)
+                            if (n + q < a.N) {
+                                sp[(i * 4 + q) * 2] = s[q];
+                                sp[(i * 4 + q) * 2 + 1] = m2[q];
+                            }
                     }
                 }
             }
         }
     }
 
-    if (!do_store) return;
-    const bool vec_ok = ((a.N & 3) == 0) && ((a.ldy & 3) == 0);
+    float bv[CL];
+#pragma unroll
+    for (int c = 0; c < CL; ++c) bv[c] = (a.bias != nullptr && nl + c < a.N) ? a.bias[nl + c] : 0.f;
+
+    const bool out_f32 = a.y_f32 || sizeof(T) == 4;
+    const uintptr_t yb = reinterpret_cast<uintptr_t>(a.y);
+    const bool v4_ok = ((a.N & 3) == 0) && ((a.ldy & 3) == 0) && ((yb & (out_f32 ? 15 : 7)) == 0);
+    const bool v8_ok = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((yb & 15) == 0);
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = mw0 + j * 16 + lr;
         if (m >= a.M) continue;
+        float v[CL];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int n = nw0 + i * 16 + lq * 4;
-            if (n >= a.N) continue;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (a.bias != nullptr) {
+        for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int q = 0; q < 4; ++q)
-                    if (n + q < a.N) v[q] += a.bias[n + q];
-            }
-            const int64_t off = (int64_t)m * a.ldy + n;
-            if (a.y_f32) {
-                float* yp = static_cast<float*>(a.y) + off;
-                if (vec_ok) {
+            for (int q = 0; q < 4; ++q) v[i * 4 + q] = acc[i][j][q] + bv[i * 4 + q];
+        const int64_t off = (int64_t)m * a.ldy + nl;
+        if (out_f32) {
+            float* yp = static_cast<float*>(a.y) + off;
+#pragma unroll
+            for (int g = 0; g < NT; ++g) {
+                const int n = nl + g * 4;
+                if (n >= a.N) continue;
+                if (v4_ok) {
+                    float4 o = make_float4(v[g * 4], v[g * 4 + 1], v[g * 4 + 2], v[g * 4 + 3]);
                     if (a.accum) {
-                        const float4 o = *reinterpret_cast<const float4*>(yp);
-                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
+                        const float4 t = *reinterpret_cast<const float4*>(yp + g * 4);
+                        o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
                     }
-                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
+                    *reinterpret_cast<float4*>(yp + g * 4) = o;
                 } else {
 #pragma unroll
                     for (int q = 0; q < 4; ++q)
-                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
+                        if (n + q < a.N) yp[g * 4 + q] = a.accum ? yp[g * 4 + q] + v[g * 4 + q] : v[g * 4 + q];
                 }
-            } else if constexpr (sizeof(T) == 4) {
-                float* yp = static_cast<float*>(a.y) + off;
-                if (vec_ok) {
-                    if (a.accum) {
-                        const float4 o = *reinterpret_cast<const float4*>(yp);
-                        v[0] += o.x; v[1] += o.y; v[2] += o.z; v[3] += o.w;
-                    }
-                    *reinterpret_cast<float4*>(yp) = make_float4(v[0], v[1], v[2], v[3]);
-                } else {
+            }
+        } else {
+            bf16_t* yp = static_cast<bf16_t*>(a.y) + off;
+            if (CL >= 8 && v8_ok) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < a.N) yp[q] = a.accum ? yp[q] + v[q] : v[q];
+                for (int g = 0; g < CL / 8; ++g) {
+                    if (nl + g * 8 >= a.N) continue;
+                    float* w = v + g * 8;
+                    if (a.accum) {
+                        const uint4 t = *reinterpret_cast<const uint4*>(yp + g * 8);
+                        const uint32_t tt[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            w[2 * e] += __uint_as_float(tt[e] << 16);
+                            w[2 * e + 1] += __uint_as_float(tt[e] & 0xffff0000u);
+                        }
+                    }
+                    *reinterpret_cast<uint4*>(yp + g * 8) =
+                        make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
+                                   pack_bf16x2(w[6], w[7]));
                 }
             } else {
-                bf16_t* yp = static_cast<bf16_t*>(a.y) + off;
-                if (vec_ok) {
-                    if (a.accum) {
-                        const uint2 o = *reinterpret_cast<const uint2*>(yp);
-                        v[0] += __uint_as_float(o.x << 16);
-                        v[1] += __uint_as_float(o.x & 0xffff0000u);
-                        v[2] += __uint_as_float(o.y << 16);
-                        v[3] += __uint_as_float(o.y & 0xffff0000u);
-                    }
-                    uint2 pk;
-                    pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                    pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                    *reinterpret_cast<uint2*>(yp) = pk;
-                } else {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q)
-                        if (n + q < a.N) yp[q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[q]) + v[q] : v[q]);
-                }
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------------
-// Output through LDS: the MFMA layout gives every lane 4 channels of one pixel (8-byte stores scattered over 16
-// rows per instruction, which is what bounds the small-K 1x1 convolutions).  Staging the tile in LDS turns
-// them into 16-byte-per-lane stores (and accumulate loads) of whole rows.  Two 64-row halves reuse the
-// operand ring, which is free after the K loop.
-// ------------------------------------------------------------------------------------------------
-template <typename OT> __device__ __forceinline__ uint4 add_vec16(uint4 a, uint4 b);
-template <> __device__ __forceinline__ uint4 add_vec16<float>(uint4 a, uint4 b) {
-    return make_uint4(__float_as_uint(__uint_as_float(a.x) + __uint_as_float(b.x)),
-                      __float_as_uint(__uint_as_float(a.y) + __uint_as_float(b.y)),
-                      __float_as_uint(__uint_as_float(a.z) + __uint_as_float(b.z)),
-                      __float_as_uint(__uint_as_float(a.w) + __uint_as_float(b.w)));
-}
-template <> __device__ __forceinline__ uint4 add_vec16<bf16_t>(uint4 a, uint4 b) {
-    const uint32_t x[4] = {a.x, a.y, a.z, a.w}, y[4] = {b.x, b.y, b.z, b.w};
-    uint32_t r[4];
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-        const float lo = __uint_as_float(x[i] << 16) + __uint_as_float(y[i] << 16);
-        const float hi = __uint_as_float(x[i] & 0xffff0000u) + __uint_as_float(y[i] & 0xffff0000u);
-        r[i] = (uint32_t)f32_to_bf16(lo) | ((uint32_t)f32_to_bf16(hi) << 16);
-    }
-    return make_uint4(r[0], r[1], r[2], r[3]);
-}
-
-template <typename OT, int BN, int NT, int MT>
-__device__ __forceinline__ void conv_store_staged(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int m0, const int n0,
-                                                  const int wm, const int wn, const int lr, const int lq,
-                                                  void* smem_raw) {
-    constexpr int TN = NT * 16;
-    constexpr int OV = 16 / (int)sizeof(OT);      // elements per 16-byte vector
-    constexpr int PO = BN + OV;                    // LDS pitch: +16 B keeps rows 16-byte aligned, spreads banks
-    constexpr int CPR = BN / OV;                   // 16-byte chunks per row
-    constexpr int RPP = NTHREADS / CPR;            // rows per pass
-    OT* sm = reinterpret_cast<OT*>(smem_raw);
-    const int tid = threadIdx.x;
-#pragma unroll
-    for (int h = 0; h < 2; ++h) {
-        if (wm == h) {
-#pragma unroll
-            for (int j = 0; j < MT; ++j)
-#pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int n = n0 + wn * TN + i * 16 + lq * 4;
-                    float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                    if (a.bias != nullptr) {
+                for (int g = 0; g < NT; ++g) {
+                    const int n = nl + g * 4;
+                    if (n >= a.N) continue;
+                    float* w = v + g * 4;
+                    if (v4_ok) {
+                        if (a.accum) {
+                            const uint2 t = *reinterpret_cast<const uint2*>(yp + g * 4);
+                            w[0] += __uint_as_float(t.x << 16);
+                            w[1] += __uint_as_float(t.x & 0xffff0000u);
+                            w[2] += __uint_as_float(t.y << 16);
+                            w[3] += __uint_as_float(t.y & 0xffff0000u);
+                        }
+                        *reinterpret_cast<uint2*>(yp + g * 4) = make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
+                    } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
-                            if (n + q < a.N) v[q] += a.bias[n + q];
-                    }
-                    OT* dst = sm + (j * 16 + lr) * PO + wn * TN + i * 16 + lq * 4;
-                    if constexpr (sizeof(OT) == 4) {
-                        *reinterpret_cast<float4*>(dst) = make_float4(v[0], v[1], v[2], v[3]);
-                    } else {
-                        uint2 pk;
-                        pk.x = (uint32_t)f32_to_bf16(v[0]) | ((uint32_t)f32_to_bf16(v[1]) << 16);
-                        pk.y = (uint32_t)f32_to_bf16(v[2]) | ((uint32_t)f32_to_bf16(v[3]) << 16);
-                        *reinterpret_cast<uint2*>(dst) = pk;
+                            if (n + q < a.N)
+                                yp[g * 4 + q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[g * 4 + q]) + w[q] : w[q]);
                     }
                 }
-        }
-        __syncthreads();
-        const int ch = tid % CPR;
-        const int n = n0 + ch * OV;
-        for (int r = tid / CPR; r < 64; r += RPP) {
-            const int m = m0 + h * 64 + r;
-            if (m < a.M && n < a.N) {
-                uint4 v = *reinterpret_cast<const uint4*>(sm + r * PO + ch * OV);
-                OT* yp = static_cast<OT*>(a.y) + (int64_t)m * a.ldy + n;
-                if (a.accum) v = add_vec16<OT>(v, *reinterpret_cast<const uint4*>(yp));
-                *reinterpret_cast<uint4*>(yp) = v;
             }
-        }
-        __syncthreads();
-    }
-}
-
-// stats + store; picks the staged path when rows are 16-byte addressable
-template <typename T, int BN, int NT, int MT, int SMEM_BYTES>
-__device__ __forceinline__ void conv_finish(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int m0, const int n0,
-                                            const int wm, const int wn, const int lr, const int lq, void* smem_raw) {
-    constexpr int TM = MT * 16, TN = NT * 16;
-    const bool out_f32 = a.y_f32 || sizeof(T) == 4;
-    const int ov = out_f32 ? 4 : 8;
-    const bool rows_ok = (a.N % ov) == 0 && (a.ldy % ov) == 0 && ((reinterpret_cast<uintptr_t>(a.y) & 15) == 0);
-    constexpr bool fits_f32 = 64 * (BN + 4) * 4 <= SMEM_BYTES;
-    constexpr bool fits_b16 = 64 * (BN + 8) * 2 <= SMEM_BYTES;
-    const bool staged = rows_ok && (out_f32 ? fits_f32 : fits_b16);
-    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq, !staged);
-    if (staged) {
-        if (out_f32) {
-            if constexpr (fits_f32) conv_store_staged<float, BN, NT, MT>(acc, a, m0, n0, wm, wn, lr, lq, smem_raw);
-        } else {
-            if constexpr (fits_b16 && sizeof(T) == 2)
-                conv_store_staged<bf16_t, BN, NT, MT>(acc, a, m0, n0, wm, wn, lr, lq, smem_raw);
         }
     }
 }
@@ -294,6 +239,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
+    uint64_t t_start = 0;
+    if constexpr (ABL == 3) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_start)::"memory");
     const int tile = xcd_remap(blockIdx.x, gridDim.x);
     const int blk_m = tile / a.nblk_n, blk_n = tile - blk_m * a.nblk_n;
     const int m0 = blk_m * BM, n0 = blk_n * BN;
@@ -390,7 +337,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
         for (int j = 0; j < B_LD; ++j) {
             const int row = prow + j * RPP;
             if (row < BN)
-                *reinterpret_cast<uint4*>(Bs(buf) + row * BK + swz_chunk<T>(row, kvec) * VEC) = b_reg[j];
+                *reinterpret_cast<uint4*>(Bs(buf) + row * BK + swz_chunk<T>(b_rho<NT>(row), kvec) * VEC) = b_reg[j];
         }
     };
 
@@ -418,26 +365,41 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
 
     const int lr = lane & 15, lq = lane >> 4;
     int cur = 0;
+    // ABL == 3: s_memtime stamps at the points where lgkmcnt(0) is harmless; deltas averaged over the K loop
+    uint32_t ph[6] = {0, 0, 0, 0, 0, 0};
+    uint64_t tprev = 0;
+    auto stamp = [&](int i) {
+        if constexpr (ABL == 3) {
+            uint64_t t;
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if (i >= 0) ph[i] += (uint32_t)(t - tprev);
+            tprev = t;
+        }
+    };
+    stamp(-1);
+    const uint64_t t_loop = tprev;
     for (int kt = 0; kt < KT; ++kt) {
         const bool has_next = kt + 1 < KT;
         if (has_next && ABL != 1) {
             advance();
             load_tiles(kt + 1, tap_r, tap_s, c0);
         }
+        stamp(0);      // global loads issued
         const T* as = As(cur) + (wm * TM) * BK;
         const T* bs = Bs(cur) + (wn * TN) * BK;
         if constexpr (sizeof(T) == 2) {
             mfma_bf16x8 bf[NT], af[MT];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) {
-                const int row = i * 16 + lr;
-                bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + row * BK + swz_chunk<T>(row, lq) * 8);
-            }
+            for (int i = 0; i < NT; ++i)
+                bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + b_row<NT>(i, lr) * BK + swz_chunk<T>(lr, lq) * 8);
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
                 const int row = j * 16 + lr;
                 af[j] = *reinterpret_cast<const mfma_bf16x8*>(as + row * BK + swz_chunk<T>(row, lq) * 8);
             }
+            stamp(1);  // fragments in registers
             if constexpr (ABL == 2) {
 #pragma unroll
                 for (int i = 0; i < NT; ++i) asm volatile("" ::"v"(bf[i]));
@@ -455,10 +417,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
             for (int kk = 0; kk < BK / 4; ++kk) {
                 float bf[NT], af[MT];
 #pragma unroll
-                for (int i = 0; i < NT; ++i) {
-                    const int row = i * 16 + lr;
-                    bf[i] = bs[row * BK + swz_chunk<T>(row, kk) * 4 + lq];
-                }
+                for (int i = 0; i < NT; ++i) bf[i] = bs[b_row<NT>(i, lr) * BK + swz_chunk<T>(lr, kk) * 4 + lq];
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int row = j * 16 + lr;
@@ -471,10 +430,16 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
                         acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(bf[i], af[j], acc[i][j], 0, 0, 0);
             }
         }
+        stamp(2);      // MFMAs issued
+        if constexpr (ABL == 3) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        stamp(3);      // next tile arrived in registers
         if (has_next) store_tiles(cur ^ 1);
+        stamp(4);      // LDS writes drained
         __syncthreads();
+        stamp(5);      // barrier released
         cur ^= 1;
     }
+    const uint64_t t_end_loop = tprev;
 
     // Cut the accumulators' live ranges here: without it hipcc keeps the MFMA results un-tied through the
     // branchy epilogue and re-copies all 64 AGPRs (v_accvgpr_mov + s_nop) in EVERY K step (-35 % throughput).
@@ -482,7 +447,18 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
-    conv_finish<T, BN, NT, MT, (int)sizeof(T) * 2 * (BM + BN) * BK>(acc, a, m0, n0, wm, wn, lr, lq, smem);
+    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+    if constexpr (ABL == 3) {
+        uint64_t t_end;
+        asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
+        if (a.dbg != nullptr && lane == 0) {
+            float* o = a.dbg + ((int64_t)blockIdx.x * 4 + wave) * 8;
+#pragma unroll
+            for (int i = 0; i < 6; ++i) o[i] = (float)ph[i] / (float)KT;
+            o[6] = (float)(uint32_t)(t_loop - t_start);
+            o[7] = (float)(uint32_t)(t_end - t_end_loop);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -548,8 +524,9 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
     uint32_t b_off[B_I];
 #pragma unroll
     for (int jj = 0; jj < B_I; ++jj) {
-        const int n = n0 + (wave * B_I + jj) * 16 + prow;
-        b_off[jj] = n < a.N ? (uint32_t)(((int64_t)n * a.Ktot + lchunk * 8) * 2) : OOB;
+        const int row = (wave * B_I + jj) * 16 + prow, n = n0 + row;
+        const int bchunk = swz_chunk<T>(b_rho<NT>(row), lane & 3);      // weight rows: swizzle keyed on the MFMA row
+        b_off[jj] = n < a.N ? (uint32_t)(((int64_t)n * a.Ktot + bchunk * 8) * 2) : OOB;
     }
 
     int ir = 0, is = 0, ic0 = 0;       // filter tap / channel offset of the next tile to issue
@@ -611,10 +588,8 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
         const T* bs = smem + (kt % NST) * STAGE + BM * BK + (wn * TN) * BK;
         mfma_bf16x8 bf[NT], af[MT];
 #pragma unroll
-        for (int i = 0; i < NT; ++i) {
-            const int row = i * 16 + lr;
-            bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + row * BK + swz_chunk<T>(row, lq) * 8);
-        }
+        for (int i = 0; i < NT; ++i)
+            bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + b_row<NT>(i, lr) * BK + swz_chunk<T>(lr, lq) * 8);
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
             const int row = j * 16 + lr;
@@ -632,8 +607,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
-    __syncthreads();      // every wave is done reading the ring before it is reused for the output tile
-    conv_finish<T, BN, NT, MT, (int)sizeof(T) * NST * STAGE>(acc, a, m0, n0, wm, wn, lr, lq, smem);
+    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -926,7 +900,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if ((int64_t)d->B * d->Ho * d->Wo >= (1ll << 31)) return DML_EINVAL;
     if (d->stats && d->bias) return DML_EINVAL;
     ConvArgs a;
-    a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.stats = d->stats;
+    a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.stats = d->stats; a.dbg = nullptr;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
     a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
@@ -954,10 +928,12 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.nblk_m = (a.M + 127) / 128; a.nblk_n = (a.N + 127) / 128;
     a.div_wo = make_fastdiv((uint32_t)d->Wo); a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
+    a.dbg = const_cast<float*>(d->pre_scale);
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(a.nblk_m * a.nblk_n);
     if (abl == 0) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 0>), grid, dim3(NTHREADS), 0, st, a);
     else if (abl == 1) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 1>), grid, dim3(NTHREADS), 0, st, a);
+    else if (abl == 3) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 3>), grid, dim3(NTHREADS), 0, st, a);
     else hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 2>), grid, dim3(NTHREADS), 0, st, a);
     DML_LAUNCH_CHECK();
     return 0;

@@ -225,6 +225,41 @@ def test_pack_input(lib):
         assert (y[..., 3:] == 0).all()
 
 
+@pytest.mark.parametrize("Cc", [72, 256])
+def test_bn_finalize_many_groups(lib, Cc):
+    """G >= 2048 row groups takes the folded two-stage finalize (the 192x192 / 384x384 layers); compare with fp64
+    statistics, including a channel with |mean| >> std and a ragged last group."""
+    M = 64 * 2500 + 17
+    g = torch.Generator().manual_seed(5)
+    y = torch.randn(M, Cc, generator=g) * (torch.rand(Cc, generator=g) * 2 + 0.01) + torch.randn(Cc, generator=g) * 3
+    y[:, 1] = y[:, 1] * 1e-2 + 40.0
+    yd = y.cuda()
+    groups = (M + 63) // 64
+    part = torch.zeros(groups * Cc * 2, device="cuda")
+    chk(lib.dml_bn_stats(yd.data_ptr(), part.data_ptr(), M, Cc, Cc, 0, st()))
+    sc, sh, mu, inv = (torch.empty(Cc, device="cuda") for _ in range(4))
+    rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+    gam = (torch.rand(Cc, generator=g) + 0.5).cuda()
+    chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, gam.data_ptr(), None, rm.data_ptr(), rv.data_ptr(),
+                            0.1, 1e-5, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
+    torch.cuda.synchronize()
+    y64 = y.double()
+    mean, var = y64.mean(0), y64.var(0, unbiased=False)
+    rt = torch.full((Cc,), 5e-6, dtype=torch.float64)
+    rt[1] = 1e-3                      # fp32 group sums of a channel with mean/std ~ 1e4 carry ~1e-4 of its std
+
+    def close(got, ref, what):
+        bad = (got.cpu().double() - ref).abs() > rt * ref.abs() + 1e-12
+        assert not bad.any(), "%s: channels %s" % (what, bad.nonzero().flatten().tolist()[:8])
+
+    close(mu, mean, "mean")
+    close(inv, 1 / torch.sqrt(var + 1e-5), "invstd")
+    close(sc, gam.cpu().double() / torch.sqrt(var + 1e-5), "scale")
+    assert (sh == 0).all()
+    close(rm, 0.1 * mean, "running_mean")
+    close(rv, 0.9 + 0.1 * y64.var(0, unbiased=True), "running_var")
+
+
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
 @pytest.mark.parametrize("relu,res,drop", [(1, False, 0.0), (1, True, 0.0), (0, False, 0.0), (1, False, 0.25)])
 def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):

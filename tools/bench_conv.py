@@ -49,6 +49,26 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         for abl, nm in ((0, "full"), (1, "no-global/no-ldswrite"), (2, "no-mfma")):
             t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), abl, st))
             line += "%s %.1fus (%.0fTF-equiv) | " % (nm, t * 1e6, fl / t / 1e12)
+    if which == "phases":
+        import ctypes
+        lib.dml_debug_conv_ablate.restype = ctypes.c_int
+        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]
+        nblk = ((M + 127) // 128) * ((N + 127) // 128)
+        dbg = torch.zeros(nblk * 4 * 8, device="cuda")
+        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, pre_scale=dbg.data_ptr(),
+                     pre_shift=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil,
+                     pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
+        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), 3, st))
+        torch.cuda.synchronize()
+        full = dbg.view(nblk * 4, 8).cpu()
+        ph = full[:, :6]
+        names = ("ld-issue", "frag-read", "mfma", "vmcnt", "lds-write", "barrier")
+        line += "%.1fus %.0fTF; cycles per K-step (mean over %d waves, total %.0f): " % (t * 1e6, fl / t / 1e12, ph.shape[0], ph.sum(1).mean())
+        line += ", ".join("%s %.0f" % (n, v) for n, v in zip(names, ph.mean(0).tolist()))
+        line += " | p10/p90 total %.0f/%.0f" % (ph.sum(1).quantile(0.1), ph.sum(1).quantile(0.9))
+        line += " | prologue %.0f (p90 %.0f) epilogue %.0f (p90 %.0f) loop %.0f cycles" % (
+            full[:, 6].mean(), full[:, 6].quantile(0.9), full[:, 7].mean(), full[:, 7].quantile(0.9),
+            ph.sum(1).mean() * (k * k * Cc // 32))
     if which in ("all", "wgrad"):
         dw = torch.zeros(N, k, k, Cc, device="cuda")
         for sk in (0, 4, 8, 16, 32, 64):
