@@ -349,15 +349,30 @@ __global__ __launch_bounds__(256) void bn_finalize_folded_kernel(
     const float* __restrict__ partials, int64_t M, int N, int R, int NC, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* scale, float* shift, float* save_mean, float* save_invstd) {
-    const int n = blockIdx.x * 256 + threadIdx.x;
-    if (n >= N) return;
+    // 32 channels x 8 chunk lanes per block: the NC (<= 128) chunk sums are read 8 at a time
+    __shared__ double sh[3][8][32];
+    const int c = threadIdx.x & 31, cl = threadIdx.x >> 5;
+    const int n = blockIdx.x * 32 + c;
     const double* f = reinterpret_cast<const double*>(partials);
     double S = 0.0, Q = 0.0, P = 0.0;
-    for (int ck = 0; ck < NC; ++ck) {
-        const int64_t g0 = (int64_t)ck * R;
-        S += f[(g0 + 0) * N + n];
-        Q += f[(g0 + 1) * N + n];
-        P += f[(g0 + 2) * N + n];
+    if (n < N)
+        for (int ck = cl; ck < NC; ck += 8) {
+            const int64_t g0 = (int64_t)ck * R;
+            S += f[(g0 + 0) * N + n];
+            Q += f[(g0 + 1) * N + n];
+            P += f[(g0 + 2) * N + n];
+        }
+    sh[0][cl][c] = S;
+    sh[1][cl][c] = Q;
+    sh[2][cl][c] = P;
+    __syncthreads();
+    if (cl != 0 || n >= N) return;
+    S = Q = P = 0.0;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        S += sh[0][k][c];
+        Q += sh[1][k][c];
+        P += sh[2][k][c];
     }
     const double cnt = (double)M, mean = S / cnt;
     double m2 = Q + (P - S * mean);
@@ -395,7 +410,7 @@ extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, const float* g
         const int last_rows = (int)(M - (G - 1) * DML_STAT_ROWS);
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((N + 63) / 64, NC), dim3(256), 0, st, partials, G, N, R, NC,
                            last_rows);
-        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((N + 255) / 256), dim3(256), 0, st, partials, M, N, R, NC,
+        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((N + 31) / 32), dim3(256), 0, st, partials, M, N, R, NC,
                            gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     } else {
         hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, st, partials, M, N, gamma,

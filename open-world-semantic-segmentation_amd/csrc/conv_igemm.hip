@@ -34,6 +34,7 @@ struct ConvArgs {
     int nblk_n, nblk_m;
     FastDiv div_wo, div_howo, div_c;
     float* dbg;      // tuning builds only (ABL == 3): per-wave phase timings
+    uint32_t x_bytes, w_bytes;   // operand extents for the buffer descriptors (fast path: both < 2^31)
 };
 
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
@@ -249,12 +250,30 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     const T* __restrict__ Wt = static_cast<const T*>(a.w);
 
     const int kvec = tid % KV, prow = tid / KV;
+    constexpr int ES = (int)sizeof(T);
+    constexpr uint32_t OOB = 0x80000000u;          // beyond any descriptor: the load returns zeros
 
-    // per-thread A rows: pixel decomposition (loop invariant)
-    int a_iy[A_LD], a_ix[A_LD], a_img[A_LD];
+    // ---- operand addressing.
+    // ALIGNED (C % 32 == 0: a K tile never straddles a filter tap): everything per-thread is loop invariant -- a
+    // signed byte offset of the row's tap-(0,0) pixel, a bit per filter tap saying whether that tap lands inside
+    // the image (and, for the stride-2 data gradient, on an even position), and the weight row offset.  Per K step
+    // the tap / channel advance is SCALAR; padding and tile edges are an out-of-range buffer offset, so the loads
+    // are branch-free: 3 VALU per activation load, none per weight load.
+    // Otherwise (stem 7x7 with 8 channels, odd channel counts, > 32 taps, > 2 GiB tensors): generic 64-bit gather.
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    const int sh2 = (MODE == 1 && a.stride == 2) ? 1 : 0;
+
+    int a_iy[A_LD], a_ix[A_LD], a_img[A_LD];       // generic path: pixel decomposition
+    int a_base[A_LD];                               // fast path
+    uint32_t a_mask[A_LD], b_base[B_LD];
 #pragma unroll
     for (int j = 0; j < A_LD; ++j) {
         const int m = m0 + prow + j * RPP;
+        a_base[j] = 0;
+        a_mask[j] = 0;
         if (m < a.M) {
             const uint32_t b = fdiv((uint32_t)m, a.div_howo);
             const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
@@ -268,16 +287,62 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
                 a_ix[j] = (int)xo + a.pad;
             }
             a_img[j] = (int)b * a.Hi;
+            if constexpr (ALIGNED) {
+                const int by = MODE == 0 ? a_iy[j] : (a_iy[j] >> sh2), bx = MODE == 0 ? a_ix[j] : (a_ix[j] >> sh2);
+                a_base[j] = (((a_img[j] + by) * a.Wi + bx) * a.ldx + kvec * VEC) * ES;
+                uint32_t mk = 0;
+                for (int r = 0, t = 0; r < a.R; ++r)
+                    for (int q = 0; q < a.S; ++q, ++t) {
+                        bool ok;
+                        if (MODE == 0) {
+                            const int ys = a_iy[j] + r * a.dil, xs = a_ix[j] + q * a.dil;
+                            ok = ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+                        } else {
+                            const int ty = a_iy[j] - r * a.dil, tx = a_ix[j] - q * a.dil;
+                            ok = (sh2 == 0 || (((ty | tx) & 1) == 0)) && ty >= 0 && tx >= 0 &&
+                                 ((ty >> sh2) < a.Hi) && ((tx >> sh2) < a.Wi);
+                        }
+                        mk |= ok ? (1u << t) : 0u;
+                    }
+                a_mask[j] = mk;
+            }
         } else {
             a_iy[j] = -(1 << 28);
             a_ix[j] = -(1 << 28);
             a_img[j] = 0;
         }
     }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int row = prow + j * RPP, n = n0 + row;
+        b_base[j] = (row < BN && n < a.N) ? (uint32_t)((n * a.Ktot + kvec * VEC) * ES) : OOB;
+    }
+    // scalar byte offset of filter tap (r, q) relative to tap (0, 0)
+    auto tap_delta = [&](int r, int q) -> int {
+        if (MODE == 0) return ((r * a.dil) * a.Wi + q * a.dil) * a.ldx * ES;
+        return -((((r * a.dil) >> sh2) * a.Wi + ((q * a.dil) >> sh2)) * a.ldx) * ES;
+    };
 
     uint4 a_reg[A_LD], b_reg[B_LD];
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
     auto load_tiles = [&](int kt, int tap_r, int tap_s, int c0) {
+        if constexpr (ALIGNED) {
+            const uint32_t tapbit = 1u << (tap_r * a.S + tap_s);
+            const int soff = tap_delta(tap_r, tap_s) + c0 * ES;
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                const uint32_t voff = (a_mask[j] & tapbit) ? (uint32_t)(a_base[j] + soff) : OOB;
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
+                a_reg[j] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+#pragma unroll
+            for (int j = 0; j < B_LD; ++j) {
+                const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)b_base[j], kt * BK * ES, 0);
+                b_reg[j] = make_uint4(v.x, v.y, v.z, v.w);
+            }
+            return;
+        }
         // ---- A operand (gathered activations)
         int r = tap_r, s = tap_s, c = c0 + kvec * VEC;
         bool kvalid = true;
@@ -336,7 +401,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
 #pragma unroll
         for (int j = 0; j < B_LD; ++j) {
             const int row = prow + j * RPP;
-            if (row < BN)
+            if ((BN % RPP) == 0 || row < BN)
                 *reinterpret_cast<uint4*>(Bs(buf) + row * BK + swz_chunk<T>(b_rho<NT>(row), kvec) * VEC) = b_reg[j];
         }
     };
@@ -812,6 +877,193 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
         }
 }
 
+// ------------------------------------------------------------------------------------------------
+// bf16 weight gradient, large tile: 256 (n) x 256 (kc) per 512-thread workgroup, 8 waves as 2 (n) x 4 (kc), wave
+// tile 128 x 64 = 32 MFMAs per 32-pixel K step.  Why: the 128 x 128 kernel moves 16 KB through the CU's vector
+// memory pipeline (64 B/clk) and 48 KB through LDS per 64 MFMAs -- both as busy as the matrix cores, so none of
+// them gets past ~50 %; this tile halves both per MFMA.  One workgroup per CU; split-K over pixel slabs sized so
+// that the grid is a multiple of the CU count.  Same LDS image as conv_wgrad_kernel (16-column sub-tiles read with
+// ds_read_b64_tr_b16); the x fragment is the MFMA row operand here, so a lane ends up with 4 consecutive kc of
+// one n and the split-K slab is written with 16-byte stores.  Operand tiles are written to LDS one K step ahead,
+// right after the barrier (one register set, loads for step t+2 re-issued immediately).
+// Addressing: buffer loads, 32-bit offsets advanced incrementally; tile edges and padding are out-of-range offsets.
+// ------------------------------------------------------------------------------------------------
+constexpr int WB_THREADS = 512;
+constexpr int WB_SUB = 528;                 // elements per 16-column sub-tile (32 k rows x 16 + pad)
+constexpr int WB_OP = 16 * WB_SUB;          // one operand, one stage (256 columns)
+
+__global__ __launch_bounds__(WB_THREADS) void conv_wgrad_big_kernel(const WgradArgs a, const uint32_t x_bytes,
+                                                                    const uint32_t dy_bytes) {
+    typedef bf16_t T;
+    constexpr int TILE = 256, VEC = 8, RPP = 16, LD = 2;
+    constexpr int NT = 8, MT = 4;                 // wave tile: 8 n-tiles x 4 kc-tiles of 16
+    constexpr uint32_t OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * 2 * WB_OP];
+    auto Ys = [&](int buf) -> T* { return smem + buf * 2 * WB_OP; };
+    auto Xs = [&](int buf) -> T* { return smem + buf * 2 * WB_OP + WB_OP; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 2, wk = wave & 3;
+    const int ntile = a.nblk_n * a.nblk_k;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntile, tile_id = logical - split * ntile;
+    const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
+    const int n0 = blk_n * TILE, kc0 = blk_k * TILE;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)dy_bytes, 0x00020000);
+
+    const int vcol = tid & 31, prow = tid >> 5;
+    const int kc = kc0 + vcol * VEC;
+    const bool kc_ok = kc < a.Ktot;
+    const uint32_t tap = fdiv((uint32_t)(kc_ok ? kc : 0), a.div_c);
+    const int xc = (kc_ok ? kc : 0) - (int)tap * a.C;
+    const int tr = (int)tap / a.S, ts = (int)tap - tr * a.S;
+    const int dyo = tr * a.dil - a.pad, dxo = ts * a.dil - a.pad;
+    const int yn = n0 + vcol * VEC;
+    const bool yn_ok = yn < a.N;
+
+    const int tile_beg = split * a.slab_tiles;
+    const int tiles_total = (a.M + BK - 1) / BK;
+    const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
+    const bool lin1x1 = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
+
+    // incremental per-row state: rows m = t*32 + prow + 16 j.  Rows past M need no test: their offsets fall
+    // beyond the descriptors (dy: m*ldy >= M*ldy; x: image index >= B).
+    uint32_t yoff[LD], xoff[LD];
+    int px_b[LD], px_y[LD], px_x[LD];             // b*Hi, yo, xo of the general gather
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+        const int m = tile_beg * BK + prow + j * RPP;
+        yoff[j] = yn_ok ? (uint32_t)((m * a.ldy + yn) * 2) : OOB;
+        xoff[j] = kc_ok ? (uint32_t)((m * a.ldx + xc) * 2) : OOB;          // 1x1 stride 1: source pixel = m
+        const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+        const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+        const uint32_t yo = fdiv(rem, a.div_wo);
+        px_b[j] = (int)b * a.Hi;
+        px_y[j] = (int)yo;
+        px_x[j] = (int)(rem - yo * (uint32_t)a.Wo);
+    }
+    const uint32_t ystep = (uint32_t)(BK * a.ldy * 2), xstep = (uint32_t)(BK * a.ldx * 2);
+
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    uint4 y_reg[LD], x_reg[LD];
+    // loads the NEXT tile in sequence (call once per K step, in order)
+    auto load_next = [&]() {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const u32x4_t yv = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)yoff[j], 0, 0);
+            yoff[j] += ystep;
+            uint32_t vo;
+            if (lin1x1) {
+                vo = xoff[j];
+                xoff[j] += xstep;
+            } else {
+                const int ys = px_y[j] * a.stride + dyo, xs = px_x[j] * a.stride + dxo;
+                const bool ok = kc_ok && ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+                const uint32_t pix = __umul24((uint32_t)(px_b[j] + ys), (uint32_t)a.Wi) + (uint32_t)xs;
+                vo = ok ? (__umul24(pix, (uint32_t)(a.ldx * 2)) + (uint32_t)(xc * 2)) : OOB;
+                px_x[j] += BK;
+                while (px_x[j] >= a.Wo) {
+                    px_x[j] -= a.Wo;
+                    if (++px_y[j] == a.Ho) {
+                        px_y[j] = 0;
+                        px_b[j] += a.Hi;
+                    }
+                }
+            }
+            const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, 0, 0);
+            y_reg[j] = make_uint4(yv.x, yv.y, yv.z, yv.w);
+            x_reg[j] = make_uint4(xv.x, xv.y, xv.z, xv.w);
+        }
+    };
+    auto store_tiles = [&](int buf) {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int row = prow + j * RPP;
+            // 16-column sub-tiles [col/16][k'][16] (1056-byte pitch), k rows stored with bits 2/3 swapped:
+            // conflict-free for ds_read_b64_tr_b16 and for these 16-byte writes
+            const int prow_ = (row & 0x13) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 3);
+            const int off = (vcol >> 1) * WB_SUB + prow_ * 16 + (vcol & 1) * 8;
+            *reinterpret_cast<uint4*>(Ys(buf) + off) = y_reg[j];
+            *reinterpret_cast<uint4*>(Xs(buf) + off) = x_reg[j];
+        }
+    };
+
+    f32x4 acc[MT][NT];
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (tile_beg < tile_end) {
+        load_next();
+        store_tiles(0);
+        if (tile_beg + 1 < tile_end) load_next();
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, lq = lane >> 4;
+    // k rows 8*lq + (lr>>2) (+8 for the second read) at their swapped positions inside a sub-tile
+    const int p_lo = ((lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4)) * 16 + (lr & 3) * 4;
+    const int p_hi = p_lo + 8 * 16;
+    int cur = 0;
+    for (int t = tile_beg; t < tile_end; ++t) {
+        const T* ys = Ys(cur) + wn * 8 * WB_SUB;
+        const T* xs = Xs(cur) + wk * 4 * WB_SUB;
+        mfma_bf16x8 yf[NT], xf[MT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const bf16x4 lo = lds_tr16_b64(xs + j * WB_SUB + p_lo);
+            const bf16x4 hi = lds_tr16_b64(xs + j * WB_SUB + p_hi);
+            bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            xf[j] = __builtin_bit_cast(mfma_bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const bf16x4 lo = lds_tr16_b64(ys + i * WB_SUB + p_lo);
+            const bf16x4 hi = lds_tr16_b64(ys + i * WB_SUB + p_hi);
+            bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            yf[i] = __builtin_bit_cast(mfma_bf16x8, v);
+        }
+        if (t + 1 < tile_end) {
+            store_tiles(cur ^ 1);                 // tile t+1 (in registers since the previous step)
+            if (t + 2 < tile_end) load_next();    // tile t+2
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j)
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[j][i], 0, 0, 0);
+        __syncthreads();
+        cur ^= 1;
+    }
+#pragma unroll
+    for (int j = 0; j < MT; ++j)
+#pragma unroll
+        for (int i = 0; i < NT; ++i) asm volatile("" : "+v"(acc[j][i]));
+
+    // acc[j][i][q] = dw[n = n0 + wn*128 + i*16 + lr][kc = kc0 + wk*64 + j*16 + lq*4 + q]
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        const int n = n0 + wn * 128 + i * 16 + lr;
+        if (n >= a.N) continue;
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const int k = kc0 + wk * 64 + j * 16 + lq * 4;
+            if (k >= a.Ktot) continue;            // Ktot is a multiple of 8: whole vectors
+            if (a.ws != nullptr) {
+                *reinterpret_cast<float4*>(a.ws + ((int64_t)split * a.N + n) * a.Ktot + k) =
+                    make_float4(acc[j][i][0], acc[j][i][1], acc[j][i][2], acc[j][i][3]);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) atomicAdd(a.dw + (int64_t)n * a.Ktot + k + q, acc[j][i][q]);
+            }
+        }
+    }
+}
+
 // dw[n][rs][c < Cm] += sum_s ws[s][n][rs][c]   (fp32 atomics on the L2 are ~10x more expensive per byte than this)
 // blockIdx.y walks chunks of 16 splits so that a small weight tensor with hundreds of splits stays parallel.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
@@ -836,7 +1088,12 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
 template <typename T, int MODE>
 int launch_conv(const ConvArgs& base, hipStream_t st) {
     ConvArgs a = base;
-    const bool aligned = (a.C % BK) == 0;
+    const int64_t xb64 = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * (int64_t)sizeof(T);
+    const int64_t wb64 = (int64_t)a.N * a.Ktot * (int64_t)sizeof(T);
+    const bool small = xb64 < (1ll << 31) && wb64 < (1ll << 31);
+    a.x_bytes = small ? (uint32_t)xb64 : 0u;
+    a.w_bytes = small ? (uint32_t)wb64 : 0u;
+    const bool aligned = (a.C % BK) == 0 && a.R * a.S <= 32 && small;
     a.nblk_m = (a.M + 127) / 128;
     if constexpr (sizeof(T) == 2) {
         // LDS-DMA kernel: bf16, K tiles inside one tap, tensors addressable with a 31-bit byte offset
@@ -929,6 +1186,8 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.div_wo = make_fastdiv((uint32_t)d->Wo); a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
     a.dbg = const_cast<float*>(d->pre_scale);
+    a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
+    a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(a.nblk_m * a.nblk_n);
     if (abl == 0) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 0>), grid, dim3(NTHREADS), 0, st, a);
@@ -980,11 +1239,57 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     }
     if (use_ws && (int64_t)splitk * plane > d->ws_elems) splitk = (int)(d->ws_elems / plane);
     if (use_ws && splitk < 1) return DML_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    // large-tile kernel: bf16, whole 256-channel output tiles, everything addressable with 31-bit byte offsets and
+    // 24-bit pixel indices.  Measured (tools/bench_conv.py wgrad, incl. the reduce pass, vs the 128 x 128 kernel):
+    // decoder 3x3 320->256 @192^2 970 vs 727 TFLOP/s, 3x3 512->512 d2 879 vs 669, ASPP 3x3 2048->256 857 vs 693,
+    // layer3 3x3 256->256 569 vs 500.  With fewer than 6 output tiles (the 1x1 256<->1024 layers) filling 256 CUs
+    // takes 64 splits and the slab traffic makes it a few % slower than the small-tile kernel, which keeps those.
+    static const bool wg_v1 = getenv("DML_WGRAD_V1") != nullptr;
+    const int64_t xb64 = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2;
+    const int64_t yb64 = (((int64_t)a.M - 1) * a.ldy + a.N) * 2;
+    if (!wg_v1 && d->dtype == DML_BF16 && use_ws && a.N % 256 == 0 && (a.N / 256) * ((a.Ktot + 255) / 256) >= 6 &&
+        tiles >= 16 &&
+        xb64 < (1ll << 31) && yb64 < (1ll << 31) && (int64_t)(a.B + 1) * a.Hi * a.Wi < (1 << 24) && a.M < (1 << 24) &&
+        a.ldx < (1 << 22) && a.ldy < (1 << 22)) {
+        a.nblk_n = a.N / 256;
+        a.nblk_k = (a.Ktot + 255) / 256;
+        const int base = a.nblk_n * a.nblk_k;
+        int sk = d->splitk;
+        if (sk <= 0) {
+            // one workgroup per CU: pick the split count that fills whole rounds of 256 workgroups best, fewest
+            // splits on ties (less slab traffic); at least 8 K steps per workgroup
+            int smax = tiles / 8;
+            if (smax > 256) smax = 256;
+            if ((int64_t)smax * plane > d->ws_elems) smax = (int)(d->ws_elems / plane);
+            if (smax < 1) smax = 1;
+            double best = -1.0;
+            sk = 1;
+            for (int c = 1; c <= smax; ++c) {
+                const int slab = (tiles + c - 1) / c;
+                const int real = (tiles + slab - 1) / slab;
+                const int blocks = base * real;
+                const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+                if (eff > best + 1e-9) { best = eff; sk = real; }
+            }
+        }
+        if ((int64_t)sk * plane > d->ws_elems) sk = (int)(d->ws_elems / plane);
+        if (sk < 1) return DML_EINVAL;
+        if (sk > tiles) sk = tiles;
+        a.ws = d->ws;
+        a.slab_tiles = (tiles + sk - 1) / sk;
+        sk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
+        hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
+        const int64_t nrs = (int64_t)a.N * a.R * a.S;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), 1), dim3(256), 0, st, d->ws, d->dw, sk, nrs,
+                           cm, d->C);
+        DML_LAUNCH_CHECK();
+        return 0;
+    }
     a.ws = use_ws ? d->ws : nullptr;
     if (splitk > tiles) splitk = tiles > 0 ? tiles : 1;
     a.slab_tiles = (tiles + splitk - 1) / splitk;
     splitk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
-    hipStream_t st = static_cast<hipStream_t>(stream);
     dim3 grid(a.nblk_n * a.nblk_k * splitk);
     if (d->dtype == DML_BF16)
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);

@@ -166,6 +166,42 @@ def test_conv_fwd_dgrad_wgrad(lib, case, dname):
         relclose(dwc.cpu().permute(0, 3, 1, 2), w.grad[:, :cm], tol if dname == "f32" else 2e-3, "conv wgrad Cm " + name)
 
 
+WGRAD_BIG_CASES = [
+    # name, B, H, W, Cin, Cout, k, stride, dil, Cm
+    ("3x3_d2", 2, 20, 24, 64, 256, 3, 1, 2, 0),
+    ("1x1", 3, 16, 18, 1024, 512, 1, 1, 1, 0),
+    ("3x3_s2", 2, 40, 36, 96, 256, 3, 2, 1, 0),
+    ("3x3_c320_cm304", 1, 24, 24, 320, 256, 3, 1, 1, 304),
+    ("3x3_w7", 5, 16, 7, 64, 256, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", WGRAD_BIG_CASES, ids=[c[0] for c in WGRAD_BIG_CASES])
+def test_conv_wgrad_large_tile(lib, case):
+    """bf16 weight gradient through the 256 x 256 tile kernel (N % 256 == 0, >= 16 pixel slabs, workspace given):
+    partial last kc tile, stride 2, rows narrower than a 32-pixel slab, ragged last slab, dropped pad channels."""
+    from dmlnet._lib import WgradDesc
+    name, B, Hh, Ww, Cin, Cout, k, stride, dil, Cm = case
+    x = qz(rnd("wgb.x" + name, (B, Cin, Hh, Ww)), torch.bfloat16)
+    w = qz(rnd("wgb.w" + name, (Cout, Cin, k, k), scale=0.05), torch.bfloat16).requires_grad_(True)
+    y, pad = conv_ref(x, w, k, stride, dil)
+    Ho, Wo = y.shape[2], y.shape[3]
+    gy = qz(rnd("wgb.gy" + name, tuple(y.shape)), torch.bfloat16)
+    (y * gy).sum().backward()
+    xd, gyd = nhwc(x, torch.bfloat16), nhwc(gy, torch.bfloat16)
+    cm = Cm or Cin
+    dw = torch.full((Cout, k, k, cm), 1.0, device="cuda")
+    ws = torch.empty(30 * Cout * k * k * Cin, device="cuda")
+    for sk in (0, 5):
+        dw.fill_(1.0)
+        wg = WgradDesc(x=xd.data_ptr(), dy=gyd.data_ptr(), dw=dw.data_ptr(), B=B, Hi=Hh, Wi=Ww, C=Cin, ldx=Cin, Ho=Ho,
+                       Wo=Wo, N=Cout, ldy=Cout, R=k, S=k, stride=stride, dil=dil, pad=pad, dtype=1, splitk=sk, Cm=Cm,
+                       ws=ws.data_ptr(), ws_elems=ws.numel())
+        chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+        torch.cuda.synchronize()
+        relclose(dw.cpu().permute(0, 3, 1, 2) - 1.0, w.grad[:, :cm], 2e-3, "wgrad large tile %s splitk=%d" % (name, sk))
+
+
 def test_conv_bias_f32_out_and_slices(lib):
     """Final 1x1 with bias writing fp32 from bf16 operands; producer writing into a concat-buffer slice."""
     B, Hh, Ww, Cin, K = 2, 6, 5, 256, 16
