@@ -4,6 +4,7 @@
 // Replaces nn.BatchNorm2d (112 instances: network/backbone/resnet.py:84-92,140,181; network/utils.py:13,21,
 // 313,323,339,352), the ReLU / residual add at resnet.py:96-113 and nn.Dropout at network/utils.py:354.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -167,6 +168,94 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(
     }
 }
 
+// Column-stationary variant: a thread keeps one 16-byte channel vector (its scale / shift / mean live in registers,
+// no per-element division) and walks rows, U rows per trip with all loads issued before the first use, so that a CU
+// has U x 32 KB of HBM reads in flight instead of 32 KB.
+template <typename T, int U>
+__global__ __launch_bounds__(256) void bn_apply_cols_kernel(
+    const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
+    const float* __restrict__ shift, const float* __restrict__ mean, uint8_t* __restrict__ mask, int64_t M, int N,
+    int ldy, int ldres, int ldz, int relu, float drop_p, uint64_t drop_seed, int CB, int RB, int rows_per_block) {
+    constexpr int V = Vec16<T>::N;
+    const int NV = N / V;
+    const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
+    const int vcol = blockIdx.y * CB + col;
+    if (rl >= RB || vcol >= NV) return;
+    const int c = vcol * V;
+    float sc[V], sh[V], mu[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { sc[q] = scale[c + q]; sh[q] = shift[c + q]; mu[q] = mean[c + q]; }
+    const uint32_t thresh = drop_p > 0.f ? (uint32_t)min(4294967295.0, (double)drop_p * 4294967296.0) : 0u;
+    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)RB * U) {
+        float v[U][V], r[U][V];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            if (m < r1) {
+                Vec16<T>::load(y + m * ldy + c, v[u]);
+                if (res != nullptr) Vec16<T>::load(res + m * ldres + c, r[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            if (m >= r1) continue;
+#pragma unroll
+            for (int q = 0; q < V; ++q) v[u][q] = (v[u][q] - mu[q]) * sc[q] + sh[q];
+            if (res != nullptr) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) v[u][q] += r[u][q];
+            }
+            if (relu) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) v[u][q] = v[u][q] > 0.f ? v[u][q] : 0.f;
+            }
+            if (drop_p > 0.f) {
+#pragma unroll
+                for (int q = 0; q < V; ++q)
+                    v[u][q] = drop_keep(drop_seed, (uint64_t)m * N + c + q, thresh) ? v[u][q] * keep_scale : 0.f;
+            }
+            Vec16<T>::store(z + m * ldz + c, v[u]);
+            if (V == 8 && mask != nullptr) {
+                uint32_t bits = 0;
+#pragma unroll
+                for (int q = 0; q < V; ++q) bits |= (v[u][q] > 0.f ? 1u : 0u) << q;
+                mask[m * NV + vcol] = (uint8_t)bits;
+            }
+        }
+    }
+}
+
+// geometry shared by the column-stationary kernels: CB vector columns x RB row lanes per 256-thread block
+struct ColGeom { int CB, RB, col_chunks, rows_per_block, row_blocks; };
+static ColGeom col_geom(int64_t M, int NV, int U, int target_blocks) {
+    ColGeom g;
+    g.CB = NV < 256 ? NV : 256;
+    g.RB = 256 / g.CB;
+    g.col_chunks = (NV + g.CB - 1) / g.CB;
+    const int64_t step = (int64_t)g.RB * U;
+    int64_t rpb = (M * g.col_chunks + target_blocks - 1) / target_blocks;
+    rpb = ((rpb + step - 1) / step) * step;
+    if (rpb < step) rpb = step;
+    g.rows_per_block = (int)rpb;
+    g.row_blocks = (int)((M + rpb - 1) / rpb);
+    return g;
+}
+// Workgroups for a streaming pass over an M x N tensor: ~16 KB of the tensor per workgroup (two trips of U = 2 rows
+// per row lane).  Measured with tools/bench_bn.py on MI355X: short-lived workgroups that sweep the tensor front to
+// back beat 2048 persistent grid-stride workgroups by 15-30 % (4.3 -> 5.1-5.7 TB/s on the >= 75 MB tensors);
+// the small layer3 tensors (19 MB) prefer ~1024.
+static int stream_blocks(int64_t M, int N, int dtype) {
+    const int64_t bytes = M * N * (dtype == DML_BF16 ? 2 : 4);
+    int64_t b = bytes / 16384;
+    if (b < 1024) b = 1024;
+    if (b > 32768) b = 32768;
+    return (int)b;
+}
+
 // ---------------------------------------------------------------------------------- backward
 // pass 1: partials[rb][n] = (sum g, sum g * xhat),  g = dz * [z > 0] * gscale
 constexpr int RED_COLS = 64;   // vector columns per block
@@ -191,27 +280,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         for (int q = 0; q < V; ++q) { mu[q] = save_mean[c + q]; is[q] = save_invstd[c + q]; }
         const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
         const int64_t r1 = min(M, r0 + rows_per_block);
-        for (int64_t m = r0 + rl; m < r1; m += rt) {
-            float g[V], yy[V];
-            Vec16<T>::load(dz + m * lddz + c, g);
-            Vec16<T>::load(y + m * ldy + c, yy);
-            if (relu) {
-                if (V == 8 && mask != nullptr) {
-                    const uint32_t bits = mask[m * NV + v];
+        constexpr int U = 2;                  // rows in flight per thread
+        const bool use_mask = V == 8 && mask != nullptr;
+        for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)rt * U) {
+            float g[U][V], yy[U][V], zz[U][V];
+            uint32_t bits[U];
 #pragma unroll
-                    for (int q = 0; q < V; ++q) g[q] = (bits >> q) & 1u ? g[q] : 0.f;
-                } else {
-                    float zz[V];
-                    Vec16<T>::load(z + m * ldz + c, zz);
-#pragma unroll
-                    for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = m0 + (int64_t)u * rt;
+                if (m < r1) {
+                    Vec16<T>::load(dz + m * lddz + c, g[u]);
+                    Vec16<T>::load(y + m * ldy + c, yy[u]);
+                    if (relu) {
+                        if (use_mask) bits[u] = mask[m * NV + v];
+                        else Vec16<T>::load(z + m * ldz + c, zz[u]);
+                    }
                 }
             }
 #pragma unroll
-            for (int q = 0; q < V; ++q) {
-                const float gg = g[q] * gscale;
-                sg[q] += gg;
-                sgx[q] += gg * (yy[q] - mu[q]) * is[q];
+            for (int u = 0; u < U; ++u) {
+                const int64_t m = m0 + (int64_t)u * rt;
+                if (m >= r1) continue;
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    const bool on = !relu || (use_mask ? ((bits[u] >> q) & 1u) != 0 : zz[u][q] > 0.f);
+                    const float gg = on ? g[u][q] * gscale : 0.f;
+                    sg[q] += gg;
+                    sgx[q] += gg * (yy[u][q] - mu[q]) * is[q];
+                }
             }
         }
     }
@@ -309,6 +405,69 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
                 for (int q = 0; q < V; ++q) g[q] += r[q];
             }
             Vec16<T>::store(dres + (int64_t)m * lddres + c, g);
+        }
+    }
+}
+
+// column-stationary backward apply (see bn_apply_cols_kernel): coefficients in registers, U rows in flight
+template <typename T, int U>
+__global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
+    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const uint8_t* __restrict__ mask,
+    const float* __restrict__ coef, T* __restrict__ dy, T* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy,
+    int lddres, int relu, float gscale, int dres_accum, int CB, int RB, int rows_per_block) {
+    constexpr int V = Vec16<T>::N;
+    const int NV = N / V;
+    const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
+    const int vcol = blockIdx.y * CB + col;
+    if (rl >= RB || vcol >= NV) return;
+    const int c = vcol * V;
+    float cA[V], cB[V], cC[V], cM[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        cA[q] = coef[c + q] * gscale;
+        cB[q] = coef[N + c + q];
+        cC[q] = coef[2 * N + c + q];
+        cM[q] = coef[3 * N + c + q];
+    }
+    const bool use_mask = V == 8 && mask != nullptr;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)RB * U) {
+        float g[U][V], yy[U][V], zz[U][V], rr[U][V];
+        uint32_t bits[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            if (m < r1) {
+                Vec16<T>::load(dz + m * lddz + c, g[u]);
+                Vec16<T>::load(y + m * ldy + c, yy[u]);
+                if (relu) {
+                    if (use_mask) bits[u] = mask[m * NV + vcol];
+                    else Vec16<T>::load(z + m * ldz + c, zz[u]);
+                }
+                if (dres != nullptr && dres_accum) Vec16<T>::load(dres + m * lddres + c, rr[u]);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            if (m >= r1) continue;
+            if (relu) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) {
+                    const bool on = use_mask ? ((bits[u] >> q) & 1u) != 0 : zz[u][q] > 0.f;
+                    g[u][q] = on ? g[u][q] : 0.f;
+                }
+            }
+            float o[V];
+#pragma unroll
+            for (int q = 0; q < V; ++q) o[q] = cA[q] * g[u][q] + cB[q] * (yy[u][q] - cM[q]) + cC[q];
+            Vec16<T>::store(dy + m * lddy + c, o);
+            if (dres != nullptr) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) g[u][q] = g[u][q] * gscale + (dres_accum ? rr[u][q] : 0.f);
+                Vec16<T>::store(dres + m * lddres + c, g[u]);
+            }
         }
     }
 }
@@ -451,17 +610,17 @@ extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float
         return DML_EALIGN;
     if (M >= (1ll << 31)) return DML_EINVAL;
     const int V = dtype == DML_BF16 ? 8 : 4;
-    const FastDiv dv = make_fastdiv((uint32_t)(N / V));
-    const int grid = grid_for(M * (N / V), 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype));
+    dim3 grid(g.row_blocks, g.col_chunks);
     if (dtype == DML_BF16)
-        hipLaunchKernelGGL(bn_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)y,
-                           (const bf16_t*)res, (bf16_t*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p,
-                           drop_seed, dv);
+        hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)y, (const bf16_t*)res,
+                           (bf16_t*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
+                           g.rows_per_block);
     else
-        hipLaunchKernelGGL(bn_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)y,
-                           (const float*)res, (float*)z, scale, shift, mean, nullptr, M, N, ldy, ldres, ldz, relu, drop_p,
-                           drop_seed, dv);
+        hipLaunchKernelGGL((bn_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)y, (const float*)res,
+                           (float*)z, scale, shift, mean, nullptr, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
+                           g.rows_per_block);
     DML_LAUNCH_CHECK();
     return 0;
 }
@@ -520,17 +679,17 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
         return DML_EALIGN;
     if (M >= (1ll << 31)) return DML_EINVAL;
     const int V = dtype == DML_BF16 ? 8 : 4;
-    const FastDiv dv = make_fastdiv((uint32_t)(N / V));
-    const int grid = grid_for(M * (N / V), 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype));
+    dim3 grid(g.row_blocks, g.col_chunks);
     if (dtype == DML_BF16)
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dz,
+        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)dz,
                            (const bf16_t*)y, (const bf16_t*)z, mask, coef, (bf16_t*)dy, (bf16_t*)dres, M, N, lddz, ldy,
-                           ldz, lddy, lddres, relu, gscale, dres_accum, dv);
+                           ldz, lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block);
     else
-        hipLaunchKernelGGL(bn_bwd_apply_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dz,
+        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)dz,
                            (const float*)y, (const float*)z, nullptr, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
-                           lddy, lddres, relu, gscale, dres_accum, dv);
+                           lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block);
     DML_LAUNCH_CHECK();
     return 0;
 }
