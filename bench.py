@@ -270,9 +270,19 @@ def main():
         conv_sec = tsec["igemm"] + tsec["wgrad"]
         n_launch = counts["igemm"] + counts["wgrad"]
         peak = PEAK[args.dtype]
+        # HBM bytes per conv launch from the committed PMC passes of this same command (tools/run_traffic.sh:
+        # separate --pmc FETCH_SIZE / WRITE_SIZE runs, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024); null when absent
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
+        if os.path.exists(tpath) and args.batch == 16 and args.size == 768 and args.dtype == "bf16":
+            with open(tpath) as fh:
+                tj = json.load(fh)
+            traffic = tj["conv_GB_per_step"] * 1e9 / tj["conv_launches_per_step"]
+            traffic_src = "profiles/r01_traffic_pmc.json (rocprofv3 --pmc, %.1f GB per step over the conv launches)" % tj["conv_GB_per_step"]
         out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (all conv launches of a step)",
                            "achieved": flops / conv_sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                           "frac": flops / conv_sec / peak, "traffic": None,
+                           "frac": flops / conv_sec / peak, "traffic": traffic, "traffic_unit": "bytes per launch (mean)",
+                           "traffic_source": traffic_src,
                            "flops_per_step": flops, "launches_per_step": n_launch,
                            "avg_launch_ms": conv_sec / n_launch * 1e3, "conv_ms_per_step": conv_sec * 1e3,
                            "igemm_ms_per_step": tsec["igemm"] * 1e3, "wgrad_ms_per_step": tsec["wgrad"] * 1e3,

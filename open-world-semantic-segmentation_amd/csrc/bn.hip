@@ -114,60 +114,6 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
     return (uint32_t)(h >> 32) >= thresh;
 }
 
-template <typename T>
-__global__ __launch_bounds__(256) void bn_apply_kernel(
-    const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
-    const float* __restrict__ shift, const float* __restrict__ mean, uint8_t* __restrict__ mask, int64_t M, int N,
-    int ldy, int ldres, int ldz, int relu, float drop_p, uint64_t drop_seed, FastDiv div_nv) {
-    constexpr int V = Vec16<T>::N;
-    const int NV = N / V;
-    const int64_t total = M * NV;
-    const uint32_t thresh = drop_p > 0.f ? (uint32_t)min(4294967295.0, (double)drop_p * 4294967296.0) : 0u;
-    const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t m = fdiv((uint32_t)i, div_nv);
-        const int c = ((int)((uint32_t)i - m * (uint32_t)NV)) * V;
-        float v[V], sc[V], sh[V], mu[V];
-        Vec16<T>::load(y + (int64_t)m * ldy + c, v);
-#pragma unroll
-        for (int q = 0; q < V; q += 4) {
-            const float4 a = *reinterpret_cast<const float4*>(scale + c + q);
-            const float4 b = *reinterpret_cast<const float4*>(shift + c + q);
-            const float4 d = *reinterpret_cast<const float4*>(mean + c + q);
-            sc[q] = a.x; sc[q + 1] = a.y; sc[q + 2] = a.z; sc[q + 3] = a.w;
-            sh[q] = b.x; sh[q + 1] = b.y; sh[q + 2] = b.z; sh[q + 3] = b.w;
-            mu[q] = d.x; mu[q + 1] = d.y; mu[q + 2] = d.z; mu[q + 3] = d.w;
-        }
-        // (y - mean) first: no cancellation between y*scale and mean*scale for low-variance channels
-#pragma unroll
-        for (int q = 0; q < V; ++q) v[q] = (v[q] - mu[q]) * sc[q] + sh[q];
-        if (res != nullptr) {
-            float r[V];
-            Vec16<T>::load(res + (int64_t)m * ldres + c, r);
-#pragma unroll
-            for (int q = 0; q < V; ++q) v[q] += r[q];
-        }
-        if (relu) {
-#pragma unroll
-            for (int q = 0; q < V; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
-        }
-        if (drop_p > 0.f) {
-#pragma unroll
-            for (int q = 0; q < V; ++q)
-                v[q] = drop_keep(drop_seed, (uint64_t)m * N + c + q, thresh) ? v[q] * keep_scale : 0.f;
-        }
-        Vec16<T>::store(z + (int64_t)m * ldz + c, v);
-        if (V == 8 && mask != nullptr) {
-            // one bit per element (z > 0): the backward passes read this byte instead of 16 bytes of z
-            uint32_t bits = 0;
-#pragma unroll
-            for (int q = 0; q < V; ++q) bits |= (v[q] > 0.f ? 1u : 0u) << q;
-            mask[i] = (uint8_t)bits;
-        }
-    }
-}
-
 // Column-stationary variant: a thread keeps one 16-byte channel vector (its scale / shift / mean live in registers,
 // no per-element division) and walks rows, U rows per trip with all loads issued before the first use, so that a CU
 // has U x 32 KB of HBM reads in flight instead of 32 KB.
@@ -361,51 +307,6 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
         coef[n] = (float)A; coef[N + n] = (float)Bc; coef[2 * N + n] = (float)C0; coef[3 * N + n] = (float)mu;
         if (dgamma) dgamma[n] += (float)dgamma_s;
         if (dbeta) dbeta[n] += (float)dbeta_s;
-    }
-}
-
-template <typename T>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(
-    const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const uint8_t* __restrict__ mask,
-    const float* __restrict__ coef, T* __restrict__ dy, T* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy,
-    int lddres, int relu, float gscale, int dres_accum, FastDiv div_nv) {
-    constexpr int V = Vec16<T>::N;
-    const int NV = N / V;
-    const int64_t total = M * NV;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
-         i += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t m = fdiv((uint32_t)i, div_nv);
-        const int c = ((int)((uint32_t)i - m * (uint32_t)NV)) * V;
-        float g[V], yy[V], o[V];
-        Vec16<T>::load(dz + (int64_t)m * lddz + c, g);
-        Vec16<T>::load(y + (int64_t)m * ldy + c, yy);
-        if (relu) {
-            if (V == 8 && mask != nullptr) {
-                const uint32_t bits = mask[i];
-#pragma unroll
-                for (int q = 0; q < V; ++q) g[q] = (bits >> q) & 1u ? g[q] : 0.f;
-            } else {
-                float zz[V];
-                Vec16<T>::load(z + (int64_t)m * ldz + c, zz);
-#pragma unroll
-                for (int q = 0; q < V; ++q) g[q] = zz[q] > 0.f ? g[q] : 0.f;
-            }
-        }
-#pragma unroll
-        for (int q = 0; q < V; ++q) {
-            g[q] *= gscale;
-            o[q] = coef[c + q] * g[q] + coef[N + c + q] * (yy[q] - coef[3 * N + c + q]) + coef[2 * N + c + q];
-        }
-        Vec16<T>::store(dy + (int64_t)m * lddy + c, o);
-        if (dres != nullptr) {
-            if (dres_accum) {
-                float r[V];
-                Vec16<T>::load(dres + (int64_t)m * lddres + c, r);
-#pragma unroll
-                for (int q = 0; q < V; ++q) g[q] += r[q];
-            }
-            Vec16<T>::store(dres + (int64_t)m * lddres + c, g);
-        }
     }
 }
 
