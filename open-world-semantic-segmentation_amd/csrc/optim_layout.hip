@@ -122,6 +122,38 @@ __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy
     if (rl < rt) atomicAdd(db + n, acc);
 }
 
+// vector form: a thread owns one 16-byte channel vector and walks rows; row lanes are folded through LDS so that a
+// block issues one atomic per channel
+template <typename T>
+__global__ __launch_bounds__(256) void bias_grad_vec_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t M,
+                                                            int N, int ldy, int rows_per_block) {
+    constexpr int V = Vec16<T>::N;
+    __shared__ float sh[256 * V];
+    const int NV = N / V, rt = 256 / NV;
+    const int col = threadIdx.x % NV, rl = threadIdx.x / NV;
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    if (rl < rt) {
+        const int64_t r0 = (int64_t)blockIdx.x * rows_per_block, r1 = min(M, r0 + rows_per_block);
+        for (int64_t m = r0 + rl; m < r1; m += rt) {
+            float v[V];
+            Vec16<T>::load(dy + m * ldy + col * V, v);
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += v[q];
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < V; ++q) sh[threadIdx.x * V + q] = acc[q];
+    __syncthreads();
+    if (threadIdx.x < N) {
+        const int c = threadIdx.x / V, q = threadIdx.x % V;
+        float t = 0.f;
+        for (int r = 0; r < rt; ++r) t += sh[(r * NV + c) * V + q];
+        atomicAdd(db + threadIdx.x, t);
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void pack_input_kernel(const float* __restrict__ x, T* __restrict__ y, int B,
                                                          int C, int64_t HW, int Cp) {
@@ -194,9 +226,22 @@ extern "C" int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int 
 
 extern "C" int dml_bias_grad(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, void* stream) {
     if (!dy || !db || M <= 0 || N <= 0 || N > 256) return DML_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    if (N % V == 0 && ldy % V == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
+        const int64_t rpb = (M + 1023) / 1024;
+        const int grid = (int)((M + rpb - 1) / rpb);
+        if (dtype == DML_BF16)
+            hipLaunchKernelGGL(bias_grad_vec_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, db, M, N, ldy,
+                               (int)rpb);
+        else
+            hipLaunchKernelGGL(bias_grad_vec_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, db, M, N, ldy,
+                               (int)rpb);
+        DML_LAUNCH_CHECK();
+        return 0;
+    }
     const int rt = 256 / N;
     const int grid = grid_for((M + rt - 1) / rt, 1, 512);
-    hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, db, M, N, ldy);
     else
