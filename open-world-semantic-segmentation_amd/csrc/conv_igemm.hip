@@ -1243,12 +1243,14 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     // large-tile kernel: bf16, whole 256-channel output tiles, everything addressable with 31-bit byte offsets and
     // 24-bit pixel indices.  Measured (tools/bench_conv.py wgrad, incl. the reduce pass, vs the 128 x 128 kernel):
     // decoder 3x3 320->256 @192^2 970 vs 727 TFLOP/s, 3x3 512->512 d2 879 vs 669, ASPP 3x3 2048->256 857 vs 693,
-    // layer3 3x3 256->256 569 vs 500.  With fewer than 6 output tiles (the 1x1 256<->1024 layers) filling 256 CUs
-    // takes 64 splits and the slab traffic makes it a few % slower than the small-tile kernel, which keeps those.
+    // layer3 3x3 256->256 569 vs 500.  With 4 output tiles (the 1x1 256<->1024 layers) filling 256 CUs would take 64
+    // splits and the slab traffic eats the gain, so those run as 128 workgroups (32 splits): standalone that is a
+    // few % slower than the small-tile kernel, but the weight gradients share the chip with the main stream and what
+    // counts there is CU-time -- whole step +0.75 % (3 interleaved A/B runs of bench.py).
     static const bool wg_v1 = getenv("DML_WGRAD_V1") != nullptr;
     const int64_t xb64 = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2;
     const int64_t yb64 = (((int64_t)a.M - 1) * a.ldy + a.N) * 2;
-    if (!wg_v1 && d->dtype == DML_BF16 && use_ws && a.N % 256 == 0 && (a.N / 256) * ((a.Ktot + 255) / 256) >= 6 &&
+    if (!wg_v1 && d->dtype == DML_BF16 && use_ws && a.N % 256 == 0 && (a.N / 256) * ((a.Ktot + 255) / 256) >= 4 &&
         tiles >= 16 &&
         xb64 < (1ll << 31) && yb64 < (1ll << 31) && (int64_t)(a.B + 1) * a.Hi * a.Wi < (1 << 24) && a.M < (1 << 24) &&
         a.ldx < (1 << 22) && a.ldy < (1 << 22)) {
@@ -1257,8 +1259,8 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         const int base = a.nblk_n * a.nblk_k;
         int sk = d->splitk;
         if (sk <= 0) {
-            // one workgroup per CU: pick the split count that fills whole rounds of 256 workgroups best, fewest
-            // splits on ties (less slab traffic); at least 8 K steps per workgroup
+            // one workgroup per CU: pick the split count that fills whole rounds of 256 (128) workgroups best,
+            // fewest splits on ties (less slab traffic); at least 8 K steps per workgroup
             int smax = tiles / 8;
             if (smax > 256) smax = 256;
             if ((int64_t)smax * plane > d->ws_elems) smax = (int)(d->ws_elems / plane);
@@ -1269,7 +1271,8 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
                 const int slab = (tiles + c - 1) / c;
                 const int real = (tiles + slab - 1) / slab;
                 const int blocks = base * real;
-                const double eff = (double)blocks / (double)(((blocks + 255) / 256) * 256);
+                const int rnd = base < 6 ? 128 : 256;
+                const double eff = (double)blocks / (double)(((blocks + rnd - 1) / rnd) * rnd);
                 if (eff > best + 1e-9) { best = eff; sk = real; }
             }
         }
