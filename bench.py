@@ -175,6 +175,62 @@ def cpu_baseline(size, threads):
                       "best of 2 after 1 warm-up, %.2f s/step" % (size, size, bs, sec)}
 
 
+def infer_bench(args):
+    """Config #5 (not the headline line): eval-mode forward + argmax / max-softmax + dissum score + novel-prototype
+    relabel (test_embedding.py:328-350,428-445 of the reference), images sharded over ranks, no collective."""
+    from dmlnet import parallel
+    rank, local, world = parallel.init_from_env()
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    import network
+    import utils
+    import numpy as np
+    torch.manual_seed(1)
+    model = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    model.to(device).eval()
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    batch = args.batch if args.batch != 16 else 1
+    g = torch.Generator().manual_seed(4321 + rank)
+    img = torch.randn(batch, 3, args.height, args.width, generator=g).to(device)
+    proto = np.full((16,), 0.1)
+
+    def step():
+        with torch.no_grad():
+            logits, centers, feats = model(img)
+            preds, msp = utils.argmax_msp(logits)
+            score = utils.dissum_score(logits, clip=1000.0, inclusive=False)
+            return utils.novel_relabel(preds, logits, feats, proto, -1.5, 16), score
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds, score = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    if rank == 0:
+        print(json.dumps({
+            "metric": "images/sec open-world inference (eval forward + argmax/msp + dissum + novel relabel), DeepLabV3+R101",
+            "value": batch * world * args.steps / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "config": {"workload": "open-world inference %dx%d, %d image(s)/GPU/step, 16 prototypes, random-init weights"
+                                   % (args.height, args.width, batch), "parallelism": "dp%d" % world}}))
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -187,7 +243,14 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dump-conv", default=None, help="write a per-launch conv table (json) from the profiled pass")
+    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+                    help="train = the headline metric (default); infer = SURVEY 8(d) config #5: open-world inference "
+                         "at --height x --width, --batch images per step (default 1), scores on the device")
+    ap.add_argument("--height", type=int, default=1024)
+    ap.add_argument("--width", type=int, default=2048)
     args = ap.parse_args()
+    if args.mode == "infer":
+        return infer_bench(args)
 
     from dmlnet import parallel
     rank, local, world = parallel.init_from_env()
