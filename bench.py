@@ -150,6 +150,80 @@ def bench_distance_kernel(batch, size, device):
             "unit": "GB/s", "frac": bytes_ / sec / HBM_PEAK, "bytes_per_px": 192, "ms": sec * 1e3}
 
 
+def bench_input_pipeline(batch, size, device):
+    """Device input pipeline: 1024 x 2048 uint8 frames -> size x size crops with colour jitter and
+    flip -> normalised fp32 NCHW + int64 labels.  Algorithmic bytes per output pixel: 3 (contrast-sum pass) + 3 + 1
+    read, 12 + 8 written = 27."""
+    import random
+    import utils
+    et = utils.ext_transforms
+    g = torch.Generator().manual_seed(7)
+    frames = torch.randint(0, 256, (batch, 1024, 2048, 3), generator=g, dtype=torch.uint8).to(device)
+    labels = torch.randint(0, 19, (batch, 1024, 2048), generator=g, dtype=torch.uint8).to(device)
+    tf = et.ExtCompose([et.ExtRandomCrop(size=(size, size)), et.ExtColorJitter(brightness=0.5, contrast=0.5, saturation=0.5),
+                        et.ExtRandomHorizontalFlip(), et.ExtToTensor(),
+                        et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
+    random.seed(0)
+    for _ in range(3):
+        tf(frames, labels)
+    torch.cuda.synchronize()
+    n = 20
+    t0 = time.perf_counter()
+    for _ in range(n):
+        tf(frames, labels)
+    torch.cuda.synchronize()
+    sec = (time.perf_counter() - t0) / n           # host parameter draw + H2D of 40 B/sample + both kernels
+    # the two kernels alone (HIP events on the launch stream, fixed parameters)
+    from dmlnet import _lib
+    lib = _lib.load()
+    params = tf.last_params
+    arr = (_lib.AugSample * batch)()
+    for b, p in enumerate(params):
+        arr[b].i, arr[b].j, arr[b].flip, arr[b].n_ops = p["i"], p["j"], int(p["flip"]), len(p["ops"])
+        for k, (code, f) in enumerate(p["ops"]):
+            arr[b].op[k], arr[b].factor[k] = code, f
+    dp = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(device)
+    lsum = torch.empty(batch, dtype=torch.int32, device=device)
+    oi = torch.empty(batch, 3, size, size, device=device)
+    ol = torch.empty(batch, size, size, dtype=torch.int64, device=device)
+    st = torch.cuda.current_stream().cuda_stream
+    def kern():
+        lib.dml_aug_contrast_sum(frames.data_ptr(), dp.data_ptr(), lsum.data_ptr(), batch, 1024, 2048, size, size, st)
+        lib.dml_aug_apply(frames.data_ptr(), labels.data_ptr(), dp.data_ptr(), lsum.data_ptr(), oi.data_ptr(), ol.data_ptr(),
+                          batch, 1024, 2048, size, size, 0.485, 0.456, 0.406, 0.229, 0.224, 0.225, st)
+    for _ in range(3):
+        kern()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        kern()
+    e1.record()
+    torch.cuda.synchronize()
+    ksec = e0.elapsed_time(e1) * 1e-3 / n
+    bytes_ = 27.0 * batch * size * size
+    return {"kernels": "aug_contrast_sum + aug_apply", "bound": "hbm", "achieved": bytes_ / ksec / 1e9,
+            "peak": HBM_PEAK / 1e9, "unit": "GB/s", "frac": bytes_ / ksec / HBM_PEAK, "bytes_per_px": 27,
+            "kernel_ms_per_batch": ksec * 1e3, "ms_per_batch_with_host": sec * 1e3, "images_per_sec": batch / sec}
+
+
+def cpu_input_pipeline(size):
+    """the oracle's restatement of the reference pipeline (numpy, one core) on two frames"""
+    import random
+    import numpy as np
+    from oracle import transforms_ref as TR
+    rs = np.random.RandomState(7)
+    img = (rs.rand(1024, 2048, 3) * 256).astype(np.uint8)
+    lbl = (rs.rand(1024, 2048) * 19).astype(np.uint8)
+    rng = random.Random(0)
+    t0 = time.perf_counter()
+    n = 2
+    for _ in range(n):
+        p = TR.sample_params(rng, 1024, 2048, (size, size))
+        TR.apply(img, lbl, p, (size, size), [0.485, 0.456, 0.406], [0.229, 0.224, 0.225])
+    return {"value": n / (time.perf_counter() - t0), "unit": "images/sec", "cores": 1, "kind": "port",
+            "sample": "2 frames 1024x2048 -> %dx%d, numpy restatement of the Pillow arithmetic" % (size, size)}
+
+
 def cpu_baseline(size, threads):
     """The CPU oracle (port of the reference's PyTorch path) on the host cores: 768x768 bs=2 train step."""
     import helpers as H
@@ -351,9 +425,12 @@ def main():
                            "igemm_ms_per_step": tsec["igemm"] * 1e3, "wgrad_ms_per_step": tsec["wgrad"] * 1e3,
                            "whole_step_frac": flops / (elapsed / args.steps) / peak}
         out["hbm_kernel"] = bench_distance_kernel(args.batch, args.size, device)
+        out["input_pipeline"] = bench_input_pipeline(args.batch, args.size, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
         out["cpu_baseline"] = cpu_baseline(args.size, threads)
+        if "input_pipeline" in out:
+            out["input_pipeline"]["cpu_baseline"] = cpu_input_pipeline(args.size)
     if rank == 0:
         print(json.dumps(out))
     if world > 1:

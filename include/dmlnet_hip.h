@@ -222,6 +222,35 @@ int dml_sgd_step(float* p, const float* g, float* v, int64_t n, float lr, float 
 /* fill / scale helpers used by the host runtime */
 int dml_fill_f32(float* p, int64_t n, float value, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Input pipeline on the device (the step before the path): the Cityscapes train
+ * transform of main_embedding.py:148-157 -- random crop, colour jitter (brightness / contrast /
+ * saturation in a random order), horizontal flip, ToTensor, Normalize (utils/ext_transforms.py:222-230,
+ * 282-293, 313-322, 357-393, 469-504) -- on a batch of uint8 NHWC frames resident in HBM.  The random
+ * draws stay on the host (utils/ext_transforms.py of this package mirrors the reference's order of
+ * `random` calls); the kernels take one DmlAugSample per image.  Pixel arithmetic is Pillow's, bit for
+ * bit: L = (19595 R + 38470 G + 7471 B + 0x8000) >> 16; blend(a, b, f) = (uint8)(a + f*(b - a)) in
+ * float32 without fused multiply-add, truncating, clipped to [0,255] when f is outside [0,1]; the
+ * contrast pivot is int(mean(L over the crop, after the ops that precede it) + 0.5).
+ * ---------------------------------------------------------------------------------------------- */
+typedef struct DmlAugSample {
+    int32_t i, j;       /* crop origin (row, column) in the source frame */
+    int32_t flip;       /* horizontal flip (applied after the jitter, ext_transforms.py:229) */
+    int32_t n_ops;      /* 0..3 jitter ops */
+    int32_t op[3];      /* 0 brightness, 1 contrast, 2 saturation, in application order */
+    float factor[3];
+} DmlAugSample;
+/* lsum[b] (device uint32, zeroed by the call) = sum of L over sample b's crop as seen by its contrast
+ * op (after the ops that precede it); untouched semantics for samples without a contrast op. */
+int dml_aug_contrast_sum(const uint8_t* img, const DmlAugSample* samples, uint32_t* lsum, int B, int H,
+                         int W, int th, int tw, void* stream);
+/* out_img[B,3,th,tw] fp32 = ((jittered, flipped crop)/255 - mean)/std; out_lbl[B,th,tw] int64 = the
+ * same crop / flip of lbl[B,H,W] (uint8).  lsum from dml_aug_contrast_sum on the same stream. */
+int dml_aug_apply(const uint8_t* img, const uint8_t* lbl, const DmlAugSample* samples,
+                  const uint32_t* lsum, float* out_img, int64_t* out_lbl, int B, int H, int W, int th,
+                  int tw, float mean0, float mean1, float mean2, float std0, float std1, float std2,
+                  void* stream);
+
 #ifdef __cplusplus
 }
 #endif

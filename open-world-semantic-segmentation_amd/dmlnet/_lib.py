@@ -45,6 +45,11 @@ class PrepDesc(C.Structure):
                 ("Cp", C.c_int32)]
 
 
+class AugSample(C.Structure):
+    _fields_ = [("i", C.c_int32), ("j", C.c_int32), ("flip", C.c_int32), ("n_ops", C.c_int32),
+                ("op", C.c_int32 * 3), ("factor", C.c_float * 3)]
+
+
 _PROTOS = {
     "dml_abi_version": (c_i, []),
     "dml_target_arch": (C.c_char_p, []),
@@ -83,6 +88,8 @@ _PROTOS = {
     "dml_loss_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_f, c_f, c_p]),
     "dml_sgd_step": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_p]),
     "dml_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
+    "dml_aug_contrast_sum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_aug_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
 }
 
 EXPORTS = tuple(_PROTOS.keys())

@@ -41,6 +41,8 @@ def get_argparser():
     p.add_argument("--print_interval", type=int, default=10)
     p.add_argument("--random_seed", type=int, default=1)
     p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--frame_height", type=int, default=1024, help="synthetic source frames (Cityscapes: 1024 x 2048)")
+    p.add_argument("--frame_width", type=int, default=2048)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
     return p
 
@@ -92,14 +94,27 @@ def main():
 
     lo, hi = parallel.shard_range(opts.batch_size, rank, world)
     g = torch.Generator().manual_seed(1234 + rank)
-    images = torch.randn(hi - lo, 3, opts.crop_size, opts.crop_size, generator=g).to(device)
-    labels = torch.randint(0, opts.num_classes, (hi - lo, opts.crop_size, opts.crop_size), generator=g)
-    labels[:, : max(1, opts.crop_size * 38 // 768)] = 255
-    labels = labels.to(device)
+    # synthetic Cityscapes: a pool of uint8 frames + blocky train-id maps resident in HBM; every iteration draws a
+    # fresh crop / colour jitter / flip of them on the device (the reference's train transform, :148-157)
+    from utils import ext_transforms as et
+    fh, fw = max(opts.crop_size, opts.frame_height), max(opts.crop_size, opts.frame_width)
+    frames = torch.randint(0, 256, (hi - lo, fh, fw, 3), generator=g, dtype=torch.uint8).to(device)
+    coarse = torch.randint(0, opts.num_classes, (hi - lo, (fh + 63) // 64, (fw + 63) // 64), generator=g, dtype=torch.uint8)
+    frame_labels = coarse.repeat_interleave(64, 1).repeat_interleave(64, 2)[:, :fh, :fw].contiguous()
+    frame_labels[:, : max(1, fh * 38 // 768)] = 255
+    frame_labels = frame_labels.to(device)
+    train_transform = et.ExtCompose([
+        et.ExtRandomCrop(size=(opts.crop_size, opts.crop_size)),
+        et.ExtColorJitter(brightness=0.5, contrast=0.5, saturation=0.5),
+        et.ExtRandomHorizontalFlip(),
+        et.ExtToTensor(),
+        et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]),
+    ])
 
     interval_loss, t0 = None, time.perf_counter()
     while cur_itrs < opts.total_itrs:
         cur_itrs += 1
+        images, labels = train_transform(frames, frame_labels)                     # :461-463 (loader + .to(device))
         optimizer.zero_grad()
         outputs, centers, features = model(images)                                 # :466
         loss = criterion(outputs, labels, features)

@@ -38,6 +38,8 @@ def test_struct_layout_matches_header():
     assert ConvDesc.B.offset == 56 and ConvDesc.pre_relu.offset == 56 + 18 * 4
     from dmlnet._lib import PrepDesc
     assert ctypes.sizeof(PrepDesc) == 40
+    from dmlnet._lib import AugSample
+    assert ctypes.sizeof(AugSample) == 40 and AugSample.factor.offset == 28
 
 
 def test_module_tree_and_state_dict_contract():

@@ -1,0 +1,139 @@
+"""Input pipeline: oracle vs the reference fixtures G9 and the live Pillow (CPU), and the HIP
+kernels vs fixtures / oracle through the C ABI (GPU)."""
+import glob
+import os
+import random
+
+import numpy as np
+import pytest
+import torch
+
+import helpers as H  # noqa: F401  (path setup)
+from oracle import transforms_ref as TR
+
+G9 = sorted(glob.glob(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g9_aug_*.npz")))
+MEAN, STD = [0.485, 0.456, 0.406], [0.229, 0.224, 0.225]
+
+
+def _fixture(path):
+    g = np.load(path)
+    return g, int(g["seed"]), tuple(int(v) for v in g["crop"])
+
+
+@pytest.mark.parametrize("path", G9, ids=[os.path.basename(p)[7:-4] for p in G9])
+def test_oracle_reproduces_reference_pipeline(path):
+    """bit-exact incl. the order of `random` draws: the fixture stores only the seed"""
+    g, seed, crop = _fixture(path)
+    p = TR.sample_params(random.Random(seed), g["img"].shape[0], g["img"].shape[1], crop)
+    img, lbl = TR.apply(g["img"], g["lbl"], p, crop, g["mean"], g["std"])
+    assert img.dtype == np.float32 and np.array_equal(img, g["out_img"])
+    assert np.array_equal(lbl, g["out_lbl"])
+
+
+def test_fixtures_cover_all_orders_and_flips():
+    orders, flips = set(), set()
+    for path in G9:
+        g, seed, crop = _fixture(path)
+        p = TR.sample_params(random.Random(seed), g["img"].shape[0], g["img"].shape[1], crop)
+        orders.add(tuple(c for c, _ in p["ops"]))
+        flips.add(p["flip"])
+    assert len(orders) == 6 and flips == {True, False}
+
+
+def test_oracle_enhance_equals_live_pillow():
+    PIL = pytest.importorskip("PIL")
+    from PIL import Image, ImageEnhance
+    rs = np.random.RandomState(3)
+    for trial in range(120):
+        a = (rs.rand(7, 9, 3) * 256).astype(np.uint8)
+        f = [0.0, 1.0, 0.5, 1.5][trial] if trial < 4 else float(rs.uniform(0.5, 1.5))
+        im = Image.fromarray(a)
+        assert np.array_equal(np.array(im.convert("L")), TR.luma(a))
+        assert np.array_equal(np.array(ImageEnhance.Brightness(im).enhance(f)), TR.adjust_brightness(a, f))
+        assert np.array_equal(np.array(ImageEnhance.Contrast(im).enhance(f)), TR.adjust_contrast(a, f))
+        assert np.array_equal(np.array(ImageEnhance.Color(im).enhance(f)), TR.adjust_saturation(a, f))
+
+
+def test_product_sampler_draws_like_the_reference():
+    """utils.ext_transforms.ExtCompose.sample consumes `random` exactly as the oracle / reference do"""
+    import utils
+    et = utils.ext_transforms
+    tf = et.ExtCompose([et.ExtRandomCrop(size=(20, 28)), et.ExtColorJitter(brightness=0.5, contrast=0.5, saturation=0.5),
+                        et.ExtRandomHorizontalFlip(), et.ExtToTensor(), et.ExtNormalize(mean=MEAN, std=STD)])
+    for seed in (1, 2, 3, 15, 99):
+        random.seed(seed)
+        got, crop = tf.sample(3, 28, 36)
+        rng = random.Random(seed)
+        ref = [TR.sample_params(rng, 28, 36, (20, 28)) for _ in range(3)]
+        assert crop == (20, 28) and got == ref
+    with pytest.raises(NotImplementedError):
+        et.ExtCompose([et.ExtToTensor(), et.ExtRandomCrop(4), et.ExtNormalize(MEAN, STD)])
+    with pytest.raises(NotImplementedError):
+        et.ExtColorJitter(hue=0.1)
+    with pytest.raises(TypeError):
+        tf(torch.zeros(2, 28, 36, 3, dtype=torch.uint8), None)          # CPU tensor: no fallback
+
+
+def _compose(crop):
+    import utils
+    et = utils.ext_transforms
+    return et.ExtCompose([et.ExtRandomCrop(size=crop), et.ExtColorJitter(brightness=0.5, contrast=0.5, saturation=0.5),
+                          et.ExtRandomHorizontalFlip(), et.ExtToTensor(), et.ExtNormalize(mean=MEAN, std=STD)])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("path", G9, ids=[os.path.basename(p)[7:-4] for p in G9])
+def test_device_pipeline_matches_reference_fixture(path):
+    g, seed, crop = _fixture(path)
+    tf = _compose(crop)
+    random.seed(seed)
+    img, lbl = tf(torch.from_numpy(g["img"]).cuda(), torch.from_numpy(g["lbl"]).cuda())
+    torch.cuda.synchronize()
+    assert img.dtype == torch.float32 and lbl.dtype == torch.int64
+    assert np.array_equal(img.cpu().numpy(), g["out_img"])                      # bit-exact
+    assert np.array_equal(lbl.cpu().numpy(), g["out_lbl"].astype(np.int64))
+
+
+@pytest.mark.gpu
+def test_device_pipeline_batch_vs_oracle_edge_factors():
+    """batch of frames, explicit parameters: factors exactly 0 / 1 / at the range ends, 0..3 ops, ragged last segment"""
+    rs = np.random.RandomState(5)
+    B, Hh, Ww, crop = 6, 70, 300, (37, 261)          # 261 = 256 + 5: two segments per row
+    img = (rs.rand(B, Hh, Ww, 3) * 256).astype(np.uint8)
+    img[1] = (img[1] * 0.2).astype(np.uint8)
+    img[2] = 255 - (img[2] * 0.1).astype(np.uint8)
+    lbl = (rs.rand(B, Hh, Ww) * 19).astype(np.uint8)
+    params = [
+        {"i": 0, "j": 0, "ops": [], "flip": False},
+        {"i": 33, "j": 39, "ops": [(1, 1.5)], "flip": True},
+        {"i": 5, "j": 7, "ops": [(2, 0.5), (0, 1.5), (1, 0.5)], "flip": True},
+        {"i": 9, "j": 1, "ops": [(0, 1.0), (1, 1.0), (2, 1.0)], "flip": False},
+        {"i": 20, "j": 30, "ops": [(1, 0.0), (2, 1.4999)], "flip": False},
+        {"i": 1, "j": 2, "ops": [(0, 0.73), (2, 1.31), (1, 1.27)], "flip": True},
+    ]
+    tf = _compose(crop)
+    out, olb = tf(torch.from_numpy(img).cuda(), torch.from_numpy(lbl).cuda(), params=params)
+    torch.cuda.synchronize()
+    for b in range(B):
+        ri, rl = TR.apply(img[b], lbl[b], params[b], crop, MEAN, STD)
+        assert np.array_equal(out[b].cpu().numpy(), ri), "image %d" % b
+        assert np.array_equal(olb[b].cpu().numpy(), rl.astype(np.int64)), "label %d" % b
+
+
+@pytest.mark.gpu
+def test_device_pipeline_cityscapes_size():
+    """1024 x 2048 frames -> 768 x 768 crops (the reference's training geometry), checked against the oracle"""
+    rs = np.random.RandomState(7)
+    B, Hh, Ww, crop = 3, 1024, 2048, (768, 768)
+    base = (rs.rand(B, Hh // 8, Ww // 8, 3) * 256).astype(np.uint8)
+    img = np.ascontiguousarray(np.repeat(np.repeat(base, 8, axis=1), 8, axis=2))
+    img ^= (rs.rand(B, Hh, Ww, 3) * 8).astype(np.uint8)
+    lbl = np.ascontiguousarray(np.repeat(np.repeat((rs.rand(B, Hh // 64, Ww // 64) * 19).astype(np.uint8), 64, 1), 64, 2))
+    tf = _compose(crop)
+    random.seed(123)
+    out, olb = tf(torch.from_numpy(img).cuda(), torch.from_numpy(lbl).cuda())
+    torch.cuda.synchronize()
+    for b in range(B):
+        ri, rl = TR.apply(img[b], lbl[b], tf.last_params[b], crop, MEAN, STD)
+        assert np.array_equal(out[b].cpu().numpy(), ri)
+        assert np.array_equal(olb[b].cpu().numpy(), rl.astype(np.int64))
