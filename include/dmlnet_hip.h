@@ -251,6 +251,15 @@ int dml_aug_apply(const uint8_t* img, const uint8_t* lbl, const DmlAugSample* sa
                   int tw, float mean0, float mean1, float mean2, float std0, float std1, float std2,
                   void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Streaming segmentation metrics on the device (the step after the path):
+ * hist[n*t + p] += 1 for every pixel with 0 <= t < n (and 0 <= p < n), the np.bincount of
+ * metrics/stream_metrics.py:49-55.  hist is a device int64[n*n] that the call accumulates into;
+ * n <= 64.  The scores of :57-83 are computed from the n x n matrix on the host.
+ * ---------------------------------------------------------------------------------------------- */
+int dml_confusion_update(const int64_t* label_true, const int64_t* label_pred, int64_t* hist,
+                         int64_t count, int n_classes, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -905,3 +905,47 @@ extern "C" int dml_loss_bwd(const float* logits, const int64_t* labels, const do
     DML_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// confusion matrix (metrics/stream_metrics.py:49-55 of the reference): per-workgroup LDS histogram, int64 flush
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void confusion_kernel(const int64_t* __restrict__ lt, const int64_t* __restrict__ lp,
+                                                        unsigned long long* __restrict__ hist, int64_t count, int n) {
+    extern __shared__ uint32_t bins[];
+    const int nb = n * n;
+    for (int i = threadIdx.x; i < nb; i += 256) bins[i] = 0u;
+    __syncthreads();
+    typedef long long ll2 __attribute__((ext_vector_type(2)));
+    const int64_t pairs = count >> 1;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < pairs; i += (int64_t)gridDim.x * 256) {
+        const ll2 t = reinterpret_cast<const ll2*>(lt)[i], p = reinterpret_cast<const ll2*>(lp)[i];
+        if (t.x >= 0 && t.x < n && p.x >= 0 && p.x < n) atomicAdd(&bins[(int)t.x * n + (int)p.x], 1u);
+        if (t.y >= 0 && t.y < n && p.y >= 0 && p.y < n) atomicAdd(&bins[(int)t.y * n + (int)p.y], 1u);
+    }
+    if ((count & 1) && blockIdx.x == 0 && threadIdx.x == 0) {
+        const int64_t t = lt[count - 1], p = lp[count - 1];
+        if (t >= 0 && t < n && p >= 0 && p < n) atomicAdd(&bins[(int)t * n + (int)p], 1u);
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < nb; i += 256)
+        if (bins[i]) atomicAdd(hist + i, (unsigned long long)bins[i]);
+}
+}  // namespace
+
+extern "C" int dml_confusion_update(const int64_t* label_true, const int64_t* label_pred, int64_t* hist, int64_t count,
+                                    int n_classes, void* stream) {
+    if (!label_true || !label_pred || !hist || count < 0 || n_classes <= 0 || n_classes > 64) return DML_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(label_true) | reinterpret_cast<uintptr_t>(label_pred)) & 15) return DML_EALIGN;
+    if (count == 0) return 0;
+    // a workgroup's uint32 bins cannot overflow: it sees at most count / grid + 512 elements
+    int64_t blocks = (count / 2 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    if (count / blocks >= (1ll << 31)) return DML_EUNSUPPORTED;
+    hipLaunchKernelGGL(confusion_kernel, dim3((int)blocks), dim3(256), sizeof(uint32_t) * n_classes * n_classes,
+                       static_cast<hipStream_t>(stream), label_true, label_pred, reinterpret_cast<unsigned long long*>(hist),
+                       count, n_classes);
+    DML_LAUNCH_CHECK();
+    return 0;
+}

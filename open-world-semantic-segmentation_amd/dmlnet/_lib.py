@@ -88,6 +88,7 @@ _PROTOS = {
     "dml_loss_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_f, c_f, c_p]),
     "dml_sgd_step": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_p]),
     "dml_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
+    "dml_confusion_update": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
     "dml_aug_contrast_sum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_aug_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
 }

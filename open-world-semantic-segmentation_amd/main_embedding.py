@@ -41,6 +41,7 @@ def get_argparser():
     p.add_argument("--print_interval", type=int, default=10)
     p.add_argument("--random_seed", type=int, default=1)
     p.add_argument("--synthetic", action="store_true")
+    p.add_argument("--val_images", type=int, default=2, help="synthetic frames scored at every --val_interval")
     p.add_argument("--frame_height", type=int, default=1024, help="synthetic source frames (Cityscapes: 1024 x 2048)")
     p.add_argument("--frame_width", type=int, default=2048)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
@@ -111,6 +112,25 @@ def main():
         et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]),
     ])
 
+    # validation as main_embedding.py:172-324 of the reference reduced to its metric path: eval forward, argmax,
+    # StreamSegMetrics.update on the device tensors (no .cpu().numpy() per batch), val transform = ToTensor + Normalize
+    import metrics as metrics_mod
+    seg_metrics = metrics_mod.StreamSegMetrics(opts.num_classes)                   # :382
+    val_transform = et.ExtCompose([et.ExtToTensor(),
+                                   et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
+
+    def validate():
+        seg_metrics.reset()                                                        # :228
+        model.eval()
+        with torch.no_grad():
+            for b in range(min(opts.val_images, frames.shape[0])):
+                vi, vl = val_transform(frames[b:b + 1], frame_labels[b:b + 1])
+                outputs, _, _ = model(vi)
+                preds, _ = utils.argmax_msp(outputs)                               # :262-266
+                seg_metrics.update(vl, preds)                                      # :269
+        model.train()
+        return seg_metrics.get_results()                                           # :324
+
     interval_loss, t0 = None, time.perf_counter()
     while cur_itrs < opts.total_itrs:
         cur_itrs += 1
@@ -128,6 +148,10 @@ def main():
                                                            float(interval_loss) / opts.print_interval,
                                                            opts.batch_size * opts.print_interval / dt))
             interval_loss, t0 = None, time.perf_counter()
+        if opts.val_interval and cur_itrs % opts.val_interval == 0 and opts.val_images > 0:
+            val_score = validate()                                                 # :487-489
+            if rank == 0:
+                print(seg_metrics.to_str(val_score))
         if opts.val_interval and cur_itrs % opts.val_interval == 0 and rank == 0:
             utils.mkdir(opts.save_dir)
             save_ckpt(os.path.join(opts.save_dir, "latest_%s_synthetic_os%d.pth" % (opts.model, opts.output_stride)))

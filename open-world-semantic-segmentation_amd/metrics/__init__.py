@@ -1,0 +1,1 @@
+from .stream_metrics import StreamSegMetrics, AverageMeter  # noqa: F401

@@ -137,3 +137,50 @@ def test_device_pipeline_cityscapes_size():
         ri, rl = TR.apply(img[b], lbl[b], tf.last_params[b], crop, MEAN, STD)
         assert np.array_equal(out[b].cpu().numpy(), ri)
         assert np.array_equal(olb[b].cpu().numpy(), rl.astype(np.int64))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# metrics after the path: confusion matrix on the device
+# ---------------------------------------------------------------------------------------------------------------------
+def test_metrics_oracle_matches_reference_fixture():
+    from oracle import metrics_ref as MR
+    g = np.load(os.path.join(os.path.dirname(G9[0]), "g10_metrics.npz"))
+    n = int(g["n"])
+    hist = sum(MR.fast_hist(g["lt"][b].flatten(), g["lp"][b].flatten(), n) for b in range(g["lt"].shape[0]))
+    assert np.array_equal(hist, g["hist"])
+    r = MR.results(hist)
+    assert r["Overall Acc"] == g["overall"] and r["Mean Acc"] == g["mean_acc"] and r["FreqW Acc"] == g["fw"]
+    assert r["Mean IoU"] == g["miou"]
+    assert np.array_equal(np.array([r["Class IoU"][k] for k in range(n)]), g["class_iou"], equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_stream_metrics_on_device():
+    import metrics
+    from oracle import metrics_ref as MR
+    g = np.load(os.path.join(os.path.dirname(G9[0]), "g10_metrics.npz"))
+    n = int(g["n"])
+    m = metrics.StreamSegMetrics(n)
+    lt, lp = torch.from_numpy(g["lt"]).cuda(), torch.from_numpy(g["lp"]).cuda()
+    m.update(lt[:2], lp[:2])
+    m.update(lt[2:], lp[2:])
+    r = m.get_results()
+    assert np.array_equal(m.confusion_matrix.cpu().numpy(), g["hist"].astype(np.int64))          # exact counts
+    assert r["Overall Acc"] == g["overall"] and r["Mean IoU"] == g["miou"] and r["Mean Acc"] == g["mean_acc"]
+    assert r["FreqW Acc"] == g["fw"]
+    assert np.array_equal(np.array([r["Class IoU"][k] for k in range(n)]), g["class_iou"], equal_nan=True)
+    m.reset()
+    assert int(m.confusion_matrix.sum()) == 0
+    # full-size, odd element count, labels outside [0, n): 3 x 1023 x 2047 pixels vs numpy bincount
+    rs = np.random.RandomState(2)
+    a = rs.randint(-1, n + 2, (3, 1023, 2047)).astype(np.int64)
+    a[a == n + 1] = 255
+    b = rs.randint(0, n, (3, 1023, 2047)).astype(np.int64)
+    m.update(torch.from_numpy(a).cuda(), torch.from_numpy(b).cuda())
+    assert np.array_equal(m.confusion_matrix.cpu().numpy(), MR.fast_hist(a.flatten(), b.flatten(), n))
+    m.reset()
+    ta, tb = torch.from_numpy(a).cuda().flatten(), torch.from_numpy(b).cuda().flatten()
+    m.update(ta[1:1001], tb[1:1001])                       # views that start 8 bytes off a 16-byte boundary
+    assert np.array_equal(m.confusion_matrix.cpu().numpy(), MR.fast_hist(a.flatten()[1:1001], b.flatten()[1:1001], n))
+    with pytest.raises(TypeError):
+        m.update(torch.from_numpy(a), torch.from_numpy(b))
