@@ -35,6 +35,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     // pass 1: exact total sum -> global mean
     double s = 0.0;
     if (n < N)
+        #pragma unroll 8
         for (int64_t g = sl; g < G; g += FIN_SL) s += (double)partials[(g * N + n) * 2];
     sh[sl][ch] = s;
     __syncthreads();
@@ -47,6 +48,7 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     // pass 2 (partials are L2-hot): M2 = sum_g [ M2_g + n_g (mean_g - mean)^2 ]  (Chan et al., no cancellation)
     double q = 0.0;
     if (n < N)
+        #pragma unroll 8
         for (int64_t g = sl; g < G; g += FIN_SL) {
             const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
             const double rows = g == G - 1 ? (double)last_rows : (double)DML_STAT_ROWS;
@@ -288,6 +290,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const int n = blockIdx.x * FIN_CH + ch;
     double s0 = 0.0, s1 = 0.0;
     if (n < N)
+        #pragma unroll 8
         for (int g = sl; g < nblocks; g += FIN_SL) {
             const float2 p = *reinterpret_cast<const float2*>(partials + ((int64_t)g * N + n) * 2);
             s0 += p.x; s1 += p.y;
@@ -388,6 +391,7 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(float* partials, 
     const int64_t g1 = (int)blockIdx.y == NC - 1 ? G : g0 + R;
     double S = 0.0, Q = 0.0, P = 0.0;
     if (n < N)
+        #pragma unroll 8
         for (int64_t g = g0 + rl; g < g1; g += 4) {
             const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
             const double rows = g == G - 1 ? (double)last_rows : (double)DML_STAT_ROWS;
@@ -416,6 +420,7 @@ __global__ __launch_bounds__(256) void bn_finalize_folded_kernel(
     const double* f = reinterpret_cast<const double*>(partials);
     double S = 0.0, Q = 0.0, P = 0.0;
     if (n < N)
+        #pragma unroll 8
         for (int ck = cl; ck < NC; ck += 8) {
             const int64_t g0 = (int64_t)ck * R;
             S += f[(g0 + 0) * N + n];

@@ -1079,6 +1079,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
             src = t * Cp + (i - t * Cm);
         }
         float acc = 0.f;
+        #pragma unroll 8
         for (int sidx = s0; sidx < s1; ++sidx) acc += ws[sidx * plane + src];
         if (gridDim.y == 1) dw[i] += acc;
         else atomicAdd(dw + i, acc);
