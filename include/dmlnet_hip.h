@@ -260,6 +260,17 @@ int dml_aug_apply(const uint8_t* img, const uint8_t* lbl, const DmlAugSample* sa
 int dml_confusion_update(const int64_t* label_true, const int64_t* label_pred, int64_t* hist,
                          int64_t count, int n_classes, void* stream);
 
+/* Pixel-level OOD measures (anomaly/anom_utils.py:25-78 as called by eval_ood_traditional.py:128-148):
+ * scores = -conf; positives = pixels whose label is one of out_labels (host array, n_out <= 8), negatives = the
+ * rest; pixels with mask[i] == 0 are left out (mask optional).  result (device double[5]) = { AUROC, AUPR,
+ * FPR at recall_level, #positives, #negatives }; the three measures are NaN when either class is empty (the
+ * reference prints a notice and skips the image).  work: >= dml_ood_workspace_bytes(n) bytes, 256-byte aligned.
+ * Device-side radix sort + rank statistics; nothing is copied to the host. */
+int64_t dml_ood_workspace_bytes(int64_t n);
+int dml_ood_measures(const float* conf, const int64_t* seg_label, const uint8_t* mask, int64_t n,
+                     const int64_t* out_labels, int n_out, double recall_level, void* work,
+                     int64_t work_bytes, double* result, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

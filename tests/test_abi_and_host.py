@@ -14,7 +14,7 @@ import helpers as H
 
 def header_symbols():
     txt = open(os.path.join(H.ROOT, "include", "dmlnet_hip.h")).read()
-    return sorted(set(re.findall(r"^(?:int|const char\*)\s+(dml_\w+)\s*\(", txt, flags=re.M)))
+    return sorted(set(re.findall(r"^(?:int|int64_t|const char\*)\s+(dml_\w+)\s*\(", txt, flags=re.M)))
 
 
 def test_library_exports_every_declared_symbol():

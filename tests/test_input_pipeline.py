@@ -184,3 +184,55 @@ def test_stream_metrics_on_device():
     assert np.array_equal(m.confusion_matrix.cpu().numpy(), MR.fast_hist(a.flatten()[1:1001], b.flatten()[1:1001], n))
     with pytest.raises(TypeError):
         m.update(torch.from_numpy(a), torch.from_numpy(b))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# OOD measures after the path: AUROC / AUPR / FPR95 by a device sort
+# ---------------------------------------------------------------------------------------------------------------------
+G11_CASES = ("cont", "ties", "sep", "inv", "r20")
+
+
+@pytest.mark.parametrize("case", G11_CASES)
+def test_ood_oracle_matches_reference_fixture(case):
+    from oracle import ood_measures_ref as OR
+    g = np.load(os.path.join(os.path.dirname(G9[0]), "g11_ood_measures.npz"))
+    a, p, f = OR.get_measures(g[case + "_pos"], g[case + "_neg"])
+    ref = g[case + "_res"]
+    assert abs(a - ref[0]) <= 1e-12 and abs(p - ref[1]) <= 1e-12 and f == ref[2]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("case", G11_CASES)
+def test_ood_measures_on_device_match_reference_fixture(case):
+    import anom_utils
+    g = np.load(os.path.join(os.path.dirname(G9[0]), "g11_ood_measures.npz"))
+    a, p, f = anom_utils.get_measures(torch.from_numpy(g[case + "_pos"]).cuda(), torch.from_numpy(g[case + "_neg"]).cuda())
+    ref = g[case + "_res"]
+    assert abs(a - ref[0]) <= 1e-12, (a, ref[0])
+    assert abs(p - ref[1]) <= 1e-12, (p, ref[1])
+    assert f == ref[2], (f, ref[2])
+
+
+@pytest.mark.gpu
+def test_ood_measures_full_image_vs_oracle():
+    """1024 x 2048 score map with a mask, several OOD labels, clipped plateaus (ties) -- vs the oracle"""
+    import anom_utils
+    from oracle import ood_measures_ref as OR
+    rs = np.random.RandomState(4)
+    Hh, Ww = 1024, 2048
+    lab = rs.randint(0, 14, (Hh, Ww)).astype(np.int64)
+    conf = rs.randn(Hh, Ww).astype(np.float32) + (lab >= 12) * 0.8
+    conf = np.clip(conf, -1.5, 2.0).astype(np.float32)                  # plateaus at both ends
+    conf[rs.rand(Hh, Ww) < 0.1] = 0.0
+    mask = rs.rand(Hh, Ww) < 0.9
+    got = anom_utils.eval_ood_measure(torch.from_numpy(conf).cuda(), torch.from_numpy(lab).cuda(), [12, 13],
+                                      mask=torch.from_numpy(mask).cuda())
+    ref = OR.eval_ood_measure(conf, lab, [12, 13], mask=mask)
+    assert abs(got[0] - ref[0]) <= 1e-12 and abs(got[1] - ref[1]) <= 1e-11 and got[2] == ref[2], (got, ref)
+    # only one class present -> None, like the reference
+    assert anom_utils.eval_ood_measure(torch.from_numpy(conf).cuda(), torch.from_numpy(lab).cuda(), [99]) is None
+    # sortedness / permutation property of the device sort at full size: same measures for a shuffled input
+    perm = rs.permutation(Hh * Ww)
+    got2 = anom_utils.eval_ood_measure(torch.from_numpy(conf.reshape(-1)[perm]).cuda(), torch.from_numpy(lab.reshape(-1)[perm]).cuda(),
+                                       [12, 13], mask=torch.from_numpy(mask.reshape(-1)[perm]).cuda())
+    assert got2[0] == got[0] and got2[2] == got[2] and abs(got2[1] - got[1]) <= 1e-13
