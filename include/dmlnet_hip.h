@@ -60,6 +60,18 @@ typedef struct DmlConvDesc {
     int32_t accum;        /* 1: y += result                                                              */
     int32_t mode;         /* 0 = forward gather, 1 = data-gradient gather (transposed conv)              */
     int32_t pre_relu;     /* with pre_scale: apply ReLU after the affine                                 */
+    /* mode 1 only, optional (all NULL/0 otherwise): the result y is the output gradient dz of a BatchNorm
+     * (+ReLU) whose pre-normalisation tensor is bnr_y [M][N] (pitch bnr_ldy) with the 1-bit ReLU mask of
+     * dml_bn_apply; the epilogue then also writes that BN's backward partial sums, exactly what
+     * dml_bn_bwd_reduce would produce from the stored dz: bnr_partials[ceil(M/DML_STAT_ROWS)][N][2] =
+     * (sum g, sum g*(bnr_y - mean)*invstd), g = dz * [mask bit] -- pass it with nblocks = ceil(M/64) to
+     * dml_bn_bwd_finalize.  bf16, N % 8 == 0, N > 32. */
+    const void* bnr_y;
+    const uint8_t* bnr_mask;
+    const float* bnr_mean;
+    const float* bnr_invstd;
+    float* bnr_partials;
+    int32_t bnr_ldy, bnr_relu;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */

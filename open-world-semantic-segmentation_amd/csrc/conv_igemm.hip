@@ -35,6 +35,13 @@ struct ConvArgs {
     FastDiv div_wo, div_howo, div_c;
     float* dbg;      // tuning builds only (ABL == 3): per-wave phase timings
     uint32_t x_bytes, w_bytes;   // operand extents for the buffer descriptors (fast path: both < 2^31)
+    // data-gradient mode: BN-backward partial sums of the tensor being written (DmlConvDesc::bnr_*)
+    const void* bnr_y;
+    const uint8_t* bnr_mask;
+    const float* bnr_mean;
+    const float* bnr_invstd;
+    float* bnr_partials;
+    int bnr_ldy, bnr_relu;
 };
 
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
@@ -80,7 +87,7 @@ __device__ __forceinline__ float row16_sum(float v) {
 // shared epilogue: BN partial statistics, bias, accumulate, fp32 / storage-dtype stores
 // acc[i][j][e] = out[m = mw0 + j*16 + (lane&15)][n = nw0 + (lane>>4)*4*NT + i*4 + e]
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT, int MT>
+template <typename T, int NT, int MT, int MODE>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int mw0, const int nw0,
                                               const int lr, const int lq) {
     constexpr int TM = MT * 16;
@@ -138,12 +145,105 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
 
     float bv[CL];
 #pragma unroll
-    for (int c = 0; c < CL; ++c) bv[c] = (a.bias != nullptr && nl + c < a.N) ? a.bias[nl + c] : 0.f;
+    for (int c = 0; c < CL; ++c) bv[c] = (MODE == 0 && a.bias != nullptr && nl + c < a.N) ? a.bias[nl + c] : 0.f;
 
     const bool out_f32 = a.y_f32 || sizeof(T) == 4;
     const uintptr_t yb = reinterpret_cast<uintptr_t>(a.y);
     const bool v4_ok = ((a.N & 3) == 0) && ((a.ldy & 3) == 0) && ((yb & (out_f32 ? 15 : 7)) == 0);
     const bool v8_ok = ((a.N & 7) == 0) && ((a.ldy & 7) == 0) && ((yb & 15) == 0);
+
+    if constexpr (sizeof(T) == 2 && CL >= 8) {
+        if (!out_f32 && v8_ok) {
+            // bf16 rows of 16-byte vectors: 8-channel group outer, rows inner, so that the optional BN-backward sums
+            // of the group (below) live in 32 registers.
+            // Data gradient whose result is the output gradient dz of a BatchNorm(+ReLU): emit that BN's backward
+            // partial sums (sum g, sum g * xhat per 64 rows, g = dz * relu') from the bf16-rounded values being
+            // stored -- exactly what dml_bn_bwd_reduce would compute from the stored tensor -- so the separate pass
+            // over dz / y / mask disappears.
+            const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
+#pragma unroll
+            for (int g = 0; g < CL / 8; ++g) {
+                const int n8 = nl + g * 8;
+                if (n8 >= a.N) continue;
+                float r1[8], r2[8], rmu[8], ris[8];
+                if (bnr) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        r1[e] = 0.f;
+                        r2[e] = 0.f;
+                        rmu[e] = a.bnr_mean[n8 + e];
+                        ris[e] = a.bnr_invstd[n8 + e];
+                    }
+                }
+                // all of the group's loads (accumulate operand, BN input, mask bytes) are issued before the first
+                // use: one memory round trip per group instead of one per row
+                uint4 told[MT], ty[MT];
+                uint32_t bits[MT];
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int m = mw0 + j * 16 + lr;
+                    told[j] = make_uint4(0, 0, 0, 0);
+                    ty[j] = make_uint4(0, 0, 0, 0);
+                    bits[j] = 0xffu;
+                    if (m < a.M) {
+                        if (a.accum)
+                            told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.y) + (int64_t)m * a.ldy + n8);
+                        if (bnr) {
+                            ty[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.bnr_y) +
+                                                                    (int64_t)m * a.bnr_ldy + n8);
+                            if (a.bnr_relu) bits[j] = a.bnr_mask[(int64_t)m * (a.N >> 3) + (n8 >> 3)];
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int m = mw0 + j * 16 + lr;
+                    if (m >= a.M) continue;
+                    float w[8];
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) w[e] = acc[(g * 8 + e) >> 2][j][e & 3] + bv[g * 8 + e];
+                    bf16_t* yp = static_cast<bf16_t*>(a.y) + (int64_t)m * a.ldy + n8;
+                    {
+                        const uint32_t tt[4] = {told[j].x, told[j].y, told[j].z, told[j].w};      // zeros unless accumulating
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            w[2 * e] += __uint_as_float(tt[e] << 16);
+                            w[2 * e + 1] += __uint_as_float(tt[e] & 0xffff0000u);
+                        }
+                    }
+                    const uint32_t pk[4] = {pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
+                                            pack_bf16x2(w[6], w[7])};
+                    *reinterpret_cast<uint4*>(yp) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    if (bnr) {
+                        const uint32_t yy[4] = {ty[j].x, ty[j].y, ty[j].z, ty[j].w};
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) {
+                            const float g0 = (bits[j] >> (2 * e)) & 1u ? __uint_as_float(pk[e] << 16) : 0.f;
+                            const float g1 = (bits[j] >> (2 * e + 1)) & 1u ? __uint_as_float(pk[e] & 0xffff0000u) : 0.f;
+                            r1[2 * e] += g0;
+                            r2[2 * e] += g0 * (__uint_as_float(yy[e] << 16) - rmu[2 * e]) * ris[2 * e];
+                            r1[2 * e + 1] += g1;
+                            r2[2 * e + 1] += g1 * (__uint_as_float(yy[e] & 0xffff0000u) - rmu[2 * e + 1]) * ris[2 * e + 1];
+                        }
+                    }
+                }
+                if (bnr && mw0 < a.M) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        r1[e] = row16_sum(r1[e]);
+                        r2[e] = row16_sum(r2[e]);
+                    }
+                    if (lr == 0) {
+                        float4* pp = reinterpret_cast<float4*>(a.bnr_partials + ((int64_t)(mw0 / TM) * a.N + n8) * 2);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) pp[e] = make_float4(r1[2 * e], r2[2 * e], r1[2 * e + 1], r2[2 * e + 1]);
+                    }
+                }
+            }
+            return;
+        }
+    }
+
 #pragma unroll
     for (int j = 0; j < MT; ++j) {
         const int m = mw0 + j * 16 + lr;
@@ -175,45 +275,24 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
             }
         } else {
             bf16_t* yp = static_cast<bf16_t*>(a.y) + off;
-            if (CL >= 8 && v8_ok) {
 #pragma unroll
-                for (int g = 0; g < CL / 8; ++g) {
-                    if (nl + g * 8 >= a.N) continue;
-                    float* w = v + g * 8;
+            for (int g = 0; g < NT; ++g) {
+                const int n = nl + g * 4;
+                if (n >= a.N) continue;
+                float* w = v + g * 4;
+                if (v4_ok) {
                     if (a.accum) {
-                        const uint4 t = *reinterpret_cast<const uint4*>(yp + g * 8);
-                        const uint32_t tt[4] = {t.x, t.y, t.z, t.w};
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            w[2 * e] += __uint_as_float(tt[e] << 16);
-                            w[2 * e + 1] += __uint_as_float(tt[e] & 0xffff0000u);
-                        }
+                        const uint2 t = *reinterpret_cast<const uint2*>(yp + g * 4);
+                        w[0] += __uint_as_float(t.x << 16);
+                        w[1] += __uint_as_float(t.x & 0xffff0000u);
+                        w[2] += __uint_as_float(t.y << 16);
+                        w[3] += __uint_as_float(t.y & 0xffff0000u);
                     }
-                    *reinterpret_cast<uint4*>(yp + g * 8) =
-                        make_uint4(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
-                                   pack_bf16x2(w[6], w[7]));
-                }
-            } else {
+                    *reinterpret_cast<uint2*>(yp + g * 4) = make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
+                } else {
 #pragma unroll
-                for (int g = 0; g < NT; ++g) {
-                    const int n = nl + g * 4;
-                    if (n >= a.N) continue;
-                    float* w = v + g * 4;
-                    if (v4_ok) {
-                        if (a.accum) {
-                            const uint2 t = *reinterpret_cast<const uint2*>(yp + g * 4);
-                            w[0] += __uint_as_float(t.x << 16);
-                            w[1] += __uint_as_float(t.x & 0xffff0000u);
-                            w[2] += __uint_as_float(t.y << 16);
-                            w[3] += __uint_as_float(t.y & 0xffff0000u);
-                        }
-                        *reinterpret_cast<uint2*>(yp + g * 4) = make_uint2(pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]));
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q)
-                            if (n + q < a.N)
-                                yp[g * 4 + q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[g * 4 + q]) + w[q] : w[q]);
-                    }
+                    for (int q = 0; q < 4; ++q)
+                        if (n + q < a.N) yp[g * 4 + q] = f32_to_bf16(a.accum ? bf16_to_f32(yp[g * 4 + q]) + w[q] : w[q]);
                 }
             }
         }
@@ -224,7 +303,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
 // forward / data-gradient kernel
 // ------------------------------------------------------------------------------------------------
 template <typename T, int BN, bool ALIGNED, int MODE, int ABL = 0>   // ABL: tuning ablations (tools/bench_conv.py)
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) {
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_kernel(const ConvArgs a) {
     constexpr int BM = 128;
     constexpr int VEC = Elem<T>::VEC;
     constexpr int KV = BK / VEC;                 // 16-byte chunks per tile row
@@ -512,7 +591,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_kernel(const ConvArgs a) 
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
-    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+    conv_epilogue<T, NT, MT, MODE>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
     if constexpr (ABL == 3) {
         uint64_t t_end;
         asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_end)::"memory");
@@ -672,7 +751,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
-    conv_epilogue<T, NT, MT>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+    conv_epilogue<T, NT, MT, MODE>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1159,6 +1238,19 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if (d->stats && d->bias) return DML_EINVAL;
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.stats = d->stats; a.dbg = nullptr;
+    a.bnr_y = nullptr; a.bnr_mask = nullptr; a.bnr_mean = nullptr; a.bnr_invstd = nullptr; a.bnr_partials = nullptr;
+    a.bnr_ldy = 0; a.bnr_relu = 0;
+    if (d->bnr_partials) {
+        // fused BN-backward reduce: data-gradient mode, bf16 result stored as 16-byte vectors, 8-channel mask bytes
+        if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || !d->bnr_y || !d->bnr_mean || !d->bnr_invstd ||
+            (d->bnr_relu && !d->bnr_mask))
+            return DML_EINVAL;
+        if (d->N % 8 || d->ldy % 8 || d->bnr_ldy % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
+            (reinterpret_cast<uintptr_t>(d->bnr_y) & 15) || (reinterpret_cast<uintptr_t>(d->bnr_partials) & 15) || d->N <= 32)
+            return DML_EUNSUPPORTED;
+        a.bnr_y = d->bnr_y; a.bnr_mask = d->bnr_mask; a.bnr_mean = d->bnr_mean; a.bnr_invstd = d->bnr_invstd;
+        a.bnr_partials = d->bnr_partials; a.bnr_ldy = d->bnr_ldy; a.bnr_relu = d->bnr_relu;
+    }
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
     a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
@@ -1187,6 +1279,8 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.div_wo = make_fastdiv((uint32_t)d->Wo); a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
     a.dbg = const_cast<float*>(d->pre_scale);
+    a.bnr_y = nullptr; a.bnr_mask = nullptr; a.bnr_mean = nullptr; a.bnr_invstd = nullptr; a.bnr_partials = nullptr;
+    a.bnr_ldy = 0; a.bnr_relu = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);

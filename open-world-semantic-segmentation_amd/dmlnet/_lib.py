@@ -28,7 +28,10 @@ class ConvDesc(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
                 ("pad", C.c_int32), ("dtype", C.c_int32), ("y_f32", C.c_int32), ("accum", C.c_int32),
-                ("mode", C.c_int32), ("pre_relu", C.c_int32)]
+                ("mode", C.c_int32), ("pre_relu", C.c_int32),
+                # mode 1: fused BN-backward partial sums of the tensor being written (see the header)
+                ("bnr_y", c_p), ("bnr_mask", c_p), ("bnr_mean", c_p), ("bnr_invstd", c_p), ("bnr_partials", c_p),
+                ("bnr_ldy", C.c_int32), ("bnr_relu", C.c_int32)]
 
 
 class WgradDesc(C.Structure):

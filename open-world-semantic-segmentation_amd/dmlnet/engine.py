@@ -217,6 +217,8 @@ class Plan:
         self.side = {}                 # backward op index -> True if it must first wait for the main stream
         self._side_events = None
         self.drop_units = []
+        self.last_dgrad = {}           # gradient buffer address -> ConvDesc of the data gradient that wrote it last
+        self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
         # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
         # of this network; backward: <= ~1100*N*2)
         self.scratch = torch.empty(max(B * H * W // 2 + 16384, 1100 * 2048 * 2 + 65536), dtype=torch.float32,
@@ -296,6 +298,9 @@ class Plan:
         x.root.grad_init = True
         self.keep.append(dsc)
         self.call(self.bwd, self.lib.dml_conv_igemm, C.byref(dsc))
+        self.last_dgrad.pop(self.grad_of(x.root).ptr, None)
+        if x is x.root:
+            self.last_dgrad[gx.ptr] = dsc         # whole-tensor gradient: candidate for the fused BN-backward reduce
 
     def conv_wgrad(self, x: Act, dy: Act, conv: nn.Conv2d, Cp: int):
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
@@ -373,10 +378,29 @@ class Plan:
         nblk = C.c_int(0)
         self.keep.append(nblk)
         mk = u.mask.data_ptr() if u.mask is not None else None
-        a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, mk, u.mean.data_ptr(),
-                       u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if u.relu else 0, 1.0,
-                       self.dt, C.byref(nblk))
-        self.call(self.bwd, lib.dml_bn_bwd_finalize, self.sp, nblk, M, N, bn.weight.data_ptr(),
+        # The data gradient that wrote dz last can emit this BN's backward sums from its epilogue (DmlConvDesc.bnr_*):
+        # one pass over dz / y / mask less.  Conditions: it wrote the whole tensor, bf16 with the 1-bit ReLU mask,
+        # no dropout scale, few enough 64-row groups for the single-kernel finalize.
+        G = (M + STAT_ROWS - 1) // STAT_ROWS
+        prod = self.last_dgrad.get(dz.ptr) if (self.fuse_bn_reduce and u.z is u.z.root) else None
+        fused = (prod is not None and self.dtype == torch.bfloat16 and (u.mask is not None or not u.relu)
+                 and u.drop is None and N % 8 == 0 and N > 32 and G <= 4096 and prod.N == N and prod.ldy == N
+                 and dz.ld == N and prod.y == dz.ptr)
+        a1 = None
+        if fused:
+            part = self.fbuf(G * N * 2)
+            prod.bnr_y, prod.bnr_mask = u.y.ptr, mk
+            prod.bnr_mean, prod.bnr_invstd = u.mean.data_ptr(), u.invstd.data_ptr()
+            prod.bnr_partials, prod.bnr_ldy, prod.bnr_relu = part.data_ptr(), u.y.ld, 1 if u.relu else 0
+            nblk = C.c_int(G)
+            self.keep.append(nblk)
+            sp = part.data_ptr()
+        else:
+            sp = self.sp
+            a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, mk, u.mean.data_ptr(),
+                           u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if u.relu else 0, 1.0,
+                           self.dt, C.byref(nblk))
+        self.call(self.bwd, lib.dml_bn_bwd_finalize, sp, nblk, M, N, bn.weight.data_ptr(),
                   u.mean.data_ptr(), u.invstd.data_ptr(), st.grad_ptr_of(bn.weight),
                   st.grad_ptr_of(bn.bias), coef.data_ptr())
         self.mark_grad(bn.weight)
@@ -385,7 +409,9 @@ class Plan:
                        dres.ptr if dres is not None else None, M, N, dz.ld, u.y.ld, u.z.ld, dy.ld,
                        dres.ld if dres is not None else 0, 1 if u.relu else 0, 1.0,
                        1 if dres_accum else 0, self.dt)
-        u.gscale_slots += [(a1, 13), (a3, 15)]
+        u.gscale_slots += ([(a1, 13)] if a1 is not None else []) + [(a3, 15)]
+        if dres is not None:
+            self.last_dgrad.pop(dres.ptr, None)   # written by the BN kernel, not by a data gradient
         self.conv_wgrad(u.x, dy, u.conv, u.Cp)
         if need_dgrad:
             self.conv_dgrad(dy, u.conv, u.wt, u.x)
@@ -502,6 +528,7 @@ class Plan:
             self.unit_bwd(branches[i], dcat1.slice(256 * i, 256))       # -> d out (accumulating)
         self.call(self.bwd, lib.dml_avgpool_bwd_add, self.grad_of(pooled).ptr, self.grad_of(out).ptr, B,
                   out.H * out.W, out.C, self.grad_of(out).ld, self.dt)
+        self.last_dgrad.pop(self.grad_of(out).ptr, None)      # not a data gradient: layer4's last BN keeps its own reduce
         # low-level projection -> d low (layer1 output)
         self.unit_bwd(up_low, dcat2.slice(0, 48))
         # bottlenecks in reverse

@@ -202,6 +202,51 @@ def test_conv_wgrad_large_tile(lib, case):
         relclose(dw.cpu().permute(0, 3, 1, 2) - 1.0, w.grad[:, :cm], 2e-3, "wgrad large tile %s splitk=%d" % (name, sk))
 
 
+@pytest.mark.parametrize("accum,relu", [(0, 1), (1, 1), (1, 0)])
+def test_dgrad_emits_bn_backward_partials(lib, accum, relu):
+    """DmlConvDesc.bnr_*: the data gradient's epilogue writes the BN-backward sums of the tensor it stores; they must
+    equal what dml_bn_bwd_reduce computes from that stored tensor (same bf16-rounded values), incl. a ragged last
+    64-row group and the accumulate path."""
+    B, Hh, Ww, Cin, Cout, k = 2, 13, 11, 128, 64, 3          # dgrad output: M = 286 rows (4.47 groups) x 128 channels
+    M = B * Hh * Ww
+    gy = qz(rnd("bnr.gy", (B, Cout, Hh, Ww)), torch.bfloat16)
+    w = qz(rnd("bnr.w", (Cout, Cin, k, k), scale=0.05), torch.bfloat16)
+    gyd = nhwc(gy, torch.bfloat16)
+    wt = w.permute(1, 2, 3, 0).contiguous().to("cuda", torch.bfloat16)          # wt[Cin][R][S][Cout]
+    dx = (torch.randn(B, Hh, Ww, Cin, device="cuda") * 0.3).to(torch.bfloat16) if accum else \
+        torch.empty(B, Hh, Ww, Cin, device="cuda", dtype=torch.bfloat16)
+    ybn = (torch.randn(M, Cin, device="cuda") * 1.5 + 0.3).to(torch.bfloat16)
+    bits = torch.randint(0, 256, (M * Cin // 8,), device="cuda", dtype=torch.uint8)
+    mean, invstd = torch.randn(Cin, device="cuda") * 0.2, torch.rand(Cin, device="cuda") + 0.5
+    G = (M + 63) // 64
+    part = torch.full((G * Cin * 2,), 7.0, device="cuda")
+    d = make_desc(lib, gyd, wt, dx, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, 1, 1, 1, mode=1, accum=accum)
+    d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    d.bnr_partials, d.bnr_ldy, d.bnr_relu = part.data_ptr(), Cin, relu
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    # reference: the stand-alone reduce on the tensor the conv stored
+    part2 = torch.zeros(4096 * Cin * 2, device="cuda")
+    nb = C.c_int(0)
+    chk(lib.dml_bn_bwd_reduce(dx.data_ptr(), ybn.data_ptr(), None, bits.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                              part2.data_ptr(), M, Cin, Cin, Cin, Cin, relu, 1.0, 1, C.byref(nb), st()))
+    torch.cuda.synchronize()
+    a = part.view(G, Cin, 2).double().sum(0)
+    b = part2[: nb.value * Cin * 2].view(nb.value, Cin, 2).double().sum(0)
+    relclose(a[:, 0].cpu(), b[:, 0].cpu(), 2e-6, "sum g")
+    relclose(a[:, 1].cpu(), b[:, 1].cpu(), 2e-6, "sum g xhat")
+    # and per group against torch on the stored values
+    g = dx.view(M, Cin).float()
+    if relu:
+        mk = ((bits.view(M, Cin // 8, 1) >> torch.arange(8, device="cuda").view(1, 1, 8)) & 1).reshape(M, Cin).float()
+        g = g * mk
+    xh = (ybn.float() - mean) * invstd
+    pad = G * 64 - M
+    gp = torch.cat([g, torch.zeros(pad, Cin, device="cuda")]).view(G, 64, Cin)
+    xp = torch.cat([xh, torch.zeros(pad, Cin, device="cuda")]).view(G, 64, Cin)
+    ref = torch.stack([gp.sum(1), (gp * xp).sum(1)], dim=-1)
+    relclose(part.view(G, Cin, 2).cpu(), ref.cpu(), 1e-5, "per-group partials")
+
+
 def test_conv_bias_f32_out_and_slices(lib):
     """Final 1x1 with bias writing fp32 from bf16 operands; producer writing into a concat-buffer slice."""
     B, Hh, Ww, Cin, K = 2, 6, 5, 256, 16
