@@ -423,7 +423,10 @@ def main():
                            "flops_per_step": flops, "launches_per_step": n_launch,
                            "avg_launch_ms": conv_sec / n_launch * 1e3, "conv_ms_per_step": conv_sec * 1e3,
                            "igemm_ms_per_step": tsec["igemm"] * 1e3, "wgrad_ms_per_step": tsec["wgrad"] * 1e3,
-                           "whole_step_frac": flops / (elapsed / args.steps) / peak}
+                           "whole_step_frac": flops / (elapsed / args.steps) / peak,
+                           "note": "data-gradient launches also compute the BatchNorm-backward sums of the tensor they "
+                                   "write (88 of 112 bn_bwd_reduce launches folded into their epilogues); their time is "
+                                   "charged to the convolutions here"}
         out["hbm_kernel"] = bench_distance_kernel(args.batch, args.size, device)
         out["input_pipeline"] = bench_input_pipeline(args.batch, args.size, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
