@@ -9,10 +9,14 @@ import helpers as H
 import network, utils
 
 shape, seed = (2, 3, 64, 96), 9
+if os.environ.get("DBG_SHAPE"):
+    shape = tuple(int(v) for v in os.environ["DBG_SHAPE"].split(","))
+    seed = int(os.environ.get("DBG_SEED", "9"))
 dtype = torch.bfloat16 if (len(sys.argv) > 1 and sys.argv[1] == "bf16") else torch.float32
 torch.set_num_threads(32)
-img = H.synth_tensor(9, "fresh.img", shape)
-lab = H.synth_labels(9, "fresh.lab", (shape[0],) + shape[2:], 16, 255, ignore_frac=0.05)
+tag = os.environ.get("DBG_TAG", "fresh")
+img = H.synth_tensor(seed, tag + ".img", shape)
+lab = H.synth_labels(seed, tag + ".lab", (shape[0],) + shape[2:], 16, 255, ignore_frac=0.05)
 m = network.deeplabv3plus_embedding_resnet101(16, 16, False)
 m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=seed))
 m.cuda().train(); m.classifier.aspp.project[3].eval(); m.set_compute_dtype(dtype)
