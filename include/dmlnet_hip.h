@@ -72,6 +72,15 @@ typedef struct DmlConvDesc {
     const float* bnr_invstd;
     float* bnr_partials;
     int32_t bnr_ldy, bnr_relu;
+    /* mode 0 only, optional: inference epilogue -- y = act((conv - post_mean) * post_scale + post_shift [+ post_res]),
+     * i.e. BatchNorm with running statistics (dml_bn_eval_coeffs gives scale / shift, post_mean = running_mean),
+     * the bottleneck's residual add (resnet.py:110-113) and ReLU applied to the fp32 accumulators, so the
+     * pre-normalisation tensor is never written.  post_res [M][N] has the storage dtype and pitch post_ldres. */
+    const float* post_scale;
+    const float* post_shift;
+    const float* post_mean;
+    const void* post_res;
+    int32_t post_ldres, post_relu;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
@@ -133,6 +142,12 @@ int dml_bn_stats(const void* y, float* partials, int64_t M, int N, int ldy, int 
 int dml_bn_eval_coeffs(const float* gamma, const float* beta, const float* running_mean,
                        const float* running_var, float eps, float* scale, float* shift, int N,
                        void* stream);
+/* the same for a whole network in one launch: `table` is a DEVICE array of `count` descriptors */
+typedef struct DmlBnEvalDesc {
+    const float* gamma; const float* beta; const float* running_var; float* scale; float* shift;
+    int32_t N; float eps;
+} DmlBnEvalDesc;
+int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, void* stream);
 /* z = act((y - mean)*scale + shift [+ res]) with optional inverted dropout (network/utils.py:354).
  * y, res, z have independent pitches.  `mask` (optional, DML_BF16 only): one bit per element, z > 0, packed as
  * mask[m*(N/8) + c/8] bit c%8 -- the backward passes then read 1 byte instead of 16 bytes of z. */

@@ -108,6 +108,15 @@ __global__ void bn_eval_coeffs_kernel(const float* gamma, const float* beta, con
     shift[n] = beta ? beta[n] : 0.f;          // z = (y - running_mean) * scale + shift
 }
 
+__global__ __launch_bounds__(256) void bn_eval_coeffs_table_kernel(const DmlBnEvalDesc* __restrict__ table) {
+    const DmlBnEvalDesc d = table[blockIdx.x];
+    for (int n = threadIdx.x; n < d.N; n += 256) {
+        const float invstd = 1.0f / sqrtf(d.running_var[n] + d.eps);
+        d.scale[n] = (d.gamma ? d.gamma[n] : 1.f) * invstd;
+        d.shift[n] = d.beta ? d.beta[n] : 0.f;
+    }
+}
+
 __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t thresh) {
     uint64_t h = seed + idx * 0x9E3779B97F4A7C15ull;
     h ^= h >> 30; h *= 0xBF58476D1CE4E5B9ull;
@@ -504,6 +513,13 @@ extern "C" int dml_bn_eval_coeffs(const float* gamma, const float* beta, const f
     hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((N + 255) / 256), dim3(256), 0,
                        static_cast<hipStream_t>(stream), gamma, beta, running_mean, running_var, eps, scale,
                        shift, N);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, void* stream) {
+    if (!table || count <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(bn_eval_coeffs_table_kernel, dim3(count), dim3(256), 0, static_cast<hipStream_t>(stream), table);
     DML_LAUNCH_CHECK();
     return 0;
 }

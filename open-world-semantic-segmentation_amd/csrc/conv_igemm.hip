@@ -42,6 +42,12 @@ struct ConvArgs {
     const float* bnr_invstd;
     float* bnr_partials;
     int bnr_ldy, bnr_relu;
+    // forward mode: inference epilogue (DmlConvDesc::post_*)
+    const float* post_scale;
+    const float* post_shift;
+    const float* post_mean;
+    const void* post_res;
+    int post_ldres, post_relu;
 };
 
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
@@ -161,11 +167,20 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
             // stored -- exactly what dml_bn_bwd_reduce would compute from the stored tensor -- so the separate pass
             // over dz / y / mask disappears.
             const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
+            const bool post = MODE == 0 && a.post_scale != nullptr;
 #pragma unroll
             for (int g = 0; g < CL / 8; ++g) {
                 const int n8 = nl + g * 8;
                 if (n8 >= a.N) continue;
-                float r1[8], r2[8], rmu[8], ris[8];
+                float r1[8], r2[8], rmu[8], ris[8];      // MODE 1: BN-backward sums; MODE 0: inference BN coefficients
+                if (post) {
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) {
+                        r1[e] = a.post_scale[n8 + e];
+                        r2[e] = a.post_shift[n8 + e];
+                        rmu[e] = a.post_mean[n8 + e];
+                    }
+                }
                 if (bnr) {
 #pragma unroll
                     for (int e = 0; e < 8; ++e) {
@@ -186,7 +201,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                     ty[j] = make_uint4(0, 0, 0, 0);
                     bits[j] = 0xffu;
                     if (m < a.M) {
-                        if (a.accum)
+                        if (post && a.post_res != nullptr)
+                            told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.post_res) +
+                                                                      (int64_t)m * a.post_ldres + n8);
+                        else if (a.accum)
                             told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.y) + (int64_t)m * a.ldy + n8);
                         if (bnr) {
                             ty[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.bnr_y) +
@@ -202,6 +220,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                     float w[8];
 #pragma unroll
                     for (int e = 0; e < 8; ++e) w[e] = acc[(g * 8 + e) >> 2][j][e & 3] + bv[g * 8 + e];
+                    if (post) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w[e] = (w[e] - rmu[e]) * r1[e] + r2[e];
+                    }
                     bf16_t* yp = static_cast<bf16_t*>(a.y) + (int64_t)m * a.ldy + n8;
                     {
                         const uint32_t tt[4] = {told[j].x, told[j].y, told[j].z, told[j].w};      // zeros unless accumulating
@@ -210,6 +232,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                             w[2 * e] += __uint_as_float(tt[e] << 16);
                             w[2 * e + 1] += __uint_as_float(tt[e] & 0xffff0000u);
                         }
+                    }
+                    if (post && a.post_relu) {
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) w[e] = w[e] > 0.f ? w[e] : 0.f;
                     }
                     const uint32_t pk[4] = {pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
                                             pack_bf16x2(w[6], w[7])};
@@ -253,6 +279,16 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[i * 4 + q] = acc[i][j][q] + bv[i * 4 + q];
+        if (MODE == 0 && a.post_scale != nullptr) {          // inference epilogue on the generic path (fp32, odd shapes)
+#pragma unroll
+            for (int c = 0; c < CL; ++c) {
+                if (nl + c >= a.N) continue;
+                float t = (v[c] - a.post_mean[nl + c]) * a.post_scale[nl + c] + a.post_shift[nl + c];
+                if (a.post_res != nullptr)
+                    t += Elem<T>::ld(static_cast<const T*>(a.post_res) + (int64_t)m * a.post_ldres + nl + c);
+                v[c] = a.post_relu ? (t > 0.f ? t : 0.f) : t;
+            }
+        }
         const int64_t off = (int64_t)m * a.ldy + nl;
         if (out_f32) {
             float* yp = static_cast<float*>(a.y) + off;
@@ -1240,6 +1276,14 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.stats = d->stats; a.dbg = nullptr;
     a.bnr_y = nullptr; a.bnr_mask = nullptr; a.bnr_mean = nullptr; a.bnr_invstd = nullptr; a.bnr_partials = nullptr;
     a.bnr_ldy = 0; a.bnr_relu = 0;
+    a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
+    a.post_relu = 0;
+    if (d->post_scale) {
+        if (d->mode != 0 || !d->post_shift || !d->post_mean || d->stats || d->bias || d->accum || d->y_f32) return DML_EINVAL;
+        if (d->post_res && (d->post_ldres % vec || (reinterpret_cast<uintptr_t>(d->post_res) & 15))) return DML_EALIGN;
+        a.post_scale = d->post_scale; a.post_shift = d->post_shift; a.post_mean = d->post_mean; a.post_res = d->post_res;
+        a.post_ldres = d->post_ldres; a.post_relu = d->post_relu;
+    }
     if (d->bnr_partials) {
         // fused BN-backward reduce: data-gradient mode, bf16 result stored as 16-byte vectors, 8-channel mask bytes
         if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || !d->bnr_y || !d->bnr_mean || !d->bnr_invstd ||
@@ -1281,6 +1325,8 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.dbg = const_cast<float*>(d->pre_scale);
     a.bnr_y = nullptr; a.bnr_mask = nullptr; a.bnr_mean = nullptr; a.bnr_invstd = nullptr; a.bnr_partials = nullptr;
     a.bnr_ldy = 0; a.bnr_relu = 0;
+    a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
+    a.post_relu = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -31,7 +31,15 @@ class ConvDesc(C.Structure):
                 ("mode", C.c_int32), ("pre_relu", C.c_int32),
                 # mode 1: fused BN-backward partial sums of the tensor being written (see the header)
                 ("bnr_y", c_p), ("bnr_mask", c_p), ("bnr_mean", c_p), ("bnr_invstd", c_p), ("bnr_partials", c_p),
-                ("bnr_ldy", C.c_int32), ("bnr_relu", C.c_int32)]
+                ("bnr_ldy", C.c_int32), ("bnr_relu", C.c_int32),
+                # mode 0: inference epilogue BN(running stats) + residual + ReLU (see the header)
+                ("post_scale", c_p), ("post_shift", c_p), ("post_mean", c_p), ("post_res", c_p),
+                ("post_ldres", C.c_int32), ("post_relu", C.c_int32)]
+
+
+class BnEvalDesc(C.Structure):
+    _fields_ = [("gamma", c_p), ("beta", c_p), ("running_var", c_p), ("scale", c_p), ("shift", c_p),
+                ("N", C.c_int32), ("eps", C.c_float)]
 
 
 class WgradDesc(C.Structure):
@@ -66,6 +74,7 @@ _PROTOS = {
     "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
+    "dml_bn_eval_coeffs_table": (c_i, [c_p, c_i, c_p]),
     "dml_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.c_uint64, c_p]),
     "dml_bn_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_f, c_i,
                                 C.POINTER(c_i), c_p]),

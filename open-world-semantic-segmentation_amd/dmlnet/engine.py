@@ -277,13 +277,18 @@ class Plan:
                           Cm, Cp))
         return w, wt
 
-    def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None):
+    def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None, post=None):
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         assert (Ho, Wo) == (y.H, y.W), ((Ho, Wo), (y.H, y.W))
         dsc = ConvDesc(x=x.ptr, w=w.data_ptr(), y=y.ptr, bias=bias_ptr, stats=stats_ptr, pre_scale=None,
                        pre_shift=None, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
                        N=conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
                        y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
+        if post is not None:            # inference epilogue: BN(running stats) + residual + ReLU (DmlConvDesc.post_*)
+            scale, shift, mean, res, relu = post
+            dsc.post_scale, dsc.post_shift, dsc.post_mean = scale.data_ptr(), shift.data_ptr(), mean.data_ptr()
+            dsc.post_res, dsc.post_ldres = (res.ptr, res.ld) if res is not None else (None, 0)
+            dsc.post_relu = 1 if relu else 0
         self.keep.append(dsc)
         self.call(self.fwd, self.lib.dml_conv_igemm, C.byref(dsc))
 
@@ -332,9 +337,9 @@ class Plan:
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         N = conv.out_channels
         u.w, u.wt = self.prep_weight(conv, u.Cp, self.training and need_dgrad)
-        u.y = self.new(x.B, Ho, Wo, N)
         u.z = out if out is not None else self.new(x.B, Ho, Wo, N)
-        M = u.y.M
+        u.y = self.new(x.B, Ho, Wo, N) if self.training else None      # inference never materialises it
+        M = u.z.M
         u.scale, u.shift = self.fbuf(N), self.fbuf(N)
         g_ptr, b_ptr = bn.weight.data_ptr(), bn.bias.data_ptr()
         mean_ptr = bn.running_mean.data_ptr()
@@ -349,9 +354,14 @@ class Plan:
                              u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr())
             self.momentum_slots.append((args, 7, bn))
         else:
-            self.conv_fwd(x, conv, u.y, u.w, None)
-            self.call(self.fwd, lib.dml_bn_eval_coeffs, g_ptr, b_ptr, bn.running_mean.data_ptr(),
-                      bn.running_var.data_ptr(), float(bn.eps), u.scale.data_ptr(), u.shift.data_ptr(), N)
+            # inference: scale / shift of every BN come from ONE table launch at the head of the plan, and BN +
+            # residual + ReLU run in the conv epilogue -- one launch per unit instead of three, no y tensor
+            self.bn_eval.append(_lib.BnEvalDesc(g_ptr, b_ptr, bn.running_var.data_ptr(), u.scale.data_ptr(),
+                                                u.shift.data_ptr(), N, float(bn.eps)))
+            self.conv_fwd(x, conv, u.z, u.w, None, post=(u.scale, u.shift, bn.running_mean, res, relu))
+            u.gscale_slots, u.mask, u.apply_args = [], None, None
+            self.units.append(u)
+            return u
         u.gscale_slots = []
         # ReLU bitmask (bf16 training): the two BN backward passes read 1 byte per 8 elements instead of z
         u.mask = None
@@ -432,6 +442,9 @@ class Plan:
                 raise NotImplementedError("BatchNorm2d modules in a different mode than the model (fix_bn) are not "
                                           "supported on the MI355X path")
 
+        self.bn_eval = []
+        if not self.training:
+            self.bn_eval_args = self.call(self.fwd, lib.dml_bn_eval_coeffs_table, 0, 0)      # filled in below
         # input packing NCHW fp32 -> NHWC (8 ch)
         x_in = self.new(B, H, W, _PAD_CIN)
         self.images_args = self.call(self.fwd, lib.dml_pack_input, 0, x_in.ptr, B, 3, H, W, _PAD_CIN, self.dt)
@@ -496,6 +509,9 @@ class Plan:
         self.head_args = self.call(self.fwd, lib.dml_upsample_dist_fwd, emb.ptr, self.protos.data_ptr(), 0, 0,
                                    None, None, B, emb.H, emb.W, K, K, H, W)
         if not self.training:
+            arr = (_lib.BnEvalDesc * len(self.bn_eval))(*self.bn_eval)
+            self.bn_eval_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self.bn_eval_args[0], self.bn_eval_args[1] = self.bn_eval_table.data_ptr(), len(self.bn_eval)
             return
 
         # ------------------------------------------------------------------ backward

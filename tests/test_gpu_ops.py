@@ -247,6 +247,44 @@ def test_dgrad_emits_bn_backward_partials(lib, accum, relu):
     relclose(part.view(G, Cin, 2).cpu(), ref.cpu(), 1e-5, "per-group partials")
 
 
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+@pytest.mark.parametrize("res,relu,Cout", [(True, 1, 128), (False, 1, 48), (False, 0, 64)])
+def test_conv_inference_epilogue(lib, dname, res, relu, Cout):
+    """DmlConvDesc.post_*: conv + BatchNorm(running stats) + residual + ReLU in one launch vs torch (eval mode);
+    scale / shift from the table form of dml_bn_eval_coeffs."""
+    from dmlnet._lib import BnEvalDesc
+    dt, tdt, tol = DT[dname]
+    B, Hh, Ww, Cin, k = 2, 9, 7, 64, 3
+    x = qz(rnd("post.x", (B, Cin, Hh, Ww)), tdt)
+    w = qz(rnd("post.w", (Cout, Cin, k, k), scale=0.05), tdt)
+    r = qz(rnd("post.r", (B, Cout, Hh, Ww)), tdt) if res else None
+    gamma, beta = rnd("post.g", (Cout,)) * 0.2 + 1, rnd("post.b", (Cout,)) * 0.1
+    rm, rv = rnd("post.rm", (Cout,)) * 0.1, rnd("post.rv", (Cout,)).abs() + 0.5
+    ref = F.batch_norm(F.conv2d(x, w, padding=1), rm, rv, gamma, beta, training=False, eps=1e-5)
+    if res:
+        ref = ref + r
+    if relu:
+        ref = F.relu(ref)
+    xd, wd = nhwc(x, tdt), w.permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
+    rd = nhwc(r, tdt) if res else None
+    g_d, b_d, rm_d, rv_d = gamma.cuda(), beta.cuda(), rm.cuda(), rv.cuda()
+    sc, sh = torch.empty(Cout, device="cuda"), torch.empty(Cout, device="cuda")
+    tab = (BnEvalDesc * 1)(BnEvalDesc(g_d.data_ptr(), b_d.data_ptr(), rv_d.data_ptr(), sc.data_ptr(), sh.data_ptr(), Cout, 1e-5))
+    tab_d = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).cuda()
+    chk(lib.dml_bn_eval_coeffs_table(tab_d.data_ptr(), 1, st()))
+    z = torch.empty((B, Hh, Ww, Cout), device="cuda", dtype=tdt)
+    d = make_desc(lib, xd, wd, z, B, Hh, Ww, Cin, Hh, Ww, Cout, k, 1, 1, 1, dt)
+    d.post_scale, d.post_shift, d.post_mean = sc.data_ptr(), sh.data_ptr(), rm_d.data_ptr()
+    if res:
+        d.post_res, d.post_ldres = rd.data_ptr(), Cout
+    else:
+        d.post_res, d.post_ldres = None, 0
+    d.post_relu = relu
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    torch.cuda.synchronize()
+    relclose(nchw(z), qz(ref, tdt) if dname == "bf16" else ref, max(tol, 1e-5) if dname == "f32" else 1e-2, "conv+bn+res+relu")
+
+
 def test_conv_bias_f32_out_and_slices(lib):
     """Final 1x1 with bias writing fp32 from bf16 operands; producer writing into a concat-buffer slice."""
     B, Hh, Ww, Cin, K = 2, 6, 5, 256, 16
