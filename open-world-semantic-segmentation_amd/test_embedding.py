@@ -49,21 +49,37 @@ def main():
         proto = utils.mean_prototype(json.load(open(o.prototype_json)))                 # :245-258
     else:
         proto = np.full((o.num_classes,), 0.1)
+    import anom_utils
+    import metrics as metrics_mod
+    seg_metrics = metrics_mod.StreamSegMetrics(o.num_classes + 1)                      # 16 known classes + the novel one
+    aurocs, auprs, fprs = [], [], []
     n, t0 = 0, None
     with torch.no_grad():
         for i in range(rank, o.num_images, world):
             g = torch.Generator().manual_seed(4321 + i)
             img = torch.randn(1, 3, o.height, o.width, generator=g).to(dev)
+            # synthetic ground truth: blocky train ids, one block-class plays the unknown object (label num_classes)
+            coarse = torch.randint(0, o.num_classes + 1, (1, (o.height + 63) // 64, (o.width + 63) // 64), generator=g)
+            target = coarse.repeat_interleave(64, 1).repeat_interleave(64, 2)[:, :o.height, :o.width].contiguous().to(dev)
             outputs, centers, features = model(img)                                     # :337
             preds, msp = utils.argmax_msp(outputs)                                      # :339-342
             score = utils.dissum_score(outputs, clip=1000.0, inclusive=False)           # :349-350,365
             preds = utils.novel_relabel(preds, outputs, features, proto, -1.5, o.num_classes)   # :428-445
+            seg_metrics.update(target, preds)                                           # :455 (metrics.update), on the device
+            # pixel-level OOD measures of the anomaly score (eval_ood_traditional.py:128-148; the reference's `conf`
+            # is a confidence, i.e. minus the anomaly score)
+            res = anom_utils.eval_ood_measure(-score.reshape(-1).float(), target.reshape(-1), [o.num_classes])
+            if res is not None:
+                aurocs.append(res[0]); auprs.append(res[1]); fprs.append(res[2])
             if t0 is None:
                 torch.cuda.synchronize()
                 t0 = time.perf_counter()
             else:
                 n += 1
     torch.cuda.synchronize()
+    if aurocs and rank == 0:
+        print(seg_metrics.to_str(seg_metrics.get_results()))
+        anom_utils.print_measures(float(np.mean(aurocs)), float(np.mean(auprs)), float(np.mean(fprs)), "dissum")
     if n:
         print("rank %d: %.2f img/s at %dx%d (%d novel-class pixels in the last image, score mean %.4f)"
               % (rank, n / (time.perf_counter() - t0), o.height, o.width, int((preds == o.num_classes).sum()),
