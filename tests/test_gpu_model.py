@@ -140,6 +140,40 @@ def test_g5b_eval_forward_config1():
     assert torch.equal(ctr.cpu(), T(g["centers"]))
 
 
+@pytest.mark.parametrize("shape", [(1, 3, 65, 97), (3, 3, 50, 34)])
+def test_odd_input_sizes_eval_and_train_forward(shape):
+    """Sizes that are no multiple of the output stride (ragged tiles everywhere, odd bilinear ratios): eval forward with
+    calibrated running statistics, and the train-mode forward, against the fp64 oracle."""
+    from oracle import dmlnet_ref as O
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    img = H.synth_tensor(31, "odd.img", shape)
+    o = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    o.load_state_dict(H.synth_state_dict(H.shapes_of(o), seed=31))
+    o = o.double()
+    o.train()
+    o.classifier.aspp.project[3].eval()
+    if shape[0] > 1:
+        m = build(seed=31)
+        with torch.no_grad():
+            lg, _, ft = m(img.cuda())
+            olg, _, oft = o(img.double())
+        relclose(lg, olg, TOL, "train-mode logits, odd size")
+        relclose(ft, oft, TOL, "train-mode features, odd size")
+    # calibrate running statistics with a few train-mode passes of the oracle, then compare eval mode
+    cal = H.synth_tensor(32, "odd.cal", (4, 3, shape[2], shape[3]))
+    with torch.no_grad():
+        for _ in range(3):
+            o(cal.double())
+    o.eval()
+    m = build(train=False, seed=31)
+    m.load_state_dict({k: v.float() for k, v in o.state_dict().items()})
+    with torch.no_grad():
+        lg, _, ft = m(img.cuda())
+        olg, _, oft = o(img.double())
+    relclose(lg, olg, TOL, "eval logits, odd size")
+    relclose(ft, oft, TOL, "eval features, odd size")
+
+
 def test_against_oracle_fresh_input_all_param_grads():
     """Non-square input, DML loss with the variance term: every parameter gradient.
 
