@@ -7,9 +7,11 @@
 // Replaces nn.Conv2d at network/backbone/resnet.py:24-32,139 and network/utils.py:11-23,311,322,
 // 337-352 of the reference (cuDNN there).  Layout NHWC / KRSC so that the GEMM K dimension is
 // contiguous in both operands; 128-row pixel tiles; bf16 (v_mfma_f32_16x16x32_bf16) or exact fp32
-// (v_mfma_f32_16x16x4_f32) with fp32 accumulation.  The MFMA "row" operand is the weight tile so
-// that every lane ends up with 4 consecutive output channels of one pixel (8/16-byte stores).
-// The epilogue can emit per-channel BatchNorm partial statistics straight from the accumulators.
+// (v_mfma_f32_16x16x4_f32) with fp32 accumulation.  The MFMA "row" operand is the weight tile, fed in a permuted
+// row order, so that every lane ends up with 16 consecutive output channels of one pixel (16-byte stores).
+// Epilogue options, all on the fp32 accumulators: per-channel BatchNorm partial statistics (training forward),
+// BatchNorm + residual + ReLU (inference), bias, accumulate, and -- data gradient -- the BN-backward partial sums
+// of the tensor being written.
 #include "common.h"
 #include <cstdlib>
 
