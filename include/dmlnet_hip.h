@@ -135,6 +135,22 @@ int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W
 int dml_bn_finalize(float* partials, int64_t M, int N, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
+/* Synchronised BatchNorm (statistics over all ranks' samples; anomaly/lib/nn/modules/batchnorm.py:56-139 of the
+ * reference -- biased variance for the normalisation, unbiased over the global count for the running estimate).
+ * The library stays collective-free: the caller all-gathers / all-reduces the small double buffers (RCCL).
+ *   forward : dml_bn_moments(partials -> moments[N][2] = (mean, M2) of this rank's M rows)
+ *             -> all_gather -> dml_bn_finalize_moments(moments[ranks][N][2], every rank holding M_each rows)
+ *   backward: dml_bn_bwd_sums(partials -> sums[N][2] = (sum g, sum g*xhat); dgamma/dbeta += the LOCAL sums)
+ *             -> all_reduce(sum) -> dml_bn_bwd_coef(sums, M_total) -> dml_bn_bwd_apply as usual. */
+int dml_bn_moments(float* partials, int64_t M, int N, double* moments, void* stream);
+int dml_bn_finalize_moments(const double* moments, int ranks, int64_t M_each, int N, const float* gamma,
+                            const float* beta, float* running_mean, float* running_var, float momentum,
+                            float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                            void* stream);
+int dml_bn_bwd_sums(const float* partials, int nblocks, int N, double* sums, float* dgamma, float* dbeta,
+                    void* stream);
+int dml_bn_bwd_coef(const double* sums, int64_t M_total, int N, const float* gamma, const float* save_mean,
+                    const float* save_invstd, float* coef, void* stream);
 /* Standalone statistics for tensors that were not produced by dml_conv_igemm (writes the same
  * partial format). */
 int dml_bn_stats(const void* y, float* partials, int64_t M, int N, int ldy, int dtype, void* stream);

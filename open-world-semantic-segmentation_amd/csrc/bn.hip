@@ -26,7 +26,7 @@ template <int FIN_CH, int FIN_SL>      // channels x group-slices per 256-thread
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ partials, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
-    float* scale, float* shift, float* save_mean, float* save_invstd) {
+    float* scale, float* shift, float* save_mean, float* save_invstd, double* moments_out) {
     __shared__ double sh[FIN_SL][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
@@ -60,6 +60,11 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
     for (int k = FIN_SL / 2; k > 0; k >>= 1) {
         if (sl < k) sh[sl][ch] += sh[sl + k][ch];
         __syncthreads();
+    }
+    if (sl == 0 && n < N && moments_out != nullptr) {       // synchronised BN: this rank's (mean, M2), merged later
+        moments_out[2 * n] = gmean;
+        moments_out[2 * n + 1] = sh[0][ch];
+        return;
     }
     if (sl == 0 && n < N) {
         const double mean = gmean, m2 = sh[0][ch], cnt = (double)M;
@@ -293,7 +298,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partials, int nblocks, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma, float* dbeta,
-    float* coef) {
+    float* coef, double* sums_out) {
     __shared__ double sh[2][FIN_SL][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
@@ -309,6 +314,13 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     for (int s = FIN_SL / 2; s > 0; s >>= 1) {
         if (sl < s) { sh[0][sl][ch] += sh[0][sl + s][ch]; sh[1][sl][ch] += sh[1][sl + s][ch]; }
         __syncthreads();
+    }
+    if (sl == 0 && n < N && sums_out != nullptr) {          // synchronised BN: local sums out, parameter gradients local
+        sums_out[2 * n] = sh[0][0][ch];
+        sums_out[2 * n + 1] = sh[1][0][ch];
+        if (dgamma) dgamma[n] += (float)sh[1][0][ch];
+        if (dbeta) dbeta[n] += (float)sh[0][0][ch];
+        return;
     }
     if (sl == 0 && n < N) {
         const double dbeta_s = sh[0][0][ch], dgamma_s = sh[1][0][ch];
@@ -488,7 +500,8 @@ extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, const float* g
                            gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     } else {
         hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, st, partials, M, N, gamma,
-                           beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+                           beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd,
+                           (double*)nullptr);
     }
     DML_LAUNCH_CHECK();
     return 0;
@@ -585,7 +598,88 @@ extern "C" int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M
     if (!partials || !save_mean || !save_invstd || !coef || nblocks <= 0 || N <= 0) return DML_EINVAL;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
                        static_cast<hipStream_t>(stream), partials, nblocks, M, N, gamma, save_mean, save_invstd,
-                       dgamma, dbeta, coef);
+                       dgamma, dbeta, coef, (double*)nullptr);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- synchronised BatchNorm (statistics over all ranks; anomaly/lib/nn/modules/batchnorm.py:56-139 of the reference,
+// SURVEY 8(e)/(f) rank 2).  The collectives themselves are the caller's (RCCL through torch.distributed):
+//   forward : dml_bn_moments -> all_gather of the [N][2] doubles -> dml_bn_finalize_moments
+//   backward: dml_bn_bwd_sums -> all_reduce(sum) of the [N][2] doubles -> dml_bn_bwd_coef
+namespace {
+__global__ __launch_bounds__(256) void bn_finalize_moments_kernel(
+    const double* __restrict__ moments, int R, int64_t M_each, int N, const float* __restrict__ gamma,
+    const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps, float* scale,
+    float* shift, float* save_mean, float* save_invstd) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    Moments t = {0.0, 0.0, 0.0};
+    for (int r = 0; r < R; ++r) merge(t, (double)M_each, moments[((int64_t)r * N + n) * 2], moments[((int64_t)r * N + n) * 2 + 1]);
+    const double var_b = t.m2 / t.n;
+    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+    scale[n] = (gamma ? gamma[n] : 1.f) * invstd;
+    shift[n] = beta ? beta[n] : 0.f;
+    save_mean[n] = (float)t.mean;
+    if (save_invstd) save_invstd[n] = invstd;
+    if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)t.mean;
+    if (running_var) {
+        const double var_u = t.n > 1.0 ? t.m2 / (t.n - 1.0) : var_b;      // unbiased over ALL ranks' samples (batchnorm.py:133-136)
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
+    }
+}
+__global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const double* __restrict__ sums, int64_t M_total, int N,
+                                                          const float* __restrict__ gamma,
+                                                          const float* __restrict__ save_mean,
+                                                          const float* __restrict__ save_invstd, float* __restrict__ coef) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const double dbeta_s = sums[2 * n], dgamma_s = sums[2 * n + 1];
+    const double g = gamma ? (double)gamma[n] : 1.0, is = save_invstd[n];
+    const double A = g * is;
+    coef[n] = (float)A;
+    coef[N + n] = (float)(-A * is * dgamma_s / (double)M_total);
+    coef[2 * N + n] = (float)(-A * dbeta_s / (double)M_total);
+    coef[3 * N + n] = save_mean[n];
+}
+}  // namespace
+
+extern "C" int dml_bn_moments(float* partials, int64_t M, int N, double* moments, void* stream) {
+    if (!partials || !moments || M <= 0 || N <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       partials, M, N, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
+                       0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, moments);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_finalize_moments(const double* moments, int ranks, int64_t M_each, int N, const float* gamma,
+                                       const float* beta, float* running_mean, float* running_var, float momentum,
+                                       float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
+                                       void* stream) {
+    if (!moments || !scale || !shift || !save_mean || ranks <= 0 || M_each <= 0 || N <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(bn_finalize_moments_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream),
+                       moments, ranks, M_each, N, gamma, beta, running_mean, running_var, momentum, eps, scale, shift,
+                       save_mean, save_invstd);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_bwd_sums(const float* partials, int nblocks, int N, double* sums, float* dgamma, float* dbeta,
+                               void* stream) {
+    if (!partials || !sums || nblocks <= 0 || N <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), partials, nblocks, (int64_t)1, N, (const float*)nullptr,
+                       (const float*)nullptr, (const float*)nullptr, dgamma, dbeta, (float*)nullptr, sums);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_bn_bwd_coef(const double* sums, int64_t M_total, int N, const float* gamma, const float* save_mean,
+                               const float* save_invstd, float* coef, void* stream) {
+    if (!sums || !save_mean || !save_invstd || !coef || M_total <= 0 || N <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((N + 255) / 256), dim3(256), 0, static_cast<hipStream_t>(stream), sums,
+                       M_total, N, gamma, save_mean, save_invstd, coef);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -72,6 +72,10 @@ _PROTOS = {
     "dml_bias_grad": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_pack_input": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "dml_bn_moments": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    "dml_bn_finalize_moments": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "dml_bn_bwd_sums": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
+    "dml_bn_bwd_coef": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
     "dml_bn_eval_coeffs_table": (c_i, [c_p, c_i, c_p]),

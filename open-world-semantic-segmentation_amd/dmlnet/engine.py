@@ -19,6 +19,7 @@ import os
 from typing import List, Optional
 
 import torch
+import torch.distributed as dist
 import torch.nn as nn
 
 from . import _lib
@@ -217,6 +218,9 @@ class Plan:
         self.side = {}                 # backward op index -> True if it must first wait for the main stream
         self._side_events = None
         self.drop_units = []
+        self.sync = bool(engine.sync_bn and training and dist.is_available() and dist.is_initialized()
+                         and dist.get_world_size(engine.sync_group) > 1)
+        self.world = dist.get_world_size(engine.sync_group) if self.sync else 1
         self.last_dgrad = {}           # gradient buffer address -> ConvDesc of the data gradient that wrote it last
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
         # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
@@ -237,6 +241,18 @@ class Plan:
         t = alloc(B * H * W * ld, dtype=dtype, device=self.device)
         self.keep.append(t)
         return Act(t, t.data_ptr(), B, H, W, C, ld, f32 or self.dtype == torch.float32, t.element_size())
+
+    def dbuf(self, n):
+        t = torch.zeros(max(int(n), 1), dtype=torch.float64, device=self.device)
+        self.keep.append(t)
+        return t
+
+    def py_op(self, ops, fn):
+        """A host-side step of the plan (a collective): called as fn(stream), runs on the caller's current stream."""
+        def op(stream):
+            fn()
+            return 0
+        ops.append((op, []))
 
     def fbuf(self, n, zero=False):
         t = (torch.zeros if zero else torch.empty)(max(int(n), 1), dtype=torch.float32, device=self.device)
@@ -349,10 +365,21 @@ class Plan:
             u.mean, u.invstd = self.fbuf(N), self.fbuf(N)
             mean_ptr = u.mean.data_ptr()
             self.conv_fwd(x, conv, u.y, u.w, self.sp)
-            args = self.call(self.fwd, lib.dml_bn_finalize, self.sp, M, N, g_ptr, b_ptr,
-                             bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
-                             u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr())
-            self.momentum_slots.append((args, 7, bn))
+            if self.sync:
+                # statistics over every rank's samples (equal shards): local (mean, M2) -> all_gather -> Chan merge
+                mom, allmom = self.dbuf(N * 2), self.dbuf(self.world * N * 2)
+                self.call(self.fwd, lib.dml_bn_moments, self.sp, M, N, mom.data_ptr())
+                grp = self.e.sync_group
+                self.py_op(self.fwd, lambda a=allmom, b=mom, g=grp: dist.all_gather_into_tensor(a, b, group=g))
+                args = self.call(self.fwd, lib.dml_bn_finalize_moments, allmom.data_ptr(), self.world, M, N, g_ptr, b_ptr,
+                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
+                                 u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr())
+                self.momentum_slots.append((args, 8, bn))
+            else:
+                args = self.call(self.fwd, lib.dml_bn_finalize, self.sp, M, N, g_ptr, b_ptr,
+                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
+                                 u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr())
+                self.momentum_slots.append((args, 7, bn))
         else:
             # inference: scale / shift of every BN come from ONE table launch at the head of the plan, and BN +
             # residual + ReLU run in the conv epilogue -- one launch per unit instead of three, no y tensor
@@ -410,9 +437,18 @@ class Plan:
             a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, mk, u.mean.data_ptr(),
                            u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if u.relu else 0, 1.0,
                            self.dt, C.byref(nblk))
-        self.call(self.bwd, lib.dml_bn_bwd_finalize, sp, nblk, M, N, bn.weight.data_ptr(),
-                  u.mean.data_ptr(), u.invstd.data_ptr(), st.grad_ptr_of(bn.weight),
-                  st.grad_ptr_of(bn.bias), coef.data_ptr())
+        if self.sync:
+            sums = self.dbuf(N * 2)
+            self.call(self.bwd, lib.dml_bn_bwd_sums, sp, nblk, N, sums.data_ptr(), st.grad_ptr_of(bn.weight),
+                      st.grad_ptr_of(bn.bias))
+            grp = self.e.sync_group
+            self.py_op(self.bwd, lambda t=sums, g=grp: dist.all_reduce(t, group=g))
+            self.call(self.bwd, lib.dml_bn_bwd_coef, sums.data_ptr(), M * self.world, N, bn.weight.data_ptr(),
+                      u.mean.data_ptr(), u.invstd.data_ptr(), coef.data_ptr())
+        else:
+            self.call(self.bwd, lib.dml_bn_bwd_finalize, sp, nblk, M, N, bn.weight.data_ptr(),
+                      u.mean.data_ptr(), u.invstd.data_ptr(), st.grad_ptr_of(bn.weight),
+                      st.grad_ptr_of(bn.bias), coef.data_ptr())
         self.mark_grad(bn.weight)
         self.mark_grad(bn.bias)
         a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, mk, coef.data_ptr(), dy.ptr,
@@ -636,6 +672,7 @@ class Engine:
         self._protos = {}
         self.reducer = None             # parallel.GradReducer, attached for multi-GPU runs
         self.overlap_wgrad = os.environ.get("DML_OVERLAP_WGRAD", "1") != "0"
+        self.sync_bn, self.sync_group = False, None     # synchronised BatchNorm statistics over the process group
         self._side = {}
         self.step_count = 0
         self.seed = 0x5DEECE66D
@@ -659,7 +696,7 @@ class Engine:
             self.plans.clear()
             self._protos.clear()
         B, Cin, H, W = x.shape
-        key = (B, H, W, dtype, training)
+        key = (B, H, W, dtype, training, bool(self.sync_bn))
         plan = self.plans.get(key)
         if plan is None:
             plan = Plan(self, B, H, W, dtype, training)

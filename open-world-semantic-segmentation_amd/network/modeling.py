@@ -149,6 +149,14 @@ class DeepLabV3_embedding(nn.Module):
         self.compute_dtype = dtype
         return self
 
+    def set_sync_batchnorm(self, enabled=True, group=None):
+        """Batch statistics over every rank of `group` instead of per replica (the anomaly side of the reference
+        trains with SynchronizedBatchNorm2d, anomaly/lib/nn/modules/batchnorm.py:56-139; the DeepLab drivers do not).
+        Needs an initialised torch.distributed process group and equal per-rank batches; off by default."""
+        self._engine.sync_bn, self._engine.sync_group = bool(enabled), group
+        self._engine.plans.clear()
+        return self
+
     @property
     def centers(self):
         return 3.0 * torch.eye(self.classifier.classifier[3].out_channels)

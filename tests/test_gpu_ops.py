@@ -285,6 +285,63 @@ def test_conv_inference_epilogue(lib, dname, res, relu, Cout):
     relclose(nchw(z), qz(ref, tdt) if dname == "bf16" else ref, max(tol, 1e-5) if dname == "f32" else 1e-2, "conv+bn+res+relu")
 
 
+def test_sync_bn_building_blocks(lib):
+    """Synchronised BN pieces on one device: statistics / backward sums of two half-batches, merged the way two ranks
+    would after their all_gather / all_reduce, must equal the single-rank results on the whole batch."""
+    Mh, N = 64 * 7 + 13, 40
+    g = torch.Generator().manual_seed(9)
+    y = (torch.randn(2 * Mh, N, generator=g) * (torch.rand(N, generator=g) + 0.2) + torch.randn(N, generator=g)).cuda()
+    dz = torch.randn(2 * Mh, N, generator=g).cuda()
+    gam, bet = (torch.rand(N, generator=g) + 0.5).cuda(), torch.randn(N, generator=g).cuda()
+
+    def stats(t):
+        p = torch.zeros(((t.shape[0] + 63) // 64) * N * 2, device="cuda")
+        chk(lib.dml_bn_stats(t.data_ptr(), p.data_ptr(), t.shape[0], N, N, 0, st()))
+        return p
+
+    # whole batch, ordinary path
+    ref = [torch.empty(N, device="cuda") for _ in range(4)]
+    rm_ref, rv_ref = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    chk(lib.dml_bn_finalize(stats(y).data_ptr(), 2 * Mh, N, gam.data_ptr(), bet.data_ptr(), rm_ref.data_ptr(), rv_ref.data_ptr(),
+                            0.1, 1e-5, *[t.data_ptr() for t in ref], st()))
+    # two "ranks"
+    mom = torch.empty(2, N, 2, device="cuda", dtype=torch.float64)
+    for r in range(2):
+        chk(lib.dml_bn_moments(stats(y[r * Mh:(r + 1) * Mh]).data_ptr(), Mh, N, mom[r].data_ptr(), st()))
+    got = [torch.empty(N, device="cuda") for _ in range(4)]
+    rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
+    chk(lib.dml_bn_finalize_moments(mom.data_ptr(), 2, Mh, N, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
+                                    1e-5, *[t.data_ptr() for t in got], st()))
+    torch.cuda.synchronize()
+    for a, b, what in zip(got + [rm, rv], ref + [rm_ref, rv_ref], ("scale", "shift", "mean", "invstd", "running_mean", "running_var")):
+        assert torch.allclose(a, b, rtol=2e-6, atol=1e-7), what
+    # backward: local sums of the halves add up to the whole, coefficients from the global sums
+    mean, invstd = ref[2], ref[3]
+    part = torch.zeros(4096 * N * 2, device="cuda")
+    nb = C.c_int(0)
+
+    def reduce(dzs, ys):
+        chk(lib.dml_bn_bwd_reduce(dzs.data_ptr(), ys.data_ptr(), None, None, mean.data_ptr(), invstd.data_ptr(), part.data_ptr(),
+                                  dzs.shape[0], N, N, N, N, 0, 1.0, 0, C.byref(nb), st()))
+
+    coef_ref, dg_ref, db_ref = torch.empty(4 * N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    reduce(dz, y)
+    chk(lib.dml_bn_bwd_finalize(part.data_ptr(), nb, 2 * Mh, N, gam.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                                dg_ref.data_ptr(), db_ref.data_ptr(), coef_ref.data_ptr(), st()))
+    sums = torch.zeros(2, N, 2, device="cuda", dtype=torch.float64)
+    dg, db = torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
+    for r in range(2):
+        reduce(dz[r * Mh:(r + 1) * Mh], y[r * Mh:(r + 1) * Mh])
+        chk(lib.dml_bn_bwd_sums(part.data_ptr(), nb, N, sums[r].data_ptr(), dg.data_ptr(), db.data_ptr(), st()))
+    tot = sums.sum(0).contiguous()                      # what all_reduce(sum) gives every rank
+    coef = torch.empty(4 * N, device="cuda")
+    chk(lib.dml_bn_bwd_coef(tot.data_ptr(), 2 * Mh, N, gam.data_ptr(), mean.data_ptr(), invstd.data_ptr(), coef.data_ptr(), st()))
+    torch.cuda.synchronize()
+    relclose(coef.cpu(), coef_ref.cpu(), 2e-6, "coef")
+    relclose(dg.cpu(), dg_ref.cpu(), 2e-6, "dgamma (sum of the ranks' local gradients)")
+    relclose(db.cpu(), db_ref.cpu(), 2e-6, "dbeta")
+
+
 def test_conv_bias_f32_out_and_slices(lib):
     """Final 1x1 with bias writing fp32 from bf16 operands; producer writing into a concat-buffer slice."""
     B, Hh, Ww, Cin, K = 2, 6, 5, 256, 16
