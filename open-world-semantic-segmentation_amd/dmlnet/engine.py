@@ -283,22 +283,24 @@ class Plan:
         Wo = (x.W + 2 * p - d * (kw - 1) - 1) // s + 1
         return kh, kw, s, d, p, Ho, Wo
 
-    def prep_weight(self, conv: nn.Conv2d, Cp: int, need_wt: bool):
-        N, Cm = conv.out_channels, conv.in_channels
+    def prep_weight(self, conv: nn.Conv2d, Cp: int, need_wt: bool, src_ptr=None, N=None):
+        """compute copies w[N][RS][Cp] (and wt[Cp][RS][N] for the data gradient) of a master weight; `src_ptr` / `N`
+        override the source and the row count (the final conv's rows are padded to a multiple of 8, see build())."""
+        N, Cm = N or conv.out_channels, conv.in_channels
         kh, kw = conv.kernel_size
         w = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device)
         wt = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device) if need_wt else None
         self.keep += [w, wt]
-        self.prep.append((conv.weight.data_ptr(), w.data_ptr(), wt.data_ptr() if wt is not None else 0, N, kh * kw,
-                          Cm, Cp))
+        self.prep.append((src_ptr or conv.weight.data_ptr(), w.data_ptr(), wt.data_ptr() if wt is not None else 0, N,
+                          kh * kw, Cm, Cp))
         return w, wt
 
-    def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None, post=None):
+    def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None, post=None, N=None):
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         assert (Ho, Wo) == (y.H, y.W), ((Ho, Wo), (y.H, y.W))
         dsc = ConvDesc(x=x.ptr, w=w.data_ptr(), y=y.ptr, bias=bias_ptr, stats=stats_ptr, pre_scale=None,
                        pre_shift=None, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
-                       N=conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
+                       N=N or conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
                        y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
         if post is not None:            # inference epilogue: BN(running stats) + residual + ReLU (DmlConvDesc.post_*)
             scale, shift, mean, res, relu = post
@@ -323,17 +325,26 @@ class Plan:
         if x is x.root:
             self.last_dgrad[gx.ptr] = dsc         # whole-tensor gradient: candidate for the fused BN-backward reduce
 
-    def conv_wgrad(self, x: Act, dy: Act, conv: nn.Conv2d, Cp: int):
+    def conv_wgrad(self, x: Act, dy: Act, conv: nn.Conv2d, Cp: int, pad_rows: int = 0):
+        """pad_rows: dy carries `pad_rows` >= out_channels channels (zero beyond); the padded rows of the gradient
+        go to a scratch tensor and only the real ones are added to the parameter's gradient."""
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         Cm = conv.in_channels
         gptr = self.e.store.grad_ptr_of(conv.weight)
-        tmp = None
         first = len(self.bwd)
-        dsc = WgradDesc(x=x.ptr, dy=dy.ptr, dw=gptr, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
-                        N=conv.out_channels, ldy=dy.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, splitk=0,
+        Nw, tmp = conv.out_channels, None
+        if pad_rows and pad_rows != conv.out_channels:
+            Nw = pad_rows
+            tmp = self.fbuf(Nw * kh * kw * Cm)
+            self.call(self.bwd, self.lib.dml_fill_f32, tmp.data_ptr(), tmp.numel(), 0.0)
+        dsc = WgradDesc(x=x.ptr, dy=dy.ptr, dw=tmp.data_ptr() if tmp is not None else gptr, B=x.B, Hi=x.H, Wi=x.W, C=x.C,
+                        ldx=x.ld, Ho=Ho, Wo=Wo,
+                        N=Nw, ldy=dy.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, splitk=0,
                         Cm=Cm, ws=self.wgrad_ws.data_ptr(), ws_elems=self.wgrad_ws.numel())
         self.keep.append(dsc)
         self.call(self.bwd, self.lib.dml_conv_wgrad, C.byref(dsc))
+        if tmp is not None:
+            self.call(self.bwd, self.lib.dml_unpad_wgrad, tmp.data_ptr(), gptr, conv.out_channels, kh * kw, Cm, Cm)
         # weight gradients only feed the optimizer: they run on a side stream, next to the HBM-bound BN backward
         # and the data gradient of the following layers (Plan.run_backward)
         for i in range(first, len(self.bwd)):
@@ -468,11 +479,12 @@ class Plan:
         B, H, W = self.B, self.H, self.W
         bb, head = m.backbone, m.classifier
         K = head.classifier[3].out_channels
-        self.K = K
-        if K % self.vec or K > 32:
-            raise NotImplementedError(
-                "num_classes=%d: the MI355X path needs the embedding dimension to be a multiple of %d (16-byte channel "
-                "vectors in %s) and <= 32; the reference's drivers use 16 (main_embedding.py:336)" % (K, self.vec, self.dtype))
+        Kp = _round_up(K, 8)           # embedding channels are carried padded to 16-byte vectors (zeros beyond K)
+        self.K, self.Kp = K, Kp
+        self.pre_prep = []
+        if Kp > 32:
+            raise NotImplementedError("num_classes=%d: the distance-head kernels hold at most 32 embedding channels and 33 "
+                                      "prototypes; the reference's drivers use 16 (main_embedding.py:336)" % K)
         for mod in itertools.chain(bb.modules(), head.modules()):
             if isinstance(mod, nn.BatchNorm2d) and mod.training != self.training:
                 raise NotImplementedError("BatchNorm2d modules in a different mode than the model (fix_bn) are not "
@@ -536,14 +548,30 @@ class Plan:
                   uproj.z.ld, cat2.ld, self.dt, 0, 0)
         ucls = self.cbr(cat2, head.classifier[0], head.classifier[1])
         fin = head.classifier[3]
-        w_fin, wt_fin = self.prep_weight(fin, 256, self.training)
-        emb = self.new(B, low.H, low.W, K, f32=True)
-        self.conv_fwd(ucls.z, fin, emb, w_fin, None, bias_ptr=fin.bias.data_ptr() if fin.bias is not None else None)
+        fin_bias_ptr = fin.bias.data_ptr() if fin.bias is not None else None
+        if Kp == K:
+            w_fin, wt_fin = self.prep_weight(fin, 256, self.training)
+        else:
+            # num_classes that is no multiple of 8 (the factory default is 21): the final conv computes Kp channels
+            # from a zero-padded copy of its weight / bias, so the embedding's pad channels are exactly 0, the
+            # prototypes are padded with zeros too, and every kernel keeps its 16-byte channel vectors
+            wpad = self.fbuf(Kp * 256, zero=True)
+            bpad = self.fbuf(Kp, zero=True)
+
+            def stage(wpad=wpad, bpad=bpad, fin=fin, K=K):
+                wpad[:K * 256].copy_(fin.weight.detach().reshape(-1))
+                if fin.bias is not None:
+                    bpad[:K].copy_(fin.bias.detach())
+            self.pre_prep.append(stage)
+            w_fin, wt_fin = self.prep_weight(fin, 256, self.training, src_ptr=wpad.data_ptr(), N=Kp)
+            fin_bias_ptr = bpad.data_ptr() if fin.bias is not None else None
+        emb = self.new(B, low.H, low.W, Kp, f32=True)
+        self.conv_fwd(ucls.z, fin, emb, w_fin, None, bias_ptr=fin_bias_ptr, N=Kp)
         self.emb = emb
-        self.protos = self.e.prototypes(K)
+        self.protos = self.e.prototypes_padded(K, Kp)
         # fused final upsample + distance head (network/utils.py:88-118); outputs are per-call tensors
         self.head_args = self.call(self.fwd, lib.dml_upsample_dist_fwd, emb.ptr, self.protos.data_ptr(), 0, 0,
-                                   None, None, B, emb.H, emb.W, K, K, H, W)
+                                   None, None, B, emb.H, emb.W, Kp, K, H, W)
         if not self.training:
             arr = (_lib.BnEvalDesc * len(self.bn_eval))(*self.bn_eval)
             self.bn_eval_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
@@ -551,16 +579,22 @@ class Plan:
             return
 
         # ------------------------------------------------------------------ backward
-        df = self.fbuf(B * H * W * K)
+        df = self.fbuf(B * H * W * Kp)
         self.df = df
         self.head_bwd_args = self.call(self.bwd, lib.dml_proto_dist_bwd, 0, None, 0, self.protos.data_ptr(),
-                                       df.data_ptr(), B, K, K, H, W)
-        de = self.new(B, emb.H, emb.W, K)
-        self.call(self.bwd, lib.dml_bilinear_bwd, df.data_ptr(), de.ptr, B, emb.H, emb.W, H, W, K, K, K, self.dt, 1, 0)
+                                       df.data_ptr(), B, Kp, K, H, W)
+        de = self.new(B, emb.H, emb.W, Kp)
+        self.call(self.bwd, lib.dml_bilinear_bwd, df.data_ptr(), de.ptr, B, emb.H, emb.W, H, W, Kp, Kp, Kp, self.dt, 1, 0)
         if fin.bias is not None:
-            self.call(self.bwd, lib.dml_bias_grad, de.ptr, st.grad_ptr_of(fin.bias), de.M, K, de.ld, self.dt)
+            if Kp == K:
+                self.call(self.bwd, lib.dml_bias_grad, de.ptr, st.grad_ptr_of(fin.bias), de.M, K, de.ld, self.dt)
+            else:
+                gb = self.fbuf(Kp)
+                self.call(self.bwd, lib.dml_fill_f32, gb.data_ptr(), Kp, 0.0)
+                self.call(self.bwd, lib.dml_bias_grad, de.ptr, gb.data_ptr(), de.M, Kp, de.ld, self.dt)
+                self.call(self.bwd, lib.dml_unpad_wgrad, gb.data_ptr(), st.grad_ptr_of(fin.bias), 1, 1, K, Kp)
             self.mark_grad(fin.bias)
-        self.conv_wgrad(ucls.z, de, fin, 256)
+        self.conv_wgrad(ucls.z, de, fin, 256, pad_rows=Kp)
         self.conv_dgrad(de, fin, wt_fin, ucls.z)
         self.unit_bwd(ucls, self.grad_of(ucls.z))                       # -> d cat2
         dcat2 = self.grad_of(cat2)
@@ -610,6 +644,8 @@ class Plan:
         key = (st.version, sum(p._version for p in st.params))
         if key == self.prepped_version:
             return
+        for fn in self.pre_prep:
+            fn()
         if self.prep_table is None:
             arr = (_lib.PrepDesc * len(self.prep))()
             for i, (src, w, wt, N, RS, Cm, Cp) in enumerate(self.prep):
@@ -690,6 +726,18 @@ class Engine:
             self._protos[key] = 3.0 * torch.eye(k, dtype=torch.float32, device=dev)
         return self._protos[key]
 
+    def prototypes_padded(self, k: int, kp: int) -> torch.Tensor:
+        """the same centers with the embedding axis zero-padded to kp (kernels' view; see Plan.build)"""
+        if kp == k:
+            return self.prototypes(k)
+        dev = self.store.flat_p.device
+        key = (k, kp, dev)
+        if key not in self._protos:
+            m = torch.zeros((k, kp), dtype=torch.float32, device=dev)
+            m[:, :k] = self.prototypes(k)
+            self._protos[key] = m
+        return self._protos[key]
+
     def plan_for(self, x: torch.Tensor, dtype: torch.dtype, training: bool) -> Plan:
         if not self.store.is_bound(x.device):
             self.store.bind(x.device)
@@ -720,7 +768,8 @@ class Engine:
         B, _, H, W = x.shape
         K = plan.K
         logits = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
-        feats = torch.empty((B, H, W, K), dtype=torch.float32, device=x.device)
+        feats = torch.empty((B, H, W, plan.Kp), dtype=torch.float32, device=x.device)
+        plan.feats_p = feats                 # the kernels' (channel-padded) features; the backward reads them again
         plan.images_args[0] = x.data_ptr()
         plan.head_args[2] = logits.data_ptr()
         plan.head_args[3] = feats.data_ptr()
@@ -739,6 +788,8 @@ class Engine:
             self.store.flat_nbt.add_(1)
         Plan.run(plan.fwd, stream)
         plan.last_input = x
+        if plan.Kp != K:
+            feats = feats[..., :K].contiguous()      # features_out has exactly num_classes channels (utils.py:95-97)
         return plan, logits, feats
 
     def backward(self, plan: Plan, glogits: Optional[torch.Tensor], gfeats: Optional[torch.Tensor],
@@ -750,11 +801,16 @@ class Engine:
         glogits = glogits.contiguous()
         if gfeats is not None:
             gfeats = gfeats.contiguous()
+            if plan.Kp != plan.K:
+                gp = torch.zeros((plan.B, plan.H, plan.W, plan.Kp), dtype=torch.float32, device=dev)
+                gp[..., :plan.K] = gfeats
+                gfeats = gp
         self.store.begin_backward()
         a = plan.head_bwd_args
         a[0] = glogits.data_ptr()
         a[1] = gfeats.data_ptr() if gfeats is not None else None
-        a[2] = feats.data_ptr()
+        a[2] = plan.feats_p.data_ptr()
+        self._keep_bwd = (glogits, gfeats)
         if self.reducer is not None:
             self.reducer.run_backward(plan, stream)
         else:

@@ -195,10 +195,11 @@ def test_against_oracle_small_nonsquare_strict():
     _check_against_oracles(m, img, lab, strict=True, seed=11)
 
 
-@pytest.mark.parametrize("num_classes,output_stride", [(16, 8), (8, 16), (24, 16), (32, 8)])
+@pytest.mark.parametrize("num_classes,output_stride", [(16, 8), (8, 16), (24, 16), (32, 8), (21, 16), (13, 16)])
 def test_variants_against_oracle(num_classes, output_stride):
     """The factory's other configurations (network/modeling.py:140-148: output_stride 8 = dilations 2/4 in layer3/4
-    and ASPP rates 12/24/36; embedding widths other than 16), train step vs the fp32 / fp64 oracle."""
+    and ASPP rates 12/24/36; embedding widths other than 16, incl. the factory default 21 and 13 = StreetHazards, which
+    are carried padded to a multiple of 8 internally), train step vs the fp32 / fp64 oracle."""
     torch.set_num_threads(min(32, torch.get_num_threads() or 8))
     m = build(seed=21, num_classes=num_classes, output_stride=output_stride)
     img = H.synth_tensor(21, "var.img", (2, 3, 64, 80))
@@ -208,11 +209,30 @@ def test_variants_against_oracle(num_classes, output_stride):
 
 def test_unsupported_embedding_width_raises():
     import network
-    m = network.deeplabv3plus_embedding_resnet101(num_classes=21, output_stride=16, pretrained_backbone=False).cuda()
+    m = network.deeplabv3plus_embedding_resnet101(num_classes=40, output_stride=16, pretrained_backbone=False).cuda()
     m.set_compute_dtype(torch.bfloat16)
     m.train()
     with pytest.raises(NotImplementedError):
         m(torch.randn(2, 3, 64, 64, device="cuda"))
+
+
+def test_default_factory_arguments_bf16_features_have_num_classes_channels():
+    """network.deeplabv3plus_embedding_resnet101() with the reference's defaults (21 classes, output stride 8)."""
+    import network
+    import utils
+    m = network.deeplabv3plus_embedding_resnet101(pretrained_backbone=False).cuda()
+    m.set_compute_dtype(torch.bfloat16)
+    m.train()
+    x = torch.randn(2, 3, 64, 64, device="cuda")
+    lab = torch.randint(0, 21, (2, 64, 64), device="cuda")
+    lg, ctr, ft = m(x)
+    assert lg.shape == (2, 21, 64, 64) and ft.shape == (2, 64, 64, 21) and ctr.shape == (21, 21) and ft.is_contiguous()
+    # logits are exactly the distances of the returned features to the returned centers (utils.py:103-118)
+    d = -((ft.unsqueeze(3) - ctr.to(ft.device)) ** 2).sum(-1).permute(0, 3, 1, 2)
+    relclose(lg, d, 1e-5, "logits vs features / centers")
+    (utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab, ft) + 1e-3 * ft.sum()).backward()      # gfeats path with padding
+    g = m.classifier.classifier[3].weight.grad
+    assert g.shape == (21, 256, 1, 1) and torch.isfinite(g).all() and g.abs().max() > 0
 
 
 def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_stride=16):
