@@ -53,7 +53,10 @@ class ParamStore:
 
     def __init__(self, model: nn.Module):
         self.model = model
-        self.params: List[nn.Parameter] = list(model.backbone.parameters()) + list(model.classifier.parameters())
+        heads = model.head_modules() if hasattr(model, "head_modules") else [model.classifier]
+        self.params: List[nn.Parameter] = list(model.backbone.parameters())
+        for h in heads:
+            self.params += list(h.parameters())
         self.n_backbone = len(list(model.backbone.parameters()))
         self.offsets: List[int] = []
         off = 0
@@ -65,7 +68,7 @@ class ParamStore:
         self.flat_p: Optional[torch.Tensor] = None
         self.flat_g: Optional[torch.Tensor] = None
         self.flat_v: Optional[torch.Tensor] = None     # momentum, created by the optimizer
-        self.bn_modules = [m for m in itertools.chain(model.backbone.modules(), model.classifier.modules())
+        self.bn_modules = [m for m in itertools.chain(model.backbone.modules(), *[h.modules() for h in heads])
                            if isinstance(m, nn.BatchNorm2d)]
         self.flat_rs: Optional[torch.Tensor] = None
         self.flat_nbt: Optional[torch.Tensor] = None
@@ -188,6 +191,10 @@ class Act:
         a = Act(self.t, self.ptr + c0 * self.es, self.B, self.H, self.W, c, self.ld, self.f32, self.es)
         a.root = self.root
         return a
+
+
+class HeadRec:
+    """per-head pieces of a plan (activations, units, the argument lists patched per call)"""
 
 
 class ConvUnit:
@@ -477,15 +484,9 @@ class Plan:
     def build(self):
         lib, m, st = self.lib, self.e.model, self.e.store
         B, H, W = self.B, self.H, self.W
-        bb, head = m.backbone, m.classifier
-        K = head.classifier[3].out_channels
-        Kp = _round_up(K, 8)           # embedding channels are carried padded to 16-byte vectors (zeros beyond K)
-        self.K, self.Kp = K, Kp
+        bb, head_modules = m.backbone, self.e.head_modules()
         self.pre_prep = []
-        if Kp > 32:
-            raise NotImplementedError("num_classes=%d: the distance-head kernels hold at most 32 embedding channels and 33 "
-                                      "prototypes; the reference's drivers use 16 (main_embedding.py:336)" % K)
-        for mod in itertools.chain(bb.modules(), head.modules()):
+        for mod in itertools.chain(bb.modules(), *[h.modules() for h in head_modules]):
             if isinstance(mod, nn.BatchNorm2d) and mod.training != self.training:
                 raise NotImplementedError("BatchNorm2d modules in a different mode than the model (fix_bn) are not "
                                           "supported on the MI355X path")
@@ -527,7 +528,53 @@ class Plan:
                 low = x
         out = x
 
-        # head (network/utils.py:27-32)
+        # heads: one for the DMLNet model, several (shared backbone) for the self-distillation model (utils.py:120-193)
+        self.heads = [self._head_fwd(h, low, out) for h in head_modules]
+        self.K, self.Kp = self.heads[0].K, self.heads[0].Kp
+        if not self.training:
+            arr = (_lib.BnEvalDesc * len(self.bn_eval))(*self.bn_eval)
+            self.bn_eval_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self.bn_eval_args[0], self.bn_eval_args[1] = self.bn_eval_table.data_ptr(), len(self.bn_eval)
+            return
+
+        # ------------------------------------------------------------------ backward
+        # The LAST head goes first: it initialises d(out) / d(low); the others accumulate into them, so their
+        # segments of the plan can be skipped when the loss does not reach them (Engine.backward).
+        self.head_bwd_range = {}
+        for hi in reversed(range(len(self.heads))):
+            start = len(self.bwd)
+            self._head_bwd(self.heads[hi], low, out)
+            self.head_bwd_range[hi] = (start, len(self.bwd))
+        # bottlenecks in reverse
+        for (xb, u1, u2, u3, ud) in reversed(blocks):
+            dz = self.grad_of(u3.z)
+            if ud is not None:
+                dres = self.grad_of(ud.z)
+                self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
+                ud.z.grad_init = True
+            else:
+                dres = self.grad_of(xb)
+                self.unit_bwd(u3, dz, dres=dres, dres_accum=xb.root.grad_init)
+                xb.root.grad_init = True
+            self.unit_bwd(u2, self.grad_of(u2.z))
+            self.unit_bwd(u1, self.grad_of(u1.z))
+            if ud is not None:
+                self.unit_bwd(ud, self.grad_of(ud.z))
+        # max pool + stem
+        dz0 = self.grad_of(z0)
+        self.call(self.bwd, lib.dml_maxpool3x3s2_bwd, self.grad_of(p0).ptr, amax.data_ptr(), dz0.ptr, B, z0.H, z0.W,
+                  64, self.dt)
+        self.unit_bwd(stem, dz0, need_dgrad=False)
+
+    def _head_fwd(self, head: nn.Module, low: Act, out: Act):
+        """DeepLabHeadV3Plus + final upsample + distance head (network/utils.py:8-32,84-118) on the backbone features."""
+        lib, st = self.lib, self.e.store
+        B, H, W = self.B, self.H, self.W
+        K = head.classifier[3].out_channels
+        Kp = _round_up(K, 8)           # embedding channels are carried padded to 16-byte vectors (zeros beyond K)
+        if Kp > 32:
+            raise NotImplementedError("num_classes=%d: the distance-head kernels hold at most 32 embedding channels and 33 "
+                                      "prototypes; the reference's drivers use 16 (main_embedding.py:336)" % K)
         cat2_c = _round_up(48 + 256, 32)                   # 304 -> 320: K tiles of 32 stay inside one tap
         cat2 = self.new(B, low.H, low.W, cat2_c, zero=True)
         up_low = self.cbr(low, head.project[0], head.project[1], out=cat2.slice(0, 48))
@@ -567,21 +614,26 @@ class Plan:
             fin_bias_ptr = bpad.data_ptr() if fin.bias is not None else None
         emb = self.new(B, low.H, low.W, Kp, f32=True)
         self.conv_fwd(ucls.z, fin, emb, w_fin, None, bias_ptr=fin_bias_ptr, N=Kp)
-        self.emb = emb
-        self.protos = self.e.prototypes_padded(K, Kp)
+        protos = self.e.prototypes_padded(K, Kp)
         # fused final upsample + distance head (network/utils.py:88-118); outputs are per-call tensors
-        self.head_args = self.call(self.fwd, lib.dml_upsample_dist_fwd, emb.ptr, self.protos.data_ptr(), 0, 0,
+        head_args = self.call(self.fwd, lib.dml_upsample_dist_fwd, emb.ptr, protos.data_ptr(), 0, 0,
                                    None, None, B, emb.H, emb.W, Kp, K, H, W)
-        if not self.training:
-            arr = (_lib.BnEvalDesc * len(self.bn_eval))(*self.bn_eval)
-            self.bn_eval_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
-            self.bn_eval_args[0], self.bn_eval_args[1] = self.bn_eval_table.data_ptr(), len(self.bn_eval)
-            return
+        rec = HeadRec()
+        rec.K, rec.Kp, rec.emb, rec.protos, rec.head_args = K, Kp, emb, protos, head_args
+        rec.cat1, rec.cat2, rec.up_low, rec.branches, rec.pooled, rec.upool = cat1, cat2, up_low, branches, pooled, upool
+        rec.uproj, rec.ucls, rec.fin, rec.wt_fin = uproj, ucls, fin, wt_fin
+        rec.head_bwd_args, rec.df, rec.feats_p = None, None, None
+        return rec
 
-        # ------------------------------------------------------------------ backward
+    def _head_bwd(self, rec, low: Act, out: Act):
+        lib, st = self.lib, self.e.store
+        B, H, W = self.B, self.H, self.W
+        K, Kp, emb, fin, wt_fin = rec.K, rec.Kp, rec.emb, rec.fin, rec.wt_fin
+        cat1, cat2, up_low, branches, pooled, upool = rec.cat1, rec.cat2, rec.up_low, rec.branches, rec.pooled, rec.upool
+        uproj, ucls = rec.uproj, rec.ucls
         df = self.fbuf(B * H * W * Kp)
-        self.df = df
-        self.head_bwd_args = self.call(self.bwd, lib.dml_proto_dist_bwd, 0, None, 0, self.protos.data_ptr(),
+        rec.df = df
+        rec.head_bwd_args = self.call(self.bwd, lib.dml_proto_dist_bwd, 0, None, 0, rec.protos.data_ptr(),
                                        df.data_ptr(), B, Kp, K, H, W)
         de = self.new(B, emb.H, emb.W, Kp)
         self.call(self.bwd, lib.dml_bilinear_bwd, df.data_ptr(), de.ptr, B, emb.H, emb.W, H, W, Kp, Kp, Kp, self.dt, 1, 0)
@@ -617,26 +669,6 @@ class Plan:
         self.last_dgrad.pop(self.grad_of(out).ptr, None)      # not a data gradient: layer4's last BN keeps its own reduce
         # low-level projection -> d low (layer1 output)
         self.unit_bwd(up_low, dcat2.slice(0, 48))
-        # bottlenecks in reverse
-        for (xb, u1, u2, u3, ud) in reversed(blocks):
-            dz = self.grad_of(u3.z)
-            if ud is not None:
-                dres = self.grad_of(ud.z)
-                self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
-                ud.z.grad_init = True
-            else:
-                dres = self.grad_of(xb)
-                self.unit_bwd(u3, dz, dres=dres, dres_accum=xb.root.grad_init)
-                xb.root.grad_init = True
-            self.unit_bwd(u2, self.grad_of(u2.z))
-            self.unit_bwd(u1, self.grad_of(u1.z))
-            if ud is not None:
-                self.unit_bwd(ud, self.grad_of(ud.z))
-        # max pool + stem
-        dz0 = self.grad_of(z0)
-        self.call(self.bwd, lib.dml_maxpool3x3s2_bwd, self.grad_of(p0).ptr, amax.data_ptr(), dz0.ptr, B, z0.H, z0.W,
-                  64, self.dt)
-        self.unit_bwd(stem, dz0, need_dgrad=False)
 
     # ---- execution ---------------------------------------------------------------------------
     def refresh_weights(self, stream):
@@ -660,8 +692,11 @@ class Plan:
         """Replay the backward plan: weight gradients on the engine's side stream, everything else on the
         caller's current stream; joined at the end."""
         main = torch.cuda.current_stream(self.device)
+        skipped = set()
+        for (lo, hi) in getattr(self, "skip_ranges", ()):
+            skipped.update(range(lo, hi))
         if not self.e.overlap_wgrad or not self.side:
-            Plan.run(self.bwd, main.cuda_stream, hook=hook)
+            Plan.run(self.bwd, main.cuda_stream, hook=hook, skipped=skipped)
             return
         side = self.e.side_stream(self.device)
         if self._side_events is None:
@@ -670,6 +705,10 @@ class Plan:
         ms, ss = main.cuda_stream, side.cuda_stream
         sidemap, events = self.side, self._side_events
         for i, (fn, args) in enumerate(self.bwd):
+            if i in skipped:
+                if hook is not None:
+                    hook(i)
+                continue
             flag = sidemap.get(i)
             if flag is None:
                 rc = fn(*args, ms)
@@ -686,9 +725,13 @@ class Plan:
         main.wait_stream(side)
 
     @staticmethod
-    def run(ops, stream, start=0, stop=None, hook=None):
+    def run(ops, stream, start=0, stop=None, hook=None, skipped=()):
         stop = len(ops) if stop is None else stop
         for i in range(start, stop):
+            if i in skipped:
+                if hook is not None:
+                    hook(i)
+                continue
             fn, args = ops[i]
             rc = fn(*args, stream)
             if rc:
@@ -725,6 +768,10 @@ class Engine:
         if key not in self._protos:
             self._protos[key] = 3.0 * torch.eye(k, dtype=torch.float32, device=dev)
         return self._protos[key]
+
+    def head_modules(self):
+        m = self.model
+        return m.head_modules() if hasattr(m, "head_modules") else [m.classifier]
 
     def prototypes_padded(self, k: int, kp: int) -> torch.Tensor:
         """the same centers with the embedding axis zero-padded to kp (kernels' view; see Plan.build)"""
@@ -766,13 +813,15 @@ class Engine:
         stream = torch.cuda.current_stream(x.device).cuda_stream
         plan.refresh_weights(stream)
         B, _, H, W = x.shape
-        K = plan.K
-        logits = torch.empty((B, K, H, W), dtype=torch.float32, device=x.device)
-        feats = torch.empty((B, H, W, plan.Kp), dtype=torch.float32, device=x.device)
-        plan.feats_p = feats                 # the kernels' (channel-padded) features; the backward reads them again
+        logits, feats = [], []
+        for rec in plan.heads:
+            lg = torch.empty((B, rec.K, H, W), dtype=torch.float32, device=x.device)
+            ft = torch.empty((B, H, W, rec.Kp), dtype=torch.float32, device=x.device)
+            rec.feats_p = ft                 # the kernels' (channel-padded) features; the backward reads them again
+            rec.head_args[2], rec.head_args[3] = lg.data_ptr(), ft.data_ptr()
+            logits.append(lg)
+            feats.append(ft)
         plan.images_args[0] = x.data_ptr()
-        plan.head_args[2] = logits.data_ptr()
-        plan.head_args[3] = feats.data_ptr()
         if training:
             for args, idx, bn in plan.momentum_slots:
                 if bn.momentum is None:
@@ -788,29 +837,39 @@ class Engine:
             self.store.flat_nbt.add_(1)
         Plan.run(plan.fwd, stream)
         plan.last_input = x
-        if plan.Kp != K:
-            feats = feats[..., :K].contiguous()      # features_out has exactly num_classes channels (utils.py:95-97)
+        for hi, rec in enumerate(plan.heads):
+            if rec.Kp != rec.K:              # features_out has exactly num_classes channels (utils.py:95-97)
+                feats[hi] = feats[hi][..., :rec.K].contiguous()
         return plan, logits, feats
 
-    def backward(self, plan: Plan, glogits: Optional[torch.Tensor], gfeats: Optional[torch.Tensor],
-                 feats: torch.Tensor):
-        dev = feats.device
+    def backward(self, plan: Plan, glogits: List[Optional[torch.Tensor]], gfeats: List[Optional[torch.Tensor]]):
+        """glogits / gfeats: one entry per head (None where the loss does not reach that output)."""
+        dev = plan.device
         stream = torch.cuda.current_stream(dev).cuda_stream
-        if glogits is None:
-            glogits = torch.zeros((plan.B, plan.K, plan.H, plan.W), dtype=torch.float32, device=dev)
-        glogits = glogits.contiguous()
-        if gfeats is not None:
-            gfeats = gfeats.contiguous()
-            if plan.Kp != plan.K:
-                gp = torch.zeros((plan.B, plan.H, plan.W, plan.Kp), dtype=torch.float32, device=dev)
-                gp[..., :plan.K] = gfeats
-                gfeats = gp
+        keep, skip = [], []
+        last = len(plan.heads) - 1
+        for hi, rec in enumerate(plan.heads):
+            gl, gf = glogits[hi], gfeats[hi]
+            if gl is None and gf is None and hi != last:
+                skip.append(plan.head_bwd_range[hi])         # accumulating segment: nothing to add
+                continue
+            if gl is None:
+                gl = torch.zeros((plan.B, rec.K, plan.H, plan.W), dtype=torch.float32, device=dev)
+            gl = gl.contiguous()
+            if gf is not None:
+                gf = gf.contiguous()
+                if rec.Kp != rec.K:
+                    gp = torch.zeros((plan.B, plan.H, plan.W, rec.Kp), dtype=torch.float32, device=dev)
+                    gp[..., :rec.K] = gf
+                    gf = gp
+            a = rec.head_bwd_args
+            a[0] = gl.data_ptr()
+            a[1] = gf.data_ptr() if gf is not None else None
+            a[2] = rec.feats_p.data_ptr()
+            keep += [gl, gf]
+        self._keep_bwd = keep
+        plan.skip_ranges = skip
         self.store.begin_backward()
-        a = plan.head_bwd_args
-        a[0] = glogits.data_ptr()
-        a[1] = gfeats.data_ptr() if gfeats is not None else None
-        a[2] = plan.feats_p.data_ptr()
-        self._keep_bwd = (glogits, gfeats)
         if self.reducer is not None:
             self.reducer.run_backward(plan, stream)
         else:

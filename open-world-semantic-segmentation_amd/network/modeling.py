@@ -110,13 +110,14 @@ class _ModelFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, anchor):
         plan, logits, feats = model._engine.forward(x, model.compute_dtype, True)
-        ctx.model, ctx.plan, ctx.feats = model, plan, feats
+        ctx.model, ctx.plan, ctx.nheads = model, plan, len(logits)
         ctx.set_materialize_grads(False)
-        return logits, feats
+        return tuple(logits) + tuple(feats)              # (logits of every head..., features of every head...)
 
     @staticmethod
-    def backward(ctx, glogits, gfeats):
-        ctx.model._engine.backward(ctx.plan, glogits, gfeats, ctx.feats)
+    def backward(ctx, *grads):
+        n = ctx.nheads
+        ctx.model._engine.backward(ctx.plan, list(grads[:n]), list(grads[n:]))
         return None, None, None
 
 
@@ -170,7 +171,47 @@ class DeepLabV3_embedding(nn.Module):
             logits, feats = _ModelFn.apply(self, x, self._anchor)
         else:
             _, logits, feats = eng.forward(x, self.compute_dtype, self.training)
+            logits, feats = logits[0], feats[0]
         return logits, eng.prototypes(k), feats
+
+
+class DeepLabV3_embedding_self_distillation(DeepLabV3_embedding):
+    """network/_deeplab.py:45 + network/utils.py:120-193 of the reference: one backbone, a base head with 16 prototypes
+    and `cls_novel` further heads with 17, 18, ... (the incremental classes); forward(x) returns three LISTS
+    (logits, centers, features_out), one entry per head.  The loss of main_self_distillation.py:447-507 reaches the
+    last head only -- the backward plan then skips the other heads' segments."""
+
+    base_classes = 16            # utils.py:131 hard-codes it
+    cls_novel = 1                # utils.py:125
+
+    def __init__(self, backbone, rates):
+        nn.Module.__init__(self)
+        self.backbone = backbone
+        self.classifier_list = ["classifier"] + ["classifier_%d" % (i + 1) for i in range(self.cls_novel)]
+        self.classifier = DeepLabHeadV3Plus(2048, 256, self.base_classes, rates)
+        for i in range(self.cls_novel):
+            setattr(self, self.classifier_list[i + 1], DeepLabHeadV3Plus(2048, 256, self.base_classes + i + 1, rates))
+        env = os.environ.get("DMLNET_DTYPE", "f32").lower()
+        self.compute_dtype = torch.bfloat16 if env in ("bf16", "bfloat16") else torch.float32
+        object.__setattr__(self, "_engine", Engine(self))
+        self._anchor = None
+        self._register_state_dict_hook(self._own_storage_hook)
+
+    def head_modules(self):
+        return [getattr(self, n) for n in self.classifier_list]
+
+    def forward(self, x):
+        eng = self._engine
+        n = len(self.classifier_list)
+        if self.training and torch.is_grad_enabled():
+            if self._anchor is None or self._anchor.device != x.device:
+                self._anchor = torch.zeros(1, device=x.device, requires_grad=True)
+            outs = _ModelFn.apply(self, x, self._anchor)
+            logits, feats = list(outs[:n]), list(outs[n:])
+        else:
+            _, logits, feats = eng.forward(x, self.compute_dtype, self.training)
+        centers = [eng.prototypes(h.classifier[3].out_channels) for h in self.head_modules()]
+        return logits, centers, feats
 
 
 def _segm_resnet(name, backbone_name, num_classes, output_stride, pretrained_backbone):
@@ -185,8 +226,10 @@ def _segm_resnet(name, backbone_name, num_classes, output_stride, pretrained_bac
     if backbone_name not in _DEPTHS:
         raise NotImplementedError(backbone_name)
     backbone = ResNetTrunk(_DEPTHS[backbone_name], dilate)
+    if name == "deeplabv3plus_embedding_self_distillation":
+        return DeepLabV3_embedding_self_distillation(backbone, rates)        # modeling.py:39-40: num_classes unused
     if name != "deeplabv3plus_embedding":
-        raise NotImplementedError("%s: only the embedding DeepLabV3+ is built on MI355X (BASELINE.json)" % name)
+        raise NotImplementedError("%s: only the embedding DeepLabV3+ models are built on MI355X (BASELINE.json)" % name)
     return DeepLabV3_embedding(backbone, DeepLabHeadV3Plus(2048, 256, num_classes, rates))
 
 
@@ -217,8 +260,14 @@ deeplabv3_resnet50 = _out_of_scope("deeplabv3_resnet50")
 deeplabv3plus_resnet50 = _out_of_scope("deeplabv3plus_resnet50")
 deeplabv3_resnet101 = _out_of_scope("deeplabv3_resnet101")
 deeplabv3plus_resnet101 = _out_of_scope("deeplabv3plus_resnet101")
-deeplabv3plus_embedding_self_distillation_resnet101 = _out_of_scope(
-    "deeplabv3plus_embedding_self_distillation_resnet101")
+
+
+def deeplabv3plus_embedding_self_distillation_resnet101(num_classes=21, output_stride=8, pretrained_backbone=True):
+    """Shared backbone + base head (16) + incremental head(s) (17, ...), modeling.py:150-158 of the reference
+    (num_classes is accepted and ignored there as well: the head widths are fixed in the model class)."""
+    return _load_model("deeplabv3plus_embedding_self_distillation", "resnet101", num_classes, output_stride,
+                       pretrained_backbone)
+
 deeplabv3_mobilenet = _out_of_scope("deeplabv3_mobilenet")
 deeplabv3plus_mobilenet = _out_of_scope("deeplabv3plus_mobilenet")
 

@@ -209,6 +209,38 @@ def deeplabv3plus_embedding_resnet101(num_classes=21, output_stride=8, pretraine
     return DeepLabV3PlusEmbeddingRef(num_classes, output_stride)
 
 
+class DeepLabV3PlusEmbeddingSelfDistillationRef(nn.Module):
+    """deeplabv3plus_embedding_self_distillation_resnet101 (modeling.py:150-158; utils.py:120-193): one backbone, a
+    16-prototype base head `classifier` and cls_novel = 1 incremental head `classifier_1` with 17; forward returns
+    lists (logits, centers, features_out), one entry per head.  Pinned by tests/golden/g12_multihead.npz
+    (tools/mint_golden_multihead.py)."""
+
+    def __init__(self, output_stride=8, cls_novel=1, base_classes=16):
+        super().__init__()
+        self.backbone = _Backbone(output_stride)
+        self.classifier_list = ["classifier"] + ["classifier_%d" % (i + 1) for i in range(cls_novel)]
+        self.classifier = _Head(base_classes, aspp_rates(output_stride))
+        for i in range(cls_novel):
+            setattr(self, self.classifier_list[i + 1], _Head(base_classes + i + 1, aspp_rates(output_stride)))
+
+    def forward(self, x):
+        feats = self.backbone(x)
+        logits, centers, features = [], [], []
+        for name in self.classifier_list:
+            e = F.interpolate(getattr(self, name)(feats), size=x.shape[-2:], mode="bilinear", align_corners=False)
+            lg, ctr, ft = distance_head(e)
+            logits.append(lg)
+            centers.append(ctr)
+            features.append(ft)
+        return logits, centers, features
+
+
+def deeplabv3plus_embedding_self_distillation_resnet101(num_classes=21, output_stride=8, pretrained_backbone=False):
+    if pretrained_backbone:
+        raise RuntimeError("oracle: no network here, pass pretrained_backbone=False")
+    return DeepLabV3PlusEmbeddingSelfDistillationRef(output_stride)
+
+
 def set_bn_momentum(model: nn.Module, momentum=0.1):
     """utils/utils.py:26-29."""
     for m in model.modules():

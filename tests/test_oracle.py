@@ -229,3 +229,30 @@ def test_stage_plan_matches_reference_dilations():
     assert l3[0]["dilation"] == 1 and l3[1]["dilation"] == 2
     assert [c["dilation"] for c in plan8 if c["stage"] == 4][:2] == [2, 4]
     assert len(plan) == 33
+
+
+def test_g12_multihead_self_distillation_model():
+    """shared backbone + 16- and 17-prototype heads (utils.py:120-193), loss on the last head only"""
+    g = H.load_golden("g12_multihead")
+    m = O.deeplabv3plus_embedding_self_distillation_resnet101(output_stride=16)
+    sd = H.synth_state_dict(H.shapes_of(m), seed=12)
+    assert len(sd) == int(g["n_keys"]) and list(sd.keys())[-4:] == [str(k) for k in g["keys"]]
+    m.load_state_dict(sd)
+    m.train()
+    m.classifier.aspp.project[3].eval()
+    m.classifier_1.aspp.project[3].eval()
+    img = H.synth_tensor(12, "g12.img", (2, 3, 64, 64))
+    lab = H.synth_labels(12, "g12.lab", (2, 64, 64), 17, 255, ignore_rows=3)
+    logits, centers, feats = m(img)
+    assert [tuple(l.shape) for l in logits] == [(2, 16, 64, 64), (2, 17, 64, 64)] and centers[1].shape == (17, 17)
+    loss = O.ce_over_n(logits[-1], lab, 255)
+    loss.backward()
+    close(logits[0][:, :, ::4, ::4], T(g["logits0_sub"]), 1e-5)
+    close(logits[1][:, :, ::4, ::4], T(g["logits1_sub"]), 1e-5)
+    close(feats[1][:, ::4, ::4, :], T(g["feats1_sub"]), 1e-5)
+    close(loss, T(g["loss"]), 1e-6)
+    grads = dict((k, p.grad) for k, p in m.named_parameters())
+    for i, k in enumerate(str(k) for k in g["grad_keys"]):
+        assert np.allclose(H.checksum(grads[k])[1:], g["grad_%d_checksum" % i][1:], rtol=1e-4), k
+    for k in (str(k) for k in g["untouched"]):
+        assert grads[k] is None
