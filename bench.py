@@ -71,9 +71,13 @@ def profile_convs(model, engine, step_fn, n_steps):
     records = []
     orig_run = E.Plan.run
 
-    def timed_run(ops, stream, start=0, stop=None, hook=None):
+    def timed_run(ops, stream, start=0, stop=None, hook=None, skipped=()):
         stop = len(ops) if stop is None else stop
         for i in range(start, stop):
+            if i in skipped:
+                if hook is not None:
+                    hook(i)
+                continue
             fn, args = ops[i]
             is_conv = fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad
             if is_conv:

@@ -34,3 +34,21 @@ def test_sync_batchnorm_two_ranks_match_one_process():
                        capture_output=True, text=True, cwd=H.ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-3000:]
     assert "rank 0:" in r.stdout and "rank 1:" in r.stdout
+
+
+def test_bench_script_default_path_small():
+    """bench.py end to end (timed region, profiled conv pass, distance kernel, input pipeline) at a small size: the
+    JSON line must carry the contract's fields."""
+    import json
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--size", "128", "--batch", "2", "--steps", "2",
+                        "--warmup", "1", "--no-cpu-baseline"], capture_output=True, text=True, cwd=H.ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "hbm_kernel", "input_pipeline"):
+        assert k in d, k
+    assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0 and d["value"] > 0
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--mode", "infer", "--height", "128", "--width",
+                        "256", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, cwd=H.ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert json.loads(r.stdout.strip().splitlines()[-1])["value"] > 0
