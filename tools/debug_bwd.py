@@ -55,7 +55,7 @@ def rep(name, got, key):
     print("%-22s hip %.2e  ref32 %.2e  (scale %.2e)" % (name, (got - ref).abs().max().item() / sc, (g32[key] - ref).abs().max().item() / sc, sc))
 rep("d logits", lg.grad.cpu().double(), "lg")
 B, Hh, Ww = shape[0], shape[2], shape[3]
-rep("d features (df)", plan.df.view(B, Hh, Ww, 16).permute(0, 3, 1, 2).cpu().double(), "e_up")
+rep("d features (df)", plan.heads[0].df.view(B, Hh, Ww, 16).permute(0, 3, 1, 2).cpu().double(), "e_up")
 ucls = units["classifier.classifier.0"]
 fin_x = ucls.z
 # de is the dy of the final conv: find through the grad chain
