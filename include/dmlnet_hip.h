@@ -303,6 +303,12 @@ int dml_aug_apply(const uint8_t* img, const uint8_t* lbl, const DmlAugSample* sa
 int dml_confusion_update(const int64_t* label_true, const int64_t* label_pred, int64_t* hist,
                          int64_t count, int n_classes, void* stream);
 
+/* Few-shot prototype extraction (the recipe at test_embedding.py:413-425 of the reference: mean of features_out over
+ * the pixels of one class): sums[c] (device double[C], zeroed by the call) = sum of feats[p][c] over pixels with
+ * labels[p] == class_id, count (device uint64) = their number.  C <= 32. */
+int dml_class_feature_sum(const float* feats, const int64_t* labels, int64_t n_px, int C, int64_t class_id,
+                          double* sums, unsigned long long* count, void* stream);
+
 /* Pixel-level OOD measures (anomaly/anom_utils.py:25-78 as called by eval_ood_traditional.py:128-148):
  * scores = -conf; positives = pixels whose label is one of out_labels (host array, n_out <= 8), negatives = the
  * rest; pixels with mask[i] == 0 are left out (mask optional).  result (device double[5]) = { AUROC, AUPR,

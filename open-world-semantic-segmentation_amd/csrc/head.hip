@@ -949,3 +949,51 @@ extern "C" int dml_confusion_update(const int64_t* label_true, const int64_t* la
     DML_LAUNCH_CHECK();
     return 0;
 }
+
+// ------------------------------------------------------------------------------------------------
+// masked feature sum for the few-shot prototypes (test_embedding.py:413-425 of the reference)
+// ------------------------------------------------------------------------------------------------
+namespace {
+__global__ __launch_bounds__(256) void class_feature_sum_kernel(const float* __restrict__ feats, const int64_t* __restrict__ labels,
+                                                                int64_t n_px, int C, int64_t class_id, double* __restrict__ sums,
+                                                                unsigned long long* __restrict__ count) {
+    __shared__ double sh[MAXC];
+    __shared__ unsigned long long shn;
+    if (threadIdx.x < MAXC) sh[threadIdx.x] = 0.0;
+    if (threadIdx.x == 0) shn = 0ull;
+    __syncthreads();
+    float acc[MAXC];
+#pragma unroll
+    for (int c = 0; c < MAXC; ++c) acc[c] = 0.f;
+    unsigned long long n = 0;
+    for (int64_t p = (int64_t)blockIdx.x * 256 + threadIdx.x; p < n_px; p += (int64_t)gridDim.x * 256) {
+        if (labels[p] != class_id) continue;
+        ++n;
+        const float* f = feats + p * C;
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) acc[c] += f[c];
+    }
+    if (n) {
+#pragma unroll
+        for (int c = 0; c < MAXC; ++c)
+            if (c < C) atomicAdd(&sh[c], (double)acc[c]);
+        atomicAdd(&shn, n);
+    }
+    __syncthreads();
+    if (threadIdx.x < C && sh[threadIdx.x] != 0.0) atomicAdd(sums + threadIdx.x, sh[threadIdx.x]);
+    if (threadIdx.x == 0 && shn) atomicAdd(count, shn);
+}
+}  // namespace
+
+extern "C" int dml_class_feature_sum(const float* feats, const int64_t* labels, int64_t n_px, int C, int64_t class_id,
+                                     double* sums, unsigned long long* count, void* stream) {
+    if (!feats || !labels || !sums || !count || n_px <= 0 || C <= 0 || C > MAXC) return DML_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (hipMemsetAsync(sums, 0, sizeof(double) * C, st) != hipSuccess || hipMemsetAsync(count, 0, 8, st) != hipSuccess)
+        return DML_EINVAL;
+    hipLaunchKernelGGL(class_feature_sum_kernel, dim3(grid_for(n_px, 256, 1024)), dim3(256), 0, st, feats, labels, n_px, C,
+                       class_id, sums, count);
+    DML_LAUNCH_CHECK();
+    return 0;
+}

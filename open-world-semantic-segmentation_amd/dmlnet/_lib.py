@@ -105,6 +105,7 @@ _PROTOS = {
     "dml_sgd_step": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_p]),
     "dml_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
     "dml_confusion_update": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
+    "dml_class_feature_sum": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p, c_p]),
     "dml_ood_workspace_bytes": (c_i64, [c_i64]),
     "dml_ood_measures": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i, C.c_double, c_p, c_i64, c_p, c_p]),
     "dml_aug_contrast_sum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -3,5 +3,5 @@
 from .loss import CrossEntropyLoss, DMLLoss  # noqa: F401
 from .scheduler import PolyLR  # noqa: F401
 from .misc import set_bn_momentum, fix_bn, mkdir  # noqa: F401
-from .scores import argmax_msp, dissum_score, novel_relabel, mean_prototype  # noqa: F401
+from .scores import argmax_msp, dissum_score, novel_relabel, mean_prototype, extract_prototype  # noqa: F401
 from . import ext_transforms  # noqa: F401,E402

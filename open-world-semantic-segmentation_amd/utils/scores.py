@@ -62,3 +62,26 @@ def novel_relabel(preds: torch.Tensor, logits: torch.Tensor, feats: torch.Tensor
     _lib.check(lib.dml_novel_relabel(feats.data_ptr(), logits.data_ptr(), pr.data_ptr(), preds.data_ptr(), B, C, K,
                                      H, W, float(thresh), int(new_label), _st(logits)), "dml_novel_relabel")
     return preds
+
+
+def extract_prototype(features: torch.Tensor, labels_true: torch.Tensor, class_id: int, min_fraction: float = 0.05):
+    """One shot of a novel-class prototype: the mean of `features_out` over the pixels labelled `class_id`, or None
+    when the class covers less than `min_fraction` of the image -- the recipe the reference keeps commented out at
+    test_embedding.py:413-425 (`features.cpu().numpy()[labels_true == 15]`, `np.mean(..., axis=0)`, json).  The
+    reduction runs on the device; collect the returned lists and `json.dump` them as the reference does."""
+    _need_cuda(features)
+    lib = _lib.load()
+    f = features.contiguous().float()
+    C = f.shape[-1]
+    f = f.view(-1, C)
+    lab = labels_true.contiguous().view(-1)
+    if lab.dtype != torch.int64 or lab.numel() != f.shape[0] or not lab.is_cuda:
+        raise ValueError("labels_true must be an int64 CUDA tensor with one entry per pixel of `features`")
+    sums = torch.empty(C, dtype=torch.float64, device=f.device)
+    cnt = torch.empty(1, dtype=torch.int64, device=f.device)
+    _lib.check(lib.dml_class_feature_sum(f.data_ptr(), lab.data_ptr(), f.shape[0], C, int(class_id), sums.data_ptr(),
+                                         cnt.data_ptr(), _st(f)), "dml_class_feature_sum")
+    n = int(cnt.item())
+    if n == 0 or n / f.shape[0] <= min_fraction:
+        return None
+    return (sums / n).float().cpu().tolist()

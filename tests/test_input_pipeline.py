@@ -236,3 +236,27 @@ def test_ood_measures_full_image_vs_oracle():
     got2 = anom_utils.eval_ood_measure(torch.from_numpy(conf.reshape(-1)[perm]).cuda(), torch.from_numpy(lab.reshape(-1)[perm]).cuda(),
                                        [12, 13], mask=torch.from_numpy(mask.reshape(-1)[perm]).cuda())
     assert got2[0] == got[0] and got2[2] == got[2] and abs(got2[1] - got[1]) <= 1e-13
+
+
+@pytest.mark.gpu
+def test_prototype_extraction_matches_numpy_recipe():
+    """utils.extract_prototype vs the reference's commented recipe (test_embedding.py:413-425):
+    np.mean(features[labels_true == c], axis=0) when the class covers more than 5 % of the image."""
+    import json
+    import utils
+    rs = np.random.RandomState(8)
+    Hh, Ww, Cc = 96, 160, 16
+    feats = (rs.randn(1, Hh, Ww, Cc) * 2).astype(np.float32)
+    lab = rs.randint(0, 16, (Hh, Ww)).astype(np.int64)
+    lab[:40, :60] = 15                                   # ~16 % of the image
+    lab[lab == 3] = 4                                    # class 3 absent
+    lab[90:, 150:] = 7
+    fd, ld = torch.from_numpy(feats).cuda(), torch.from_numpy(lab).cuda()
+    got = utils.extract_prototype(fd, ld, 15)
+    ref = np.mean(feats[0][lab == 15], axis=0)
+    assert len(got) == Cc and np.allclose(np.array(got), ref, rtol=1e-5, atol=1e-6)
+    assert utils.extract_prototype(fd, ld, 3) is None                       # absent
+    frac7 = (lab == 7).mean()
+    assert (utils.extract_prototype(fd, ld, 7) is None) == (frac7 <= 0.05)   # below the 5 % rule of the recipe
+    proto = utils.mean_prototype(json.loads(json.dumps([got, got])))        # round trip through the json format
+    assert np.allclose(proto, ref, rtol=1e-5, atol=1e-6)
