@@ -645,19 +645,19 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
 
 // ------------------------------------------------------------------------------------------------
 // bf16 forward / data-gradient kernel, LDS-DMA version (requires C % 32 == 0).
-// Operand tiles go HBM -> LDS with buffer_load ... lds (no VGPR round trip, no ds_write): a 4-stage ring,
-// tiles issued 3 K-steps ahead, counted vmcnt waits and ONE barrier per K-step.  Zero padding / masked rows
+// Operand tiles go HBM -> LDS with buffer_load ... lds (no VGPR round trip, no ds_write): an NST-stage ring (3: 48 KB,
+// three workgroups per CU), tiles issued NST-1 K-steps ahead, counted vmcnt waits and ONE barrier per K-step.  Zero padding / masked rows
 // come from the buffer descriptor's bounds check (an out-of-range voffset writes zeros to LDS).  The LDS image
 // is lane-linear, so the bank-conflict swizzle is applied to the per-lane SOURCE address.
 // ------------------------------------------------------------------------------------------------
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN, int MODE>
-__global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
+template <int BN, int MODE, int NST>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
                                                                   const uint32_t w_bytes) {
     typedef bf16_t T;
-    constexpr int BM = 128, NST = 4, LA = 3;
+    constexpr int BM = 128, LA = NST - 1;
     constexpr int STAGE = (BM + BN) * BK;          // elements per ring stage
     constexpr int TM = 64, TN = BN / 2, MT = 4, NT = TN / 16;
     constexpr int A_I = 2, B_I = BN / 64;           // DMA instructions per wave per tile (1 KiB = 16 rows each)
@@ -761,7 +761,7 @@ __global__ __launch_bounds__(NTHREADS) void conv_igemm_dma_kernel(const ConvArgs
 
     const int lr = lane & 15, lq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
-        if (kt + 2 < KT) wait_vmcnt<2 * NI>();
+        if (LA > 2 && kt + 2 < KT) wait_vmcnt<(LA > 2 ? 2 : 1) * NI>();
         else if (kt + 1 < KT) wait_vmcnt<NI>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
@@ -1214,23 +1214,23 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
     const bool aligned = (a.C % BK) == 0 && a.R * a.S <= 32 && small;
     a.nblk_m = (a.M + 127) / 128;
     if constexpr (sizeof(T) == 2) {
-        // LDS-DMA kernel: bf16, K tiles inside one tap, tensors addressable with a 31-bit byte offset
-        // Measured on MI355X (tools/bench_conv.py): the DMA ring wins on large grids with long K loops (decoder
-        // 3x3 304->256 @192^2: 771 vs 711 TFLOP/s) and loses ~10 % where only ~2 blocks/CU exist (its 64 KB of
-        // LDS allows 2 blocks/CU vs 5 for the register-staged kernel).  DML_CONV_DMA=1 / DML_CONV_V1=1 force one.
-        static const bool use_v1 = getenv("DML_CONV_V1") != nullptr;
-        static const bool force_dma = getenv("DML_CONV_DMA") != nullptr;
-        const bool big = (int64_t)a.nblk_m * ((a.N + 127) / 128) >= 2048 && a.Ktot / BK >= 32;
+        // LDS-DMA kernel: bf16, K tiles inside one tap, tensors addressable with a 31-bit byte offset.  With a 3-stage
+        // ring (48 KB of LDS) and the 168-register budget three workgroups fit a CU like the register-staged kernel, and
+        // it is the default for every eligible shape: whole train step 362.4 vs 356.4 images/s (three interleaved A/B
+        // runs; a 4-stage ring on the largest grids only: 360.2).  In isolation the two kernels are within +-5 % of each
+        // other (tools/bench_conv.py); the register-staged kernel stays for fp32, unaligned channel counts (stem, final
+        // conv) and N <= 32.
+        static const bool use_v1 = getenv("DML_CONV_V1") != nullptr;        // tuning / test switch: register-staged kernel
         const int64_t xb = ((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx * 2 + (int64_t)a.C * 2;
         const int64_t wb = (int64_t)a.N * a.Ktot * 2;
-        if (!use_v1 && (big || force_dma) && aligned && a.N > 32 && xb < (1ll << 31) && wb < (1ll << 31)) {
+        if (!use_v1 && aligned && a.N > 32 && xb < (1ll << 31) && wb < (1ll << 31)) {
             if (a.N > 64) {
                 a.nblk_n = (a.N + 127) / 128;
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st,
-                                   a, (uint32_t)xb, (uint32_t)wb);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
+                                   (uint32_t)xb, (uint32_t)wb);
             } else {
                 a.nblk_n = 1;
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<64, MODE>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<64, MODE, 3>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
                                    (uint32_t)xb, (uint32_t)wb);
             }
             DML_LAUNCH_CHECK();

@@ -1,5 +1,6 @@
-"""GPU: the LDS-DMA conv kernel (buffer_load ... lds ring) is only selected automatically for very large grids;
-force it with DML_CONV_DMA=1 in a child process and run the conv parity tests through it."""
+"""GPU: the LDS-DMA conv kernel (buffer_load ... lds ring) is the default for every eligible bf16 shape; the
+register-staged kernel then only sees fp32 / unaligned shapes -- force it for everything with DML_CONV_V1=1 in a
+child process and run the conv parity tests through it as well.  Plus end-to-end runs of scripts in child processes."""
 import os
 import subprocess
 import sys
@@ -11,8 +12,8 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def test_conv_ops_through_the_dma_kernel():
-    env = dict(os.environ, DML_CONV_DMA="1")
+def test_conv_ops_through_the_register_staged_kernel():
+    env = dict(os.environ, DML_CONV_V1="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu",
                         "-q", "-x", "-k", "conv", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                        cwd=H.ROOT, timeout=900)
