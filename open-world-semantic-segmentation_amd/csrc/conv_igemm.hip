@@ -680,27 +680,41 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
     const int prow = lane >> 2;
     const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
 
-    int a_iy[A_I], a_ix[A_I], a_img[A_I];
+    // per piece and lane: signed byte offset of the row's tap-(0,0) pixel (+ swizzled chunk) and one validity bit per
+    // filter tap (image border, stride-2 parity of the data gradient) -- the per-K-step part is scalar (see
+    // conv_igemm_kernel)
+    const int sh2 = (MODE == 1 && a.stride == 2) ? 1 : 0;
+    int a_base[A_I];
+    uint32_t a_mask[A_I];
 #pragma unroll
     for (int jj = 0; jj < A_I; ++jj) {
         const int m = m0 + (wave * A_I + jj) * 16 + prow;
+        a_base[jj] = 0;
+        a_mask[jj] = 0;
         if (m < a.M) {
             const uint32_t b = fdiv((uint32_t)m, a.div_howo);
             const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
             const uint32_t yo = fdiv(rem, a.div_wo);
             const uint32_t xo = rem - yo * (uint32_t)a.Wo;
-            if (MODE == 0) {
-                a_iy[jj] = (int)yo * a.stride - a.pad;
-                a_ix[jj] = (int)xo * a.stride - a.pad;
-            } else {
-                a_iy[jj] = (int)yo + a.pad;
-                a_ix[jj] = (int)xo + a.pad;
-            }
-            a_img[jj] = (int)b * a.Hi;
-        } else {
-            a_iy[jj] = -(1 << 28);
-            a_ix[jj] = -(1 << 28);
-            a_img[jj] = 0;
+            const int iy = MODE == 0 ? (int)yo * a.stride - a.pad : (int)yo + a.pad;
+            const int ix = MODE == 0 ? (int)xo * a.stride - a.pad : (int)xo + a.pad;
+            const int by = MODE == 0 ? iy : (iy >> sh2), bx = MODE == 0 ? ix : (ix >> sh2);
+            a_base[jj] = ((((int)b * a.Hi + by) * a.Wi + bx) * a.ldx + lchunk * 8) * 2;
+            uint32_t mk = 0;
+            for (int r = 0, t = 0; r < a.R; ++r)
+                for (int q = 0; q < a.S; ++q, ++t) {
+                    bool ok;
+                    if (MODE == 0) {
+                        const int ys = iy + r * a.dil, xs = ix + q * a.dil;
+                        ok = ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+                    } else {
+                        const int ty = iy - r * a.dil, tx = ix - q * a.dil;
+                        ok = (sh2 == 0 || (((ty | tx) & 1) == 0)) && ty >= 0 && tx >= 0 && ((ty >> sh2) < a.Hi) &&
+                             ((tx >> sh2) < a.Wi);
+                    }
+                    mk |= ok ? (1u << t) : 0u;
+                }
+            a_mask[jj] = mk;
         }
     }
     uint32_t b_off[B_I];
@@ -714,31 +728,17 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
     int ir = 0, is = 0, ic0 = 0;       // filter tap / channel offset of the next tile to issue
     auto issue = [&](int kt, int stage) {
         T* sbase = smem + stage * STAGE;
+        const uint32_t tapbit = 1u << (ir * a.S + is);
+        const int soff = (MODE == 0 ? ((ir * a.dil) * a.Wi + is * a.dil) * a.ldx
+                                    : -((((ir * a.dil) >> sh2) * a.Wi + ((is * a.dil) >> sh2)) * a.ldx)) * 2 + ic0 * 2;
 #pragma unroll
         for (int jj = 0; jj < A_I; ++jj) {
-            int ys, xs;
-            bool ok = true;
-            if (MODE == 0) {
-                ys = a_iy[jj] + ir * a.dil;
-                xs = a_ix[jj] + is * a.dil;
-            } else {
-                const int ty = a_iy[jj] - ir * a.dil, tx = a_ix[jj] - is * a.dil;
-                if (a.stride == 2) {
-                    ok = ((ty | tx) & 1) == 0;
-                    ys = ty >> 1;
-                    xs = tx >> 1;
-                } else {
-                    ys = ty;
-                    xs = tx;
-                }
-            }
-            ok = ok && ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
-            const uint32_t voff = ok ? (uint32_t)((((a_img[jj] + ys) * a.Wi + xs) * a.ldx + ic0 + lchunk * 8) * 2) : OOB;
+            const uint32_t voff = (a_mask[jj] & tapbit) ? (uint32_t)(a_base[jj] + soff) : OOB;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + (wave * A_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
         }
 #pragma unroll
-        for (int jj = 0; jj < B_I; ++jj) {
-            const uint32_t voff = b_off[jj] == OOB ? OOB : b_off[jj] + (uint32_t)(kt * BK * 2);
+        for (int jj = 0; jj < B_I; ++jj) {    // OOB + K offset stays past the descriptor's range (tensors < 2^31 bytes)
+            const uint32_t voff = b_off[jj] + (uint32_t)(kt * BK * 2);
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * BK + (wave * B_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
         }
         ic0 += BK;
