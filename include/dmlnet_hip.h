@@ -293,6 +293,18 @@ int dml_aug_apply(const uint8_t* img, const uint8_t* lbl, const DmlAugSample* sa
                   const uint32_t* lsum, float* out_img, int64_t* out_lbl, int B, int H, int W, int th,
                   int tw, float mean0, float mean1, float mean2, float std0, float std1, float std2,
                   void* stream);
+/* Same, with the dataset's label encoding folded in (datasets/cityscapes.py:132-154 of the reference:
+ * Cityscapes.encode_target = raw id -> train id -> unknown classes to 255, higher ids shifted down; pointwise, so it
+ * commutes with crop / flip): out_lbl = lut[raw], out_lbl_true = lut_true[raw] (optional second output, the reference's
+ * `target_true`).  lut / lut_true: device uint8[256]. */
+int dml_aug_apply_encoded(const uint8_t* img, const uint8_t* lbl, const DmlAugSample* samples,
+                          const uint32_t* lsum, float* out_img, int64_t* out_lbl, int B, int H, int W,
+                          int th, int tw, float mean0, float mean1, float mean2, float std0, float std1,
+                          float std2, const uint8_t* lut, const uint8_t* lut_true, int64_t* out_lbl_true,
+                          void* stream);
+/* The same table applied to a whole uint8 label tensor (validation path: no crop / jitter). */
+int dml_label_encode(const uint8_t* raw, int64_t n, const uint8_t* lut, const uint8_t* lut_true,
+                     int64_t* out, int64_t* out_true, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Streaming segmentation metrics on the device (the step after the path):

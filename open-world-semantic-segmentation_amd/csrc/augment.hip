@@ -108,7 +108,9 @@ __global__ __launch_bounds__(TPB) void aug_apply_kernel(const uint8_t* __restric
                                                         const DmlAugSample* __restrict__ samples,
                                                         const uint32_t* __restrict__ lsum, float* __restrict__ out_img,
                                                         int64_t* __restrict__ out_lbl, int H, int W, int th, int tw,
-                                                        float m0, float m1, float m2, float s0, float s1, float s2) {
+                                                        float m0, float m1, float m2, float s0, float s1, float s2,
+                                                        const uint8_t* __restrict__ lut, const uint8_t* __restrict__ lut_true,
+                                                        int64_t* __restrict__ out_lbl_true) {
     __shared__ uint32_t sm[SEG * 3 / 4 + 2];
     const int b = blockIdx.z, y = blockIdx.y, x0 = blockIdx.x * SEG;
     const DmlAugSample s = samples[b];
@@ -119,7 +121,7 @@ __global__ __launch_bounds__(TPB) void aug_apply_kernel(const uint8_t* __restric
     // ImageStat mean in double, + 0.5, truncated (ImageEnhance.Contrast)
     const uint32_t pivot = (uint32_t)(int)((double)lsum[b] / (double)((int64_t)th * tw) + 0.5);
     float v[3][PPT];
-    int64_t lab[PPT];
+    int64_t lab[PPT], lab_true[PPT];
     const int64_t lrow = ((int64_t)b * H + s.i + y) * W + s.j;
 #pragma unroll
     for (int e = 0; e < PPT; ++e) {
@@ -133,7 +135,10 @@ __global__ __launch_bounds__(TPB) void aug_apply_kernel(const uint8_t* __restric
             v[2][e] = __fdiv_rn(__fsub_rn(__fdiv_rn((float)p.b, 255.f), m2), s2);
             if (lbl != nullptr) {
                 const int x = x0 + k;
-                lab[e] = (int64_t)lbl[lrow + (s.flip ? (tw - 1 - x) : x)];
+                const uint8_t raw = lbl[lrow + (s.flip ? (tw - 1 - x) : x)];
+                // dataset label encoding (Cityscapes.encode_target) is a pointwise table, so it commutes with crop / flip
+                lab[e] = (int64_t)(lut != nullptr ? lut[raw] : raw);
+                lab_true[e] = (int64_t)(lut_true != nullptr ? lut_true[raw] : raw);
             }
         }
     }
@@ -159,6 +164,24 @@ __global__ __launch_bounds__(TPB) void aug_apply_kernel(const uint8_t* __restric
             for (int e = 0; e < PPT && xl + e < n; ++e) ol[e] = lab[e];
         }
     }
+    if (lbl != nullptr && out_lbl_true != nullptr) {
+        int64_t* ol = out_lbl_true + (int64_t)b * plane + o;
+        for (int e = 0; e < PPT && xl + e < n; ++e) ol[e] = lab_true[e];
+    }
+}
+
+__global__ __launch_bounds__(256) void label_encode_kernel(const uint8_t* __restrict__ raw, int64_t n,
+                                                           const uint8_t* __restrict__ lut, const uint8_t* __restrict__ lut_true,
+                                                           int64_t* __restrict__ out, int64_t* __restrict__ out_true) {
+    __shared__ uint8_t t[2][256];
+    t[0][threadIdx.x] = lut[threadIdx.x];
+    t[1][threadIdx.x] = lut_true != nullptr ? lut_true[threadIdx.x] : (uint8_t)threadIdx.x;
+    __syncthreads();
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint8_t r = raw[i];
+        out[i] = (int64_t)t[0][r];
+        if (out_true != nullptr) out_true[i] = (int64_t)t[1][r];
+    }
 }
 
 }  // namespace
@@ -181,7 +204,33 @@ extern "C" int dml_aug_apply(const uint8_t* img, const uint8_t* lbl, const DmlAu
     if (!img || !samples || !lsum || !out_img || B <= 0 || th <= 0 || tw <= 0 || th > H || tw > W) return DML_EINVAL;
     if (std0 == 0.f || std1 == 0.f || std2 == 0.f) return DML_EINVAL;
     hipLaunchKernelGGL(aug_apply_kernel, dim3((tw + SEG - 1) / SEG, th, B), dim3(TPB), 0, static_cast<hipStream_t>(stream), img,
-                       lbl, samples, lsum, out_img, out_lbl, H, W, th, tw, mean0, mean1, mean2, std0, std1, std2);
+                       lbl, samples, lsum, out_img, out_lbl, H, W, th, tw, mean0, mean1, mean2, std0, std1, std2, nullptr, nullptr,
+                       nullptr);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_aug_apply_encoded(const uint8_t* img, const uint8_t* lbl, const DmlAugSample* samples, const uint32_t* lsum,
+                                     float* out_img, int64_t* out_lbl, int B, int H, int W, int th, int tw, float mean0,
+                                     float mean1, float mean2, float std0, float std1, float std2, const uint8_t* lut,
+                                     const uint8_t* lut_true, int64_t* out_lbl_true, void* stream) {
+    if (!img || !lbl || !samples || !lsum || !out_img || !out_lbl || !lut || B <= 0 || th <= 0 || tw <= 0 || th > H || tw > W)
+        return DML_EINVAL;
+    if (std0 == 0.f || std1 == 0.f || std2 == 0.f) return DML_EINVAL;
+    hipLaunchKernelGGL(aug_apply_kernel, dim3((tw + SEG - 1) / SEG, th, B), dim3(TPB), 0, static_cast<hipStream_t>(stream), img,
+                       lbl, samples, lsum, out_img, out_lbl, H, W, th, tw, mean0, mean1, mean2, std0, std1, std2, lut, lut_true,
+                       out_lbl_true);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_label_encode(const uint8_t* raw, int64_t n, const uint8_t* lut, const uint8_t* lut_true, int64_t* out,
+                                int64_t* out_true, void* stream) {
+    if (n == 0) return 0;
+    if (!raw || !lut || !out || n < 0 || (out_true && !lut_true)) return DML_EINVAL;
+    const int64_t want = (n + 256 * 8 - 1) / (256 * 8);
+    hipLaunchKernelGGL(label_encode_kernel, dim3((unsigned)(want < 65536 ? want : 65536)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), raw, n, lut, lut_true, out, out_true);
     DML_LAUNCH_CHECK();
     return 0;
 }

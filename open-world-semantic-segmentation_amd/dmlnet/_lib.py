@@ -110,6 +110,9 @@ _PROTOS = {
     "dml_ood_measures": (c_i, [c_p, c_p, c_p, c_i64, c_p, c_i, C.c_double, c_p, c_i64, c_p, c_p]),
     "dml_aug_contrast_sum": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_aug_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f, c_p]),
+    "dml_aug_apply_encoded": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
+                                    c_p, c_p, c_p, c_p]),
+    "dml_label_encode": (c_i, [c_p, C.c_int64, c_p, c_p, c_p, c_p, c_p]),
 }
 
 EXPORTS = tuple(_PROTOS.keys())

@@ -100,31 +100,39 @@ def main():
     from utils import ext_transforms as et
     fh, fw = max(opts.crop_size, opts.frame_height), max(opts.crop_size, opts.frame_width)
     frames = torch.randint(0, 256, (hi - lo, fh, fw, 3), generator=g, dtype=torch.uint8).to(device)
-    coarse = torch.randint(0, opts.num_classes, (hi - lo, (fh + 63) // 64, (fw + 63) // 64), generator=g, dtype=torch.uint8)
+    # label maps hold RAW Cityscapes ids (0..33, as the gtFine PNGs do) when the class count is one the label space
+    # defines: 19 (all), 17 (truck, bus held out -- as shipped, datasets/cityscapes.py:71), 16 (car, truck, bus held out
+    # -- README.md:108-109); Cityscapes.encode_target is then applied inside the crop kernel as one 256-entry table
+    from datasets import Cityscapes
+    unknown = {19: None, 17: [14, 15], 16: [13, 14, 15]}.get(opts.num_classes, "n/a")
+    raw_ids = unknown != "n/a"
+    coarse = torch.randint(0, 34 if raw_ids else opts.num_classes, (hi - lo, (fh + 63) // 64, (fw + 63) // 64), generator=g,
+                           dtype=torch.uint8)
     frame_labels = coarse.repeat_interleave(64, 1).repeat_interleave(64, 2)[:, :fh, :fw].contiguous()
-    frame_labels[:, : max(1, fh * 38 // 768)] = 255
+    frame_labels[:, : max(1, fh * 38 // 768)] = 0 if raw_ids else 255              # raw id 0 = 'unlabeled' -> 255
     frame_labels = frame_labels.to(device)
+    luts = Cityscapes.label_luts(unknown) if raw_ids else None
     train_transform = et.ExtCompose([
         et.ExtRandomCrop(size=(opts.crop_size, opts.crop_size)),
         et.ExtColorJitter(brightness=0.5, contrast=0.5, saturation=0.5),
         et.ExtRandomHorizontalFlip(),
         et.ExtToTensor(),
         et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225]),
-    ])
+    ], label_luts=luts)
 
     # validation as main_embedding.py:172-324 of the reference reduced to its metric path: eval forward, argmax,
     # StreamSegMetrics.update on the device tensors (no .cpu().numpy() per batch), val transform = ToTensor + Normalize
     import metrics as metrics_mod
     seg_metrics = metrics_mod.StreamSegMetrics(opts.num_classes)                   # :382
     val_transform = et.ExtCompose([et.ExtToTensor(),
-                                   et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])])
+                                   et.ExtNormalize(mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])], label_luts=luts)
 
     def validate():
         seg_metrics.reset()                                                        # :228
         model.eval()
         with torch.no_grad():
             for b in range(min(opts.val_images, frames.shape[0])):
-                vi, vl = val_transform(frames[b:b + 1], frame_labels[b:b + 1])
+                vi, vl = val_transform(frames[b:b + 1], frame_labels[b:b + 1])[:2]
                 outputs, _, _ = model(vi)
                 preds, _ = utils.argmax_msp(outputs)                               # :262-266
                 seg_metrics.update(vl, preds)                                      # :269
@@ -134,7 +142,7 @@ def main():
     interval_loss, t0 = None, time.perf_counter()
     while cur_itrs < opts.total_itrs:
         cur_itrs += 1
-        images, labels = train_transform(frames, frame_labels)                     # :461-463 (loader + .to(device))
+        images, labels = train_transform(frames, frame_labels)[:2]                 # :461-463 (loader + .to(device))
         optimizer.zero_grad()
         outputs, centers, features = model(images)                                 # :466
         loss = criterion(outputs, labels, features)

@@ -98,8 +98,13 @@ class ExtNormalize(object):
 class ExtCompose(object):
     """[ExtRandomCrop]? [ExtColorJitter]? [ExtRandomHorizontalFlip]? ExtToTensor ExtNormalize, fused on the device."""
 
-    def __init__(self, transforms):
+    def __init__(self, transforms, label_luts=None):
+        """label_luts: optional (lut, lut_true) uint8[256] tables (datasets.Cityscapes.label_luts) -- the dataset's
+        encode_target folded into the crop kernel; __call__ then returns (images, labels, labels_true) like the
+        reference dataset's __getitem__ (datasets/cityscapes.py:171-197)."""
         self.transforms = list(transforms)
+        self.label_luts = label_luts
+        self._dev_luts = None
         order = [ExtRandomCrop, ExtColorJitter, ExtRandomHorizontalFlip, ExtToTensor, ExtNormalize]
         pos = -1
         self.crop = self.jitter = self.flip = self.norm = None
@@ -163,6 +168,20 @@ class ExtCompose(object):
         m, s = self.norm.mean, self.norm.std
         _lib.check(lib.dml_aug_contrast_sum(img.data_ptr(), dev_params.data_ptr(), lsum.data_ptr(), B, H, W, th, tw, st),
                    "dml_aug_contrast_sum")
+        if self.label_luts is not None:
+            if lbl is None:
+                raise ValueError("label tables were given but no labels")
+            if self._dev_luts is None or self._dev_luts[0].device != img.device:
+                self._dev_luts = tuple(torch.as_tensor(t, dtype=torch.uint8).to(img.device).contiguous()
+                                       for t in self.label_luts)
+                if any(t.numel() != 256 for t in self._dev_luts):
+                    raise ValueError("label tables have 256 entries")
+            olt = torch.empty_like(olb)
+            _lib.check(lib.dml_aug_apply_encoded(img.data_ptr(), lbl.data_ptr(), dev_params.data_ptr(), lsum.data_ptr(),
+                                                 out.data_ptr(), olb.data_ptr(), B, H, W, th, tw, m[0], m[1], m[2], s[0],
+                                                 s[1], s[2], self._dev_luts[0].data_ptr(), self._dev_luts[1].data_ptr(),
+                                                 olt.data_ptr(), st), "dml_aug_apply_encoded")
+            return (out[0], olb[0], olt[0]) if single else (out, olb, olt)
         _lib.check(lib.dml_aug_apply(img.data_ptr(), lbl.data_ptr() if lbl is not None else None, dev_params.data_ptr(),
                                      lsum.data_ptr(), out.data_ptr(), olb.data_ptr() if olb is not None else None, B, H, W,
                                      th, tw, m[0], m[1], m[2], s[0], s[1], s[2], st), "dml_aug_apply")

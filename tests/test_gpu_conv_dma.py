@@ -5,6 +5,7 @@ import os
 import subprocess
 import sys
 
+import numpy as np
 import pytest
 
 import helpers as H
@@ -53,3 +54,18 @@ def test_bench_script_default_path_small():
                         "256", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, cwd=H.ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert json.loads(r.stdout.strip().splitlines()[-1])["value"] > 0
+
+
+def test_train_driver_synthetic_with_raw_label_ids(tmp_path):
+    """main_embedding.py end to end at a small size: raw-id label frames -> crop / jitter / flip / encode_target in one
+    kernel -> train steps -> validation (device confusion matrix) -> checkpoint."""
+    drv = os.path.join(H.PKG, "main_embedding.py")
+    r = subprocess.run([sys.executable, drv, "--synthetic", "--crop_size", "128", "--batch_size", "4", "--total_itrs", "4",
+                        "--print_interval", "2", "--val_interval", "4", "--val_images", "1", "--frame_height", "160",
+                        "--frame_width", "224", "--loss_type", "dml", "--save_dir", str(tmp_path)],
+                       capture_output=True, text=True, cwd=H.PKG, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "Itrs 4/4, Loss=" in r.stdout and "Mean IoU" in r.stdout
+    loss = float(r.stdout.split("Itrs 4/4, Loss=")[1].split(",")[0])
+    assert np.isfinite(loss) and loss > 0
+    assert any(f.endswith(".pth") for f in os.listdir(tmp_path))

@@ -260,3 +260,91 @@ def test_prototype_extraction_matches_numpy_recipe():
     assert (utils.extract_prototype(fd, ld, 7) is None) == (frac7 <= 0.05)   # below the 5 % rule of the recipe
     proto = utils.mean_prototype(json.loads(json.dumps([got, got])))        # round trip through the json format
     assert np.allclose(proto, ref, rtol=1e-5, atol=1e-6)
+
+
+# ---- Cityscapes label encoding (datasets/cityscapes.py:132-154), fixture G13 minted from the reference class --------
+G13_CASES = ["none", "shipped", "train16", "one", "first"]
+
+
+def _g13():
+    return np.load(os.path.join(os.path.dirname(G9[0]), "g13_cityscapes_labels.npz"))
+
+
+@pytest.mark.parametrize("case", G13_CASES)
+def test_label_oracle_and_host_tables_match_reference_fixture(case):
+    from oracle import cityscapes_ref as CR
+    from datasets import Cityscapes
+    g = _g13()
+    unk = [int(v) for v in g["unk_" + case]] if case != "none" else None
+    t, tt = CR.encode_target(g["raw"], unk)
+    assert np.array_equal(t, g["target_" + case]) and np.array_equal(tt, g["true_" + case])
+    lut, lut_true = Cityscapes.label_luts(unk)                       # host logic of the product: one composed table
+    assert lut.dtype == np.uint8 and lut.shape == (256,)
+    assert np.array_equal(lut[g["raw"]].astype(np.int64), g["target_" + case])
+    assert np.array_equal(lut_true[g["raw"]].astype(np.int64), g["true_" + case])
+    assert (lut[34:] == 255).all()
+
+
+def test_label_class_table_and_eval_relabel_match_reference_fixture():
+    from oracle import cityscapes_ref as CR
+    from datasets import Cityscapes
+    g = _g13()
+    assert np.array_equal(Cityscapes.id_to_train_id, g["id_to_train_id"])
+    assert np.array_equal(Cityscapes.train_id_to_color, g["train_id_to_color"])
+    assert len(Cityscapes.classes) == 35 and Cityscapes.classes[26].name == "car" and Cityscapes.unknown_target == [14, 15]
+    assert np.array_equal(CR.eval_relabel(g["target_shipped"]), g["eval_relabel_shipped"])
+    lut2 = Cityscapes.eval_relabel_lut()
+    assert np.array_equal(lut2[g["target_shipped"]].astype(np.int64), g["eval_relabel_shipped"])
+    dec = Cityscapes.decode_target(torch.from_numpy(g["target_shipped"][0].copy()))
+    assert np.array_equal(dec.numpy(), g["decoded_shipped0"])
+    with pytest.raises(TypeError, match="no CPU fallback"):
+        Cityscapes.encode_target(torch.zeros(4, dtype=torch.uint8))
+    with pytest.raises(NotImplementedError):
+        Cityscapes("/nonexistent")
+
+
+@pytest.mark.gpu
+def test_label_encode_on_device_matches_reference_fixture():
+    from datasets import Cityscapes
+    g = _g13()
+    raw = torch.from_numpy(g["raw"]).cuda()
+    saved = Cityscapes.unknown_target
+    try:
+        for case in G13_CASES:
+            Cityscapes.unknown_target = [int(v) for v in g["unk_" + case]] if case != "none" else None
+            t, tt = Cityscapes.encode_target(raw)
+            assert t.dtype == torch.int64 and t.shape == raw.shape
+            assert np.array_equal(t.cpu().numpy(), g["target_" + case]), case
+            assert np.array_equal(tt.cpu().numpy(), g["true_" + case]), case
+            # odd sizes / misaligned views
+            v = raw.flatten()[3:3 + 1001]
+            t2, _ = Cityscapes.encode_target(v)
+            assert np.array_equal(t2.cpu().numpy(), g["target_" + case].reshape(-1)[3:3 + 1001])
+    finally:
+        Cityscapes.unknown_target = saved
+    e, _ = Cityscapes.encode_target(torch.empty(0, dtype=torch.uint8, device="cuda"))
+    assert e.numel() == 0
+
+
+@pytest.mark.gpu
+def test_device_pipeline_with_label_tables_equals_encode_after_transform():
+    """Reference order: transform (crop / flip on raw ids), then encode_target; the fused kernel must give that."""
+    import utils.ext_transforms as et
+    from datasets import Cityscapes
+    from oracle import cityscapes_ref as CR
+    rng = np.random.default_rng(5)
+    B, Hh, Ww, crop = 3, 70, 90, (48, 64)
+    img = rng.integers(0, 256, size=(B, Hh, Ww, 3), dtype=np.uint8)
+    lbl = rng.integers(0, 34, size=(B, Hh, Ww), dtype=np.uint8)
+    tf = [et.ExtRandomCrop(size=crop), et.ExtColorJitter(0.5, 0.5, 0.5), et.ExtRandomHorizontalFlip(), et.ExtToTensor(),
+          et.ExtNormalize(mean=MEAN, std=STD)]
+    plain = et.ExtCompose(tf)
+    fused = et.ExtCompose(tf, label_luts=Cityscapes.label_luts([13, 14, 15]))
+    random.seed(77)
+    xi, xl = plain(torch.from_numpy(img).cuda(), torch.from_numpy(lbl).cuda())
+    yi, yl, yt = fused(torch.from_numpy(img).cuda(), torch.from_numpy(lbl).cuda(), params=plain.last_params)
+    assert torch.equal(xi, yi)
+    want, want_true = CR.encode_target(xl.cpu().numpy().astype(np.uint8), [13, 14, 15])
+    assert yl.dtype == torch.int64 and np.array_equal(yl.cpu().numpy(), want)
+    assert np.array_equal(yt.cpu().numpy(), want_true)
+    assert {True, False} >= {p["flip"] for p in plain.last_params}
