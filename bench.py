@@ -420,7 +420,7 @@ def main():
                 tj = json.load(fh)
             traffic = tj["conv_GB_per_step"] * 1e9 / tj["conv_launches_per_step"]
             traffic_src = "profiles/r01_traffic_pmc.json (rocprofv3 --pmc, %.1f GB per step over the conv launches)" % tj["conv_GB_per_step"]
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_kernel + conv_wgrad_kernel (all conv launches of a step)",
+        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel + conv_wgrad_big_kernel / conv_wgrad_kernel (all conv launches of a step)",
                            "achieved": flops / conv_sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
                            "frac": flops / conv_sec / peak, "traffic": traffic, "traffic_unit": "bytes per launch (mean)",
                            "traffic_source": traffic_src,

@@ -177,7 +177,10 @@ int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const uint8_
                       const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
                       int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream);
 /* backward, pass 1b: fold partials, write dgamma/dbeta (+=) and the per-channel coefficients
- * coef[4][N] with dy = coef0*g + coef1*(y - coef3) + coef2  (coef3 = batch mean). */
+ * coef[4][N] with dy = coef0*g + coef1*(y - coef3) + coef2  (coef3 = batch mean).
+ * M = 0 selects a layer that normalised with FIXED statistics (BatchNorm2d.eval() inside a training step, the
+ * reference's main_self_distillation.py:432-435): save_mean / save_invstd are then the running statistics, the two
+ * correction terms are zero (coef1 = coef2 = 0) and dgamma / dbeta are unchanged. */
 int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                         float* coef, void* stream);

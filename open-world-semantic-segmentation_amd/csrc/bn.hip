@@ -326,8 +326,10 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
         const double dbeta_s = sh[0][0][ch], dgamma_s = sh[1][0][ch];
         const double g = gamma ? (double)gamma[n] : 1.0, is = save_invstd[n], mu = save_mean[n];
         const double A = g * is;
-        const double Bc = -A * is * dgamma_s / (double)M;
-        const double C0 = -A * dbeta_s / (double)M;
+        // M == 0: the layer normalised with FIXED (running) statistics -- they do not depend on the batch, so the two
+        // mean-correction terms of the batch-statistics backward vanish and dy = gamma * invstd * g
+        const double Bc = M > 0 ? -A * is * dgamma_s / (double)M : 0.0;
+        const double C0 = M > 0 ? -A * dbeta_s / (double)M : 0.0;
         coef[n] = (float)A; coef[N + n] = (float)Bc; coef[2 * N + n] = (float)C0; coef[3 * N + n] = (float)mu;
         if (dgamma) dgamma[n] += (float)dgamma_s;
         if (dbeta) dbeta[n] += (float)dbeta_s;
@@ -595,7 +597,7 @@ extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
 extern "C" int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                                    float* coef, void* stream) {
-    if (!partials || !save_mean || !save_invstd || !coef || nblocks <= 0 || N <= 0) return DML_EINVAL;
+    if (!partials || !save_mean || !save_invstd || !coef || nblocks <= 0 || N <= 0 || M < 0) return DML_EINVAL;
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
                        static_cast<hipStream_t>(stream), partials, nblocks, M, N, gamma, save_mean, save_invstd,
                        dgamma, dbeta, coef, (double*)nullptr);

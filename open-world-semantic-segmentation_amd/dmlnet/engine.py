@@ -199,7 +199,7 @@ class HeadRec:
 
 class ConvUnit:
     __slots__ = ("conv", "bn", "x", "y", "z", "relu", "res", "w", "wt", "scale", "shift", "mean", "invstd",
-                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy", "mask")
+                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy", "mask", "frozen")
 
 
 class Plan:
@@ -377,7 +377,20 @@ class Plan:
         u.scale, u.shift = self.fbuf(N), self.fbuf(N)
         g_ptr, b_ptr = bn.weight.data_ptr(), bn.bias.data_ptr()
         mean_ptr = bn.running_mean.data_ptr()
-        if self.training:
+        u.frozen = self.training and not bn.training
+        if u.frozen:
+            # BatchNorm2d.eval() inside a training step (main_self_distillation.py:432-435 of the reference): normalise
+            # with the running statistics, leave them alone; gamma / beta still train.  scale / shift / invstd come from
+            # the coefficient table launch at the head of the plan (two rows: the second with gamma = beta = None
+            # yields 1/sqrt(var + eps) itself), the backward is the batch-statistics one without its correction terms.
+            u.mean, u.invstd = bn.running_mean, self.fbuf(N)
+            dummy = self.fbuf(N)
+            self.bn_eval.append(_lib.BnEvalDesc(g_ptr, b_ptr, bn.running_var.data_ptr(), u.scale.data_ptr(),
+                                                u.shift.data_ptr(), N, float(bn.eps)))
+            self.bn_eval.append(_lib.BnEvalDesc(None, None, bn.running_var.data_ptr(), u.invstd.data_ptr(),
+                                                dummy.data_ptr(), N, float(bn.eps)))
+            self.conv_fwd(x, conv, u.y, u.w, None)
+        elif self.training:
             groups = (M + STAT_ROWS - 1) // STAT_ROWS
             assert groups * N * 2 <= self.scratch.numel(), "BN statistics scratch too small"
             u.mean, u.invstd = self.fbuf(N), self.fbuf(N)
@@ -455,7 +468,7 @@ class Plan:
             a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, mk, u.mean.data_ptr(),
                            u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if u.relu else 0, 1.0,
                            self.dt, C.byref(nblk))
-        if self.sync:
+        if self.sync and not u.frozen:
             sums = self.dbuf(N * 2)
             self.call(self.bwd, lib.dml_bn_bwd_sums, sp, nblk, N, sums.data_ptr(), st.grad_ptr_of(bn.weight),
                       st.grad_ptr_of(bn.bias))
@@ -464,7 +477,7 @@ class Plan:
             self.call(self.bwd, lib.dml_bn_bwd_coef, sums.data_ptr(), M * self.world, N, bn.weight.data_ptr(),
                       u.mean.data_ptr(), u.invstd.data_ptr(), coef.data_ptr())
         else:
-            self.call(self.bwd, lib.dml_bn_bwd_finalize, sp, nblk, M, N, bn.weight.data_ptr(),
+            self.call(self.bwd, lib.dml_bn_bwd_finalize, sp, nblk, 0 if u.frozen else M, N, bn.weight.data_ptr(),
                       u.mean.data_ptr(), u.invstd.data_ptr(), st.grad_ptr_of(bn.weight),
                       st.grad_ptr_of(bn.bias), coef.data_ptr())
         self.mark_grad(bn.weight)
@@ -486,13 +499,15 @@ class Plan:
         B, H, W = self.B, self.H, self.W
         bb, head_modules = m.backbone, self.e.head_modules()
         self.pre_prep = []
+        n_fixed = 0
         for mod in itertools.chain(bb.modules(), *[h.modules() for h in head_modules]):
-            if isinstance(mod, nn.BatchNorm2d) and mod.training != self.training:
-                raise NotImplementedError("BatchNorm2d modules in a different mode than the model (fix_bn) are not "
-                                          "supported on the MI355X path")
+            if isinstance(mod, nn.BatchNorm2d):
+                if mod.training and not self.training:
+                    raise NotImplementedError("a BatchNorm2d in train() mode inside an eval() model is not supported")
+                n_fixed += 0 if mod.training else 1
 
         self.bn_eval = []
-        if not self.training:
+        if n_fixed:
             self.bn_eval_args = self.call(self.fwd, lib.dml_bn_eval_coeffs_table, 0, 0)      # filled in below
         # input packing NCHW fp32 -> NHWC (8 ch)
         x_in = self.new(B, H, W, _PAD_CIN)
@@ -531,10 +546,15 @@ class Plan:
         # heads: one for the DMLNet model, several (shared backbone) for the self-distillation model (utils.py:120-193)
         self.heads = [self._head_fwd(h, low, out) for h in head_modules]
         self.K, self.Kp = self.heads[0].K, self.heads[0].Kp
-        if not self.training:
+        self.nbt_inc = None
+        if self.training and n_fixed:
+            self.nbt_inc = torch.tensor([1 if mod.training else 0 for mod in st.bn_modules], dtype=torch.int64,
+                                        device=self.device)
+        if self.bn_eval:
             arr = (_lib.BnEvalDesc * len(self.bn_eval))(*self.bn_eval)
             self.bn_eval_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
             self.bn_eval_args[0], self.bn_eval_args[1] = self.bn_eval_table.data_ptr(), len(self.bn_eval)
+        if not self.training:
             return
 
         # ------------------------------------------------------------------ backward
@@ -785,13 +805,24 @@ class Engine:
             self._protos[key] = m
         return self._protos[key]
 
+    def bn_modes(self) -> int:
+        """Bit i set = the i-th BatchNorm2d normalises with its running statistics (module in eval()) -- part of the
+        plan key, because a training plan is built around each layer's mode."""
+        if getattr(self, "_bn_list", None) is None:
+            self._bn_list = self.store.bn_modules
+        sig = 0
+        for i, m in enumerate(self._bn_list):
+            if not m.training:
+                sig |= 1 << i
+        return sig
+
     def plan_for(self, x: torch.Tensor, dtype: torch.dtype, training: bool) -> Plan:
         if not self.store.is_bound(x.device):
             self.store.bind(x.device)
             self.plans.clear()
             self._protos.clear()
         B, Cin, H, W = x.shape
-        key = (B, H, W, dtype, training, bool(self.sync_bn))
+        key = (B, H, W, dtype, training, bool(self.sync_bn), self.bn_modes() if training else 0)
         plan = self.plans.get(key)
         if plan is None:
             plan = Plan(self, B, H, W, dtype, training)
@@ -804,7 +835,7 @@ class Engine:
                                "in oracle/ and is test infrastructure only" % x.device)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected input [B,3,H,W], got %s" % (tuple(x.shape),))
-        if training and x.shape[0] < 2:
+        if training and x.shape[0] < 2 and self.bn_modes() != (1 << len(self._bn_list)) - 1:
             # same failure as the reference: BatchNorm over B x 256 x 1 x 1 in ASPPPooling (network/utils.py:318-329)
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              "torch.Size([%d, 256, 1, 1])" % x.shape[0])
@@ -834,7 +865,10 @@ class Engine:
                 u.apply_args[15] = (self.seed + 0x9E3779B97F4A7C15 * self.step_count) & 0xFFFFFFFFFFFFFFFF
                 for (a, i) in u.gscale_slots:
                     a[i] = 1.0 / (1.0 - p) if p > 0 else 1.0
-            self.store.flat_nbt.add_(1)
+            if plan.nbt_inc is None:
+                self.store.flat_nbt.add_(1)
+            else:
+                self.store.flat_nbt.add_(plan.nbt_inc)      # layers with fixed statistics do not count the batch
         Plan.run(plan.fwd, stream)
         plan.last_input = x
         for hi, rec in enumerate(plan.heads):

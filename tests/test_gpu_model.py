@@ -235,9 +235,11 @@ def test_default_factory_arguments_bf16_features_have_num_classes_channels():
     assert g.shape == (21, 256, 1, 1) and torch.isfinite(g).all() and g.abs().max() > 0
 
 
-def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_stride=16):
+def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_stride=16, prep=None):
     import utils
     from oracle import dmlnet_ref as O
+    if prep is not None:
+        prep(m)
     lg, _, ft = m(img.cuda())
     loss = utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft)
     loss.backward()
@@ -248,6 +250,8 @@ def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_s
         o = o.to(dt)
         o.train()
         o.classifier.aspp.project[3].eval()
+        if prep is not None:
+            prep(o)
         olg, _, oft = o(img.to(dt))
         oloss = O.dml_loss(olg, lab, alpha=0.01, ignore_index=255)
         oloss.backward()
@@ -284,6 +288,57 @@ def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_s
     assert np.median(e_hip) <= 3 * np.median(e_ref) + TOL
     assert np.percentile(e_hip, 95) <= 3 * np.percentile(e_ref, 95) + TOL
     assert e_hip.max() <= 10 * e_ref.max() + TOL
+
+
+def _freeze_bn(which):
+    def prep(model):
+        for name, mod in model.named_modules():
+            if isinstance(mod, torch.nn.BatchNorm2d) and (which == "all" or name.startswith(which)):
+                mod.eval()
+    return prep
+
+
+@pytest.mark.parametrize("which", ["all", "backbone."])
+def test_train_step_with_fixed_batchnorm_statistics(which):
+    """model.train() with BatchNorm2d modules in eval() (main_self_distillation.py:432-435 of the reference freezes all
+    of them; freezing only the backbone is the other common recipe): running statistics normalise and stay untouched,
+    gamma / beta and everything upstream still get their gradients."""
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    m = build(seed=33)
+    before = {k: v.clone() for k, v in m.state_dict().items() if "running_" in k or "num_batches" in k}
+    img = H.synth_tensor(33, "fix.img", (2, 3, 64, 80))
+    lab = H.synth_labels(33, "fix.lab", (2, 64, 80), 16, 255, ignore_frac=0.05)
+    _check_against_oracles(m, img, lab, strict=None, seed=33, prep=_freeze_bn(which))
+    after = m.state_dict()
+    changed = [k for k in before if not torch.equal(before[k], after[k])]
+    if which == "all":
+        assert not changed, changed[:5]
+    else:
+        assert changed and all(k.startswith("classifier.") for k in changed)
+        assert int(after["classifier.project.1.num_batches_tracked"]) == int(before["classifier.project.1.num_batches_tracked"]) + 1
+        assert int(after["backbone.bn1.num_batches_tracked"]) == int(before["backbone.bn1.num_batches_tracked"])
+    g = m.backbone.layer3[5].bn2.weight.grad
+    assert g is not None and torch.isfinite(g).all() and g.abs().max() > 0
+    if which == "all":
+        # no batch statistics anywhere: a single image is a legal training batch now (the reference's B >= 2 rule comes
+        # from the pooled ASPP branch's BatchNorm, network/utils.py:318-329)
+        lg1, _, _ = m(img[:1].cuda())
+        assert lg1.shape == (1, 16, 64, 80) and torch.isfinite(lg1).all()
+        # ... and the bf16 plan (fused backward sums in the data gradients) tracks the fp32 one
+        import utils
+        mb = build(dtype=torch.bfloat16, seed=33)
+        _freeze_bn("all")(mb)
+        lgb, _, ftb = mb(img.cuda())
+        utils.DMLLoss(alpha=0.01, ignore_index=255)(lgb, lab.cuda(), ftb).backward()
+        mf = build(seed=33)
+        _freeze_bn("all")(mf)
+        lg, _, ft = mf(img.cuda())
+        utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft).backward()
+        relclose(lgb, lg, 0.15, "bf16 logits vs fp32 logits, fixed statistics")
+        for mod_b, mod_f in ((mb.classifier.classifier[3], mf.classifier.classifier[3]),
+                             (mb.backbone.layer4[2].bn3, mf.backbone.layer4[2].bn3)):
+            gb, gf = mod_b.weight.grad.flatten(), mod_f.weight.grad.flatten()
+            assert torch.isfinite(gb).all() and torch.nn.functional.cosine_similarity(gb, gf, dim=0).item() > 0.95
 
 
 def test_features_out_carries_grad_and_eval_no_grad():
