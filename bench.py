@@ -431,6 +431,10 @@ def main():
                            "note": "data-gradient launches also compute the BatchNorm-backward sums of the tensor they "
                                    "write (88 of 112 bn_bwd_reduce launches folded into their epilogues); their time is "
                                    "charged to the convolutions here"}
+        if traffic is not None:
+            # the same launches against the OTHER roof: residual accumulates, fused BN sums and split-K partials make
+            # several of the 1x1 layers bandwidth-bound (e.g. the 256->1024 data gradient moves ~250 MB in 90 us)
+            out["roofline"]["hbm_frac_of_same_launches"] = traffic * n_launch / conv_sec / 8e12
         out["hbm_kernel"] = bench_distance_kernel(args.batch, args.size, device)
         out["input_pipeline"] = bench_input_pipeline(args.batch, args.size, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
