@@ -309,6 +309,53 @@ def infer_bench(args):
         dist.destroy_process_group()
 
 
+def ood_bench(args):
+    """SURVEY 8(f) rank 2 (not the headline line): the open-set evaluation of anomaly/eval_ood_traditional.py:190-305 for
+    one StreetHazards-sized frame -- five resized copies (short side 300..600, long side <= 1000, padded to multiples of
+    8: config imgSizes / imgMaxSize / padding_constant) through ResNet-50-dilated + pyramid-pooling embedding decoder, scores
+    averaged at 720x1280 inside the upsample kernel, argmax, dissum score (clip 400), AUROC / AUPR / FPR95 on the device."""
+    torch.cuda.set_device(0)
+    device = torch.device("cuda", 0)
+    import anom_utils
+    import models
+    import utils
+    torch.manual_seed(1)
+    enc = models.ModelBuilder.build_encoder("resnet50dilated", fc_dim=2048)
+    dec = models.ModelBuilder.build_decoder("ppm_deepsup_embedding", fc_dim=2048, num_class=13, use_softmax=True)
+    m = models.SegmentationModuleOOD(enc, dec, None).to(device).eval()
+    m.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    Hs, Ws = 720, 1280
+    g = torch.Generator().manual_seed(99)
+    imgs = []
+    for short in (300, 375, 450, 525, 600):
+        sc = min(short / float(min(Hs, Ws)), 1000.0 / float(max(Hs, Ws)))
+        h, w = (int(Hs * sc) + 7) // 8 * 8, (int(Ws * sc) + 7) // 8 * 8
+        imgs.append(torch.randn(1, 3, h, w, generator=g).to(device))
+    label = torch.randint(0, 14, (Hs, Ws), generator=g).to(device)          # 13 = the anomaly class
+
+    def step():
+        scores, ft = models.evaluate_multiscale(m, imgs, (Hs, Ws))
+        preds, _ = utils.argmax_msp(scores)
+        conf = utils.dissum_score(scores, clip=400.0, inclusive=True)
+        return preds, anom_utils.eval_ood_measure(conf[0], label, (13,))
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        preds, res = step()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    print(json.dumps({
+        "metric": "images/sec open-set evaluation (5-scale ResNet-50-dilated + PPM embedding decoder, dissum, AUROC/AUPR/FPR95)",
+        "value": args.steps / elapsed, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": "one 720x1280 frame, inputs %s, segSize 720x1280, 13 prototypes, random-init weights"
+                               % ", ".join("%dx%d" % (t.shape[2], t.shape[3]) for t in imgs), "parallelism": "dp1"}}))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -321,12 +368,14 @@ def main():
     ap.add_argument("--no-profile", action="store_true")
     ap.add_argument("--cpu-threads", type=int, default=0)
     ap.add_argument("--dump-conv", default=None, help="write a per-launch conv table (json) from the profiled pass")
-    ap.add_argument("--mode", default="train", choices=["train", "infer"],
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "ood"],
                     help="train = the headline metric (default); infer = SURVEY 8(d) config #5: open-world inference "
                          "at --height x --width, --batch images per step (default 1), scores on the device")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     args = ap.parse_args()
+    if args.mode == "ood":
+        return ood_bench(args)
     if args.mode == "infer":
         return infer_bench(args)
 

@@ -310,6 +310,25 @@ int dml_label_encode(const uint8_t* raw, int64_t n, const uint8_t* lut, const ui
                      int64_t* out, int64_t* out_true, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
+ * Pyramid-pooling decoder of the anomaly model (anomaly/models/models.py:586-687,
+ * eval_ood_traditional.py:198-210 of the reference), inference only.
+ * ---------------------------------------------------------------------------------------------- */
+/* nn.AdaptiveAvgPool2d(S) on NHWC x[B,H,W,C] (pitch ldx) -> y[B,S,S,C] (dense): bin i = [floor(i*H/S), ceil((i+1)*H/S)).
+ * ws: caller-owned fp32 workspace of dml_adaptive_avgpool_ws_elems(...) elements (two deterministic stages). */
+int64_t dml_adaptive_avgpool_ws_elems(int B, int H, int W, int C, int S);
+int dml_adaptive_avgpool_fwd(const void* x, void* y, float* ws, int B, int H, int W, int C, int ldx, int S,
+                             int dtype, void* stream);
+/* out[m][k] = -sum_c (emb[m][c] - protos[k][c])^2 for k < K on an NHWC fp32 embedding with Kp (<= 32) channels
+ * (pad channels zero in emb and protos[K][Kp]); out channels K..Kp-1 = 0.  models.py:633-657: the distance is
+ * taken at 1/8 resolution, BEFORE the upsample. */
+int dml_proto_dist_nhwc(const float* emb, const float* protos, float* out, int64_t M, int K, int Kp, int lde,
+                        int ldo, void* stream);
+/* dst[B,C,H,W] (+)= alpha * bilinear(src[B,h,w,ld] channels 0..C-1), align_corners = False -- F.interpolate to
+ * segSize (models.py:659-668) with the multi-scale mean `scores = scores + scores_tmp / n` folded in. */
+int dml_upsample_nhwc_to_nchw(const float* src, float* dst, int B, int h, int w, int ld, int C, int H, int W,
+                              float alpha, int accumulate, void* stream);
+
+/* ------------------------------------------------------------------------------------------------
  * Streaming segmentation metrics on the device (the step after the path):
  * hist[n*t + p] += 1 for every pixel with 0 <= t < n (and 0 <= p < n), the np.bincount of
  * metrics/stream_metrics.py:49-55.  hist is a device int64[n*n] that the call accumulates into;

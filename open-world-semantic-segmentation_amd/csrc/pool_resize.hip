@@ -378,3 +378,167 @@ extern "C" int dml_bilinear_bwd(const void* dy, void* dx, int B, int h, int w, i
                                 int lddx, int dtype, int in_f32, int out_f32, void* stream) {
     return launch_bilinear<true>(dy, dx, B, h, w, H, W, C, lddy, lddx, dtype, in_f32, out_f32, stream);
 }
+
+// ------------------------------------------------------------------------------------------------
+// Pyramid pooling pieces of the anomaly model's decoder (anomaly/models/models.py:586-687 of the reference,
+// SURVEY 8(f) rank 2): nn.AdaptiveAvgPool2d(s) on NHWC features, the 13-prototype distance on the 1/8-resolution
+// embedding, and F.interpolate(..., size=segSize, bilinear) of an NHWC fp32 map into the NCHW score tensor with the
+// multi-scale average of eval_ood_traditional.py:198-210 (scores += scores_tmp / n) folded into the store.
+// ------------------------------------------------------------------------------------------------
+namespace {
+__device__ __forceinline__ int bin_lo(int i, int n, int s) { return (int)(((int64_t)i * n) / s); }
+__device__ __forceinline__ int bin_hi(int i, int n, int s) { return (int)((((int64_t)(i + 1)) * n + s - 1) / s); }
+
+// stage 1: per (image, bin, row slice) fp32 sums; thread = one 16-byte channel vector, rows walked in a fixed order
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_pool_partial_kernel(const T* __restrict__ x, float* __restrict__ part, int H,
+                                                                    int W, int C, int ldx, int S, int RS) {
+    constexpr int V = Vec16<T>::N;
+    const int cv = blockIdx.y * 256 + threadIdx.x;
+    if (cv * V >= C) return;
+    const int rs = blockIdx.x % RS, bin = blockIdx.x / RS;
+    const int j = bin % S, i = (bin / S) % S, b = bin / (S * S);
+    const int y0 = bin_lo(i, H, S), y1 = bin_hi(i, H, S), x0 = bin_lo(j, W, S), x1 = bin_hi(j, W, S);
+    const int rows = (y1 - y0 + RS - 1) / RS;
+    const int ya = y0 + rs * rows, yb = min(y1, ya + rows);
+    float acc[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) acc[q] = 0.f;
+    for (int y = ya; y < yb; ++y) {
+        const T* row = x + (((int64_t)b * H + y) * W) * ldx + cv * V;
+#pragma unroll 4
+        for (int xx = x0; xx < x1; ++xx) {
+            float v[V];
+            Vec16<T>::load(row + (int64_t)xx * ldx, v);
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[q] += v[q];
+        }
+    }
+    float* o = part + ((int64_t)blockIdx.x * C) + cv * V;
+#pragma unroll
+    for (int q = 0; q < V; ++q) o[q] = acc[q];
+}
+template <typename T>
+__global__ __launch_bounds__(256) void adaptive_pool_finish_kernel(const float* __restrict__ part, T* __restrict__ y, int bins,
+                                                                   int H, int W, int C, int S, int RS) {
+    const int64_t total = (int64_t)bins * C;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int c = (int)(t % C), bin = (int)(t / C);
+        const int j = bin % S, i = (bin / S) % S;
+        const int cnt = (bin_hi(i, H, S) - bin_lo(i, H, S)) * (bin_hi(j, W, S) - bin_lo(j, W, S));
+        float s = 0.f;
+        for (int r = 0; r < RS; ++r) s += part[((int64_t)bin * RS + r) * C + c];
+        Elem<T>::st(y + t, s / (float)cnt);
+    }
+}
+
+// out[m][k] = -sum_c (e[m][c] - P[k][c])^2 on the low-resolution NHWC embedding (k < K; pad channels of out = 0)
+__global__ __launch_bounds__(256) void proto_dist_nhwc_kernel(const float* __restrict__ e, const float* __restrict__ protos,
+                                                              float* __restrict__ out, int64_t M, int K, int Kp, int lde,
+                                                              int ldo) {
+    __shared__ float P[33 * 32];
+    for (int t = threadIdx.x; t < K * Kp; t += 256) P[t] = protos[t];
+    __syncthreads();
+    for (int64_t m = (int64_t)blockIdx.x * 256 + threadIdx.x; m < M; m += (int64_t)gridDim.x * 256) {
+        float f[32];
+        for (int c = 0; c < Kp; ++c) f[c] = e[m * lde + c];
+        for (int k = 0; k < Kp; ++k) {
+            float d = 0.f;
+            if (k < K)
+                for (int c = 0; c < Kp; ++c) {
+                    const float t = f[c] - P[k * Kp + c];
+                    d += t * t;
+                }
+            out[m * ldo + k] = k < K ? -d : 0.f;
+        }
+    }
+}
+
+// dst[b][c][Y][X] (+)= alpha * bilinear(src[b][.][.][c]); 4 consecutive X per thread, 16-byte stores when aligned
+__global__ __launch_bounds__(256) void upsample_to_nchw_kernel(const float* __restrict__ src, float* __restrict__ dst, int B,
+                                                               int h, int w, int ld, int C, int H, int W, float sy, float sx,
+                                                               float alpha, int accumulate) {
+    const int W4 = (W + 3) / 4;
+    const int64_t total = (int64_t)B * C * H * W4;
+    const bool vec = (W & 3) == 0 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0;
+    for (int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x; t < total; t += (int64_t)gridDim.x * 256) {
+        const int xq = (int)(t % W4);
+        int64_t p = t / W4;
+        const int Y = (int)(p % H); p /= H;
+        const int c = (int)(p % C);
+        const int b = (int)(p / C);
+        const Lerp ly = src_index(Y, sy, h);
+        const float* r0 = src + (((int64_t)b * h + ly.i0) * w) * ld + c;
+        const float* r1 = src + (((int64_t)b * h + ly.i1) * w) * ld + c;
+        float o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int X = min(xq * 4 + e, W - 1);
+            const Lerp lx = src_index(X, sx, w);
+            o[e] = alpha * (ly.l0 * (lx.l0 * r0[(int64_t)lx.i0 * ld] + lx.l1 * r0[(int64_t)lx.i1 * ld]) +
+                            ly.l1 * (lx.l0 * r1[(int64_t)lx.i0 * ld] + lx.l1 * r1[(int64_t)lx.i1 * ld]));
+        }
+        float* d = dst + (((int64_t)b * C + c) * H + Y) * W + xq * 4;
+        if (vec) {
+            float4 v = make_float4(o[0], o[1], o[2], o[3]);
+            if (accumulate) {
+                const float4 old = *reinterpret_cast<const float4*>(d);
+                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+            }
+            *reinterpret_cast<float4*>(d) = v;
+        } else {
+            for (int e = 0; e < 4 && xq * 4 + e < W; ++e) d[e] = accumulate ? d[e] + o[e] : o[e];
+        }
+    }
+}
+}  // namespace
+
+extern "C" int64_t dml_adaptive_avgpool_ws_elems(int B, int H, int W, int C, int S) {
+    if (B <= 0 || H <= 0 || W <= 0 || C <= 0 || S <= 0) return 0;
+    const int rows = (H + S - 1) / S + 1;
+    const int RS = rows < 16 ? rows : 16;
+    return (int64_t)B * S * S * RS * C;
+}
+extern "C" int dml_adaptive_avgpool_fwd(const void* x, void* y, float* ws, int B, int H, int W, int C, int ldx, int S,
+                                        int dtype, void* stream) {
+    if (!x || !y || !ws || B <= 0 || H <= 0 || W <= 0 || S <= 0 || S > H || S > W) return DML_EINVAL;
+    if (!vec_ok(dtype, C) || !vec_ok(dtype, ldx)) return DML_EALIGN;
+    const int rows = (H + S - 1) / S + 1;
+    const int RS = rows < 16 ? rows : 16;
+    const int V = dtype == DML_BF16 ? 8 : 4;
+    const int bins = B * S * S;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    dim3 grid(bins * RS, (C / V + 255) / 256);
+    const int fgrid = grid_for((int64_t)bins * C, 256);
+    if (dtype == DML_BF16) {
+        hipLaunchKernelGGL(adaptive_pool_partial_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, ws, H, W, C, ldx, S, RS);
+        hipLaunchKernelGGL(adaptive_pool_finish_kernel<bf16_t>, dim3(fgrid), dim3(256), 0, st, ws, (bf16_t*)y, bins, H, W, C, S, RS);
+    } else {
+        hipLaunchKernelGGL(adaptive_pool_partial_kernel<float>, grid, dim3(256), 0, st, (const float*)x, ws, H, W, C, ldx, S, RS);
+        hipLaunchKernelGGL(adaptive_pool_finish_kernel<float>, dim3(fgrid), dim3(256), 0, st, ws, (float*)y, bins, H, W, C, S, RS);
+    }
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_proto_dist_nhwc(const float* emb, const float* protos, float* out, int64_t M, int K, int Kp, int lde,
+                                   int ldo, void* stream) {
+    if (!emb || !protos || !out || M <= 0 || K <= 0 || K > 33 || Kp < 1 || Kp > 32 || K > Kp + 1 || lde < Kp || ldo < Kp)
+        return DML_EINVAL;
+    if (K > Kp) return DML_EUNSUPPORTED;          // one output channel per prototype inside the padded width
+    hipLaunchKernelGGL(proto_dist_nhwc_kernel, dim3(grid_for(M, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), emb,
+                       protos, out, M, K, Kp, lde, ldo);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_upsample_nhwc_to_nchw(const float* src, float* dst, int B, int h, int w, int ld, int C, int H, int W,
+                                         float alpha, int accumulate, void* stream) {
+    if (!src || !dst || B <= 0 || h <= 0 || w <= 0 || C <= 0 || C > ld || H <= 0 || W <= 0) return DML_EINVAL;
+    const int64_t items = (int64_t)B * C * H * ((W + 3) / 4);
+    hipLaunchKernelGGL(upsample_to_nchw_kernel, dim3(grid_for(items, 256, 256 * 32)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, dst, B, h, w, ld, C, H, W, (float)h / (float)H,
+                       (float)w / (float)W, alpha, accumulate);
+    DML_LAUNCH_CHECK();
+    return 0;
+}

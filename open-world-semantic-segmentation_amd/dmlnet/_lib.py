@@ -113,6 +113,10 @@ _PROTOS = {
     "dml_aug_apply_encoded": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_f, c_f, c_f, c_f, c_f,
                                     c_p, c_p, c_p, c_p]),
     "dml_label_encode": (c_i, [c_p, C.c_int64, c_p, c_p, c_p, c_p, c_p]),
+    "dml_adaptive_avgpool_ws_elems": (c_i64, [c_i, c_i, c_i, c_i, c_i]),
+    "dml_adaptive_avgpool_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_proto_dist_nhwc": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
+    "dml_upsample_nhwc_to_nchw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
 }
 
 EXPORTS = tuple(_PROTOS.keys())

@@ -763,6 +763,8 @@ class Plan:
 class Engine:
     """Owns the parameter store and the plan cache of one model instance."""
 
+    plan_cls = Plan
+
     def __init__(self, model: nn.Module):
         self.model = model
         self.lib = _lib.load()
@@ -825,7 +827,7 @@ class Engine:
         key = (B, H, W, dtype, training, bool(self.sync_bn), self.bn_modes() if training else 0)
         plan = self.plans.get(key)
         if plan is None:
-            plan = Plan(self, B, H, W, dtype, training)
+            plan = self.plan_cls(self, B, H, W, dtype, training)
             self.plans[key] = plan
         return plan
 
