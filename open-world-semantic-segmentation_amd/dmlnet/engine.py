@@ -561,11 +561,15 @@ class Plan:
         # The LAST head goes first: it initialises d(out) / d(low); the others accumulate into them, so their
         # segments of the plan can be skipped when the loss does not reach them (Engine.backward).
         self.head_bwd_range = {}
+        self.to_backbone_ops = []
         for hi in reversed(range(len(self.heads))):
             start = len(self.bwd)
             self._head_bwd(self.heads[hi], low, out)
             self.head_bwd_range[hi] = (start, len(self.bwd))
-        # bottlenecks in reverse
+        # bottlenecks in reverse (this whole segment, and the head ops that only feed it, are skipped when no backbone
+        # parameter requires a gradient: the reference's incremental recipe trains one new head on a fixed trunk,
+        # main_self_distillation.py:352-357)
+        backbone_start = len(self.bwd)
         for (xb, u1, u2, u3, ud) in reversed(blocks):
             dz = self.grad_of(u3.z)
             if ud is not None:
@@ -585,6 +589,7 @@ class Plan:
         self.call(self.bwd, lib.dml_maxpool3x3s2_bwd, self.grad_of(p0).ptr, amax.data_ptr(), dz0.ptr, B, z0.H, z0.W,
                   64, self.dt)
         self.unit_bwd(stem, dz0, need_dgrad=False)
+        self.backbone_bwd_range = (backbone_start, len(self.bwd))
 
     def _head_fwd(self, head: nn.Module, low: Act, out: Act):
         """DeepLabHeadV3Plus + final upsample + distance head (network/utils.py:8-32,84-118) on the backbone features."""
@@ -682,13 +687,17 @@ class Plan:
         self.call(self.bwd, lib.dml_reduce_hw, dcat1.slice(1024, 256).ptr, dzp.ptr, B, out.H * out.W, 256, dcat1.ld,
                   self.dt)
         self.unit_bwd(upool, dzp)                                        # -> d pooled
+        feeders = self.to_backbone_ops                 # backward ops whose only product is d(out) / d(low)
         for i in range(4):
             self.unit_bwd(branches[i], dcat1.slice(256 * i, 256))       # -> d out (accumulating)
+            feeders.append(len(self.bwd) - 1)           # unit_bwd ends with the data gradient
         self.call(self.bwd, lib.dml_avgpool_bwd_add, self.grad_of(pooled).ptr, self.grad_of(out).ptr, B,
                   out.H * out.W, out.C, self.grad_of(out).ld, self.dt)
+        feeders.append(len(self.bwd) - 1)
         self.last_dgrad.pop(self.grad_of(out).ptr, None)      # not a data gradient: layer4's last BN keeps its own reduce
         # low-level projection -> d low (layer1 output)
         self.unit_bwd(up_low, dcat2.slice(0, 48))
+        feeders.append(len(self.bwd) - 1)
 
     # ---- execution ---------------------------------------------------------------------------
     def refresh_weights(self, stream):
@@ -904,6 +913,9 @@ class Engine:
             a[2] = rec.feats_p.data_ptr()
             keep += [gl, gf]
         self._keep_bwd = keep
+        if not any(p.requires_grad for p in self.model.backbone.parameters()):
+            skip.append(plan.backbone_bwd_range)
+            skip += [(i, i + 1) for i in plan.to_backbone_ops]
         plan.skip_ranges = skip
         self.store.begin_backward()
         if self.reducer is not None:

@@ -65,8 +65,10 @@ class FusedSGD(torch.optim.Optimizer):
                 return loss                       # no forward/backward happened yet
             if st.flat_v is None or st.flat_v.device != st.flat_p.device:
                 st.flat_v = torch.zeros_like(st.flat_p)
+                mine = {id(q) for g in self.param_groups for q in g["params"]}
                 for p, off in zip(st.params, st.offsets):
-                    self.state[p]["momentum_buffer"] = st._view(st.flat_v, off, p)
+                    if id(p) in mine:            # a parameter outside every group has no optimizer state (state_dict())
+                        self.state[p]["momentum_buffer"] = st._view(st.flat_v, off, p)
             # gradients that are not views of the flat buffer (foreign autograd use) are folded in
             for p, gv in zip(st.params, st.grad_views):
                 if p.grad is None:

@@ -69,3 +69,29 @@ def test_train_driver_synthetic_with_raw_label_ids(tmp_path):
     loss = float(r.stdout.split("Itrs 4/4, Loss=")[1].split(",")[0])
     assert np.isfinite(loss) and loss > 0
     assert any(f.endswith(".pth") for f in os.listdir(tmp_path))
+
+
+def test_incremental_head_driver_synthetic(tmp_path):
+    """main_self_distillation.py end to end at a small size (base checkpoint -> two-head model, pseudo-labels on)."""
+    import torch
+    import network
+    base = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    base.load_state_dict(H.synth_state_dict(H.shapes_of(base), seed=3))      # a conditioned trunk: running statistics are used as they are
+    ck = os.path.join(str(tmp_path), "base.pth")
+    torch.save({"model_state": base.state_dict(), "cur_itrs": 0, "best_score": 0.0}, ck)
+    drv = os.path.join(H.PKG, "main_self_distillation.py")
+    r = subprocess.run([sys.executable, drv, "--synthetic", "--crop_size", "128", "--batch_size", "4", "--total_itrs", "4",
+                        "--print_interval", "2", "--frame_height", "160", "--frame_width", "224", "--ckpt", ck,
+                        "--pseudo_labels", "--save_interval", "4", "--save_dir", str(tmp_path)],
+                       capture_output=True, text=True, cwd=H.PKG, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "Itrs 4/4, Loss=" in r.stdout
+    loss = float(r.stdout.split("Itrs 4/4, Loss=")[1].split(",")[0])
+    assert np.isfinite(loss) and loss > 0
+    out = torch.load(os.path.join(str(tmp_path), "latest_deeplabv3plus_embedding_self_distillation_resnet101_synthetic.pth"),
+                     map_location="cpu")["model_state"]
+    sd = base.state_dict()
+    # trunk and base head untouched by the four steps, the new head moved
+    assert torch.equal(out["backbone.layer3.5.conv2.weight"], sd["backbone.layer3.5.conv2.weight"])
+    assert torch.equal(out["classifier.classifier.3.weight"], sd["classifier.classifier.3.weight"])
+    assert torch.equal(out["backbone.bn1.running_mean"], sd["backbone.bn1.running_mean"])

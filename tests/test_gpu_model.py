@@ -497,3 +497,30 @@ def test_self_distillation_model_both_heads_against_oracle():
     # a missing or doubled head contribution to d(out) / d(low) would put O(1) errors on every backbone tensor; single
     # early-layer tensors sit at a few % from ReLU sign flips on this input (measured: median 1.7e-4, p95 6.6e-3, max 8.4e-2)
     assert np.median(errs) <= 1e-3 and np.percentile(errs, 95) <= 3e-2 and errs.max() <= 0.2
+
+
+def test_incremental_head_recipe_skips_the_trunk_backward():
+    """main_self_distillation.py:354-357,432-435,497-499: only `classifier_1` trains, every BatchNorm2d on running
+    statistics, loss on the last head.  With requires_grad = False on trunk and base head the backward plan stops at
+    the new head's inputs; the new head's gradients are the same as in the full backward."""
+    import utils
+    img = H.synth_tensor(41, "inc.img", (2, 3, 64, 80)).cuda()
+    lab = H.synth_labels(41, "inc.lab", (2, 64, 80), 17, 255, ignore_frac=0.05).cuda()
+    grads = {}
+    for frozen in (False, True):
+        m = _multihead()
+        _freeze_bn("all")(m)
+        if frozen:
+            for p in list(m.backbone.parameters()) + list(m.classifier.parameters()):
+                p.requires_grad_(False)
+        lg, _, ft = m(img)
+        utils.CrossEntropyLoss(ignore_index=255)(lg[-1], lab, ft[-1]).backward()
+        grads[frozen] = {k: p.grad.detach().clone() for k, p in m.classifier_1.named_parameters()}
+        st = m._engine.store
+        if frozen:
+            assert float(st.flat_g[:st.split].abs().max()) == 0.0            # nothing was written for the trunk
+            assert m._engine.plans and all(pl.skip_ranges for pl in m._engine.plans.values() if pl.training)
+        else:
+            assert float(st.flat_g[:st.split].abs().max()) > 0.0
+    for k in grads[True]:      # same kernels on the same inputs; split-K partial sums may be folded in another order
+        relclose(grads[True][k], grads[False][k], 1e-5, k)
