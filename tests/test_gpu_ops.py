@@ -546,9 +546,10 @@ def test_maxpool(lib, dname):
 
 
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
-def test_avgpool_broadcast_reduce(lib, dname):
+@pytest.mark.parametrize("geom", [(3, 35, 64, 96), (2, 301, 256, 1280), (2, 2304, 48, 64)])
+def test_avgpool_broadcast_reduce(lib, dname, geom):
     dt, tdt, tol = DT[dname]
-    B, HW, Cc, ld = 3, 35, 64, 96
+    B, HW, Cc, ld = geom
     x = qz(rnd("ap.x", (B, HW, ld)), tdt)
     xd = x.to("cuda", tdt)
     out = torch.empty((B, Cc), device="cuda", dtype=tdt)
