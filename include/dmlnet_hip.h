@@ -147,7 +147,7 @@ int dml_bn_finalize_moments(const double* moments, int ranks, int64_t M_each, in
                             const float* beta, float* running_mean, float* running_var, float momentum,
                             float eps, float* scale, float* shift, float* save_mean, float* save_invstd,
                             void* stream);
-int dml_bn_bwd_sums(const float* partials, int nblocks, int N, double* sums, float* dgamma, float* dbeta,
+int dml_bn_bwd_sums(float* partials, int nblocks, int N, double* sums, float* dgamma, float* dbeta,
                     void* stream);
 int dml_bn_bwd_coef(const double* sums, int64_t M_total, int N, const float* gamma, const float* save_mean,
                     const float* save_invstd, float* coef, void* stream);
@@ -180,8 +180,9 @@ int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const uint8_
  * coef[4][N] with dy = coef0*g + coef1*(y - coef3) + coef2  (coef3 = batch mean).
  * M = 0 selects a layer that normalised with FIXED statistics (BatchNorm2d.eval() inside a training step, the
  * reference's main_self_distillation.py:432-435): save_mean / save_invstd are then the running statistics, the two
- * correction terms are zero (coef1 = coef2 = 0) and dgamma / dbeta are unchanged. */
-int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, const float* gamma,
+ * correction terms are zero (coef1 = coef2 = 0) and dgamma / dbeta are unchanged.
+ * With more than 2048 partial rows they are first folded in place (two coalesced stages): `partials` is clobbered. */
+int dml_bn_bwd_finalize(float* partials, int nblocks, int64_t M, int N, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                         float* coef, void* stream);
 /* backward, pass 2: dy = coef0*g + coef1*(y - coef3) + coef2; optionally dres (+)= g for the identity branch. */

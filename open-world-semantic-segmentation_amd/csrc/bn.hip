@@ -295,10 +295,34 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     }
 }
 
+// many partial rows (the 64-row groups of a fused reduce on the 192 x 192 layers: 9216): chunks of R rows are summed
+// first, each chunk into ITS OWN first row (nobody else touches those columns of that row), and the finalize then
+// walks the chunk heads with row stride R -- the same two coalesced stages as the forward statistics
+__global__ __launch_bounds__(256) void bn_bwd_fold_kernel(float* partials, int G, int N, int R) {
+    __shared__ double sh[2][4][64];
+    const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const int n = blockIdx.x * 64 + c;
+    const int g0 = blockIdx.y * R, g1 = min(G, g0 + R);
+    double s0 = 0.0, s1 = 0.0;
+    if (n < N)
+        #pragma unroll 8
+        for (int g = g0 + rl; g < g1; g += 4) {
+            const float2 p = *reinterpret_cast<const float2*>(partials + ((int64_t)g * N + n) * 2);
+            s0 += (double)p.x; s1 += (double)p.y;
+        }
+    sh[0][rl][c] = s0; sh[1][rl][c] = s1;
+    __syncthreads();
+    if (rl == 0 && n < N) {
+        const double a = sh[0][0][c] + sh[0][1][c] + sh[0][2][c] + sh[0][3][c];
+        const double b = sh[1][0][c] + sh[1][1][c] + sh[1][2][c] + sh[1][3][c];
+        *reinterpret_cast<float2*>(partials + ((int64_t)g0 * N + n) * 2) = make_float2((float)a, (float)b);
+    }
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partials, int nblocks, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma, float* dbeta,
-    float* coef, double* sums_out) {
+    float* coef, double* sums_out, int row_stride) {
     __shared__ double sh[2][FIN_SL][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
@@ -306,7 +330,7 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     if (n < N)
         #pragma unroll 8
         for (int g = sl; g < nblocks; g += FIN_SL) {
-            const float2 p = *reinterpret_cast<const float2*>(partials + ((int64_t)g * N + n) * 2);
+            const float2 p = *reinterpret_cast<const float2*>(partials + ((int64_t)g * row_stride * N + n) * 2);
             s0 += p.x; s1 += p.y;
         }
     sh[0][sl][ch] = s0; sh[1][sl][ch] = s1;
@@ -594,13 +618,24 @@ extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
     return 0;
 }
 
-extern "C" int dml_bn_bwd_finalize(const float* partials, int nblocks, int64_t M, int N, const float* gamma,
+// folds `nblocks` partial rows down to <= 128 chunk heads when there are many; returns the row stride of the heads
+static int fold_bwd_partials(float* partials, int& nblocks, int N, hipStream_t st) {
+    if (nblocks <= 2048) return 1;
+    const int R = (nblocks + 127) / 128;
+    const int NC = (nblocks + R - 1) / R;
+    hipLaunchKernelGGL(bn_bwd_fold_kernel, dim3((N + 63) / 64, NC), dim3(256), 0, st, partials, nblocks, N, R);
+    nblocks = NC;
+    return R;
+}
+
+extern "C" int dml_bn_bwd_finalize(float* partials, int nblocks, int64_t M, int N, const float* gamma,
                                    const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                                    float* coef, void* stream) {
     if (!partials || !save_mean || !save_invstd || !coef || nblocks <= 0 || N <= 0 || M < 0) return DML_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), partials, nblocks, M, N, gamma, save_mean, save_invstd,
-                       dgamma, dbeta, coef, (double*)nullptr);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int stride = fold_bwd_partials(partials, nblocks, N, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partials, nblocks, M, N,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, coef, (double*)nullptr, stride);
     DML_LAUNCH_CHECK();
     return 0;
 }
@@ -667,12 +702,14 @@ extern "C" int dml_bn_finalize_moments(const double* moments, int ranks, int64_t
     return 0;
 }
 
-extern "C" int dml_bn_bwd_sums(const float* partials, int nblocks, int N, double* sums, float* dgamma, float* dbeta,
+extern "C" int dml_bn_bwd_sums(float* partials, int nblocks, int N, double* sums, float* dgamma, float* dbeta,
                                void* stream) {
     if (!partials || !sums || nblocks <= 0 || N <= 0) return DML_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0,
-                       static_cast<hipStream_t>(stream), partials, nblocks, (int64_t)1, N, (const float*)nullptr,
-                       (const float*)nullptr, (const float*)nullptr, dgamma, dbeta, (float*)nullptr, sums);
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int stride = fold_bwd_partials(partials, nblocks, N, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partials, nblocks,
+                       (int64_t)1, N, (const float*)nullptr, (const float*)nullptr, (const float*)nullptr, dgamma, dbeta,
+                       (float*)nullptr, sums, stride);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -436,6 +436,29 @@ def test_bn_finalize_many_groups(lib, Cc):
     close(rv, 0.9 + 0.1 * y64.var(0, unbiased=True), "running_var")
 
 
+@pytest.mark.parametrize("Cc,G", [(72, 9216), (256, 2049), (64, 2048)])
+def test_bn_bwd_finalize_many_partial_rows(lib, Cc, G):
+    """More than 2048 partial rows (a data gradient's fused sums on a 192 x 192 layer: one row per 64 pixels) are
+    folded in two stages before the finalize; same coefficients and parameter gradients as fp64 sums."""
+    g = torch.Generator().manual_seed(9)
+    part = torch.randn(G, Cc, 2, generator=g)
+    M = 64 * G - 5
+    gam = torch.rand(Cc, generator=g) + 0.5
+    mu, inv = torch.randn(Cc, generator=g), torch.rand(Cc, generator=g) + 0.5
+    pd, dg, db, coef = part.cuda().contiguous(), torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda"), \
+        torch.empty(4 * Cc, device="cuda")
+    gam_d, mu_d, inv_d = gam.cuda(), mu.cuda(), inv.cuda()
+    chk(lib.dml_bn_bwd_finalize(pd.data_ptr(), G, M, Cc, gam_d.data_ptr(), mu_d.data_ptr(), inv_d.data_ptr(),
+                                dg.data_ptr(), db.data_ptr(), coef.data_ptr(), st()))
+    torch.cuda.synchronize()
+    s = part.double().sum(0)
+    A = gam.double() * inv.double()
+    ref = torch.stack([A, -A * inv.double() * s[:, 1] / M, -A * s[:, 0] / M, mu.double()])
+    relclose(coef.view(4, Cc).cpu(), ref, 2e-6, "coef")
+    relclose(db.cpu(), s[:, 0], 2e-6, "dbeta")
+    relclose(dg.cpu(), s[:, 1], 2e-6, "dgamma")
+
+
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
 @pytest.mark.parametrize("relu,res,drop", [(1, False, 0.0), (1, True, 0.0), (0, False, 0.0), (1, False, 0.25)])
 def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
