@@ -8,6 +8,8 @@ training path for it is dead.
 """
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -109,28 +111,99 @@ class PPMPlan(Plan):
 class PPMEngine(Engine):
     plan_cls = PPMPlan
 
-    def infer(self, x: torch.Tensor, seg_size, dtype: torch.dtype, scores=None, feats=None, alpha: float = 1.0):
-        """One forward at x's resolution; scores / feats [B, 13, *seg_size] (+)= alpha * upsampled result."""
+    def _prepare(self, x, seg_size, dtype, scores, feats, alpha, accumulate):
         if not x.is_cuda:
             raise RuntimeError("the MI355X path needs a ROCm device tensor (got %s); there is no CPU fallback" % x.device)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected input [B,3,H,W], got %s" % (tuple(x.shape),))
         x = x.contiguous().float()
         plan = self.plan_for(x, dtype, False)
-        stream = torch.cuda.current_stream(x.device).cuda_stream
-        plan.refresh_weights(stream)
+        plan.refresh_weights(torch.cuda.current_stream(x.device).cuda_stream)
         B = x.shape[0]
         Hs, Ws = int(seg_size[0]), int(seg_size[1])
-        accumulate = scores is not None
-        if scores is None:
-            scores = torch.empty((B, plan.K, Hs, Ws), dtype=torch.float32, device=x.device)
-            feats = torch.empty((B, plan.K, Hs, Ws), dtype=torch.float32, device=x.device)
         for t in (scores, feats):
             if tuple(t.shape) != (B, plan.K, Hs, Ws) or t.dtype != torch.float32 or not t.is_contiguous() or t.device != x.device:
                 raise ValueError("accumulators must be contiguous float32 [B, %d, %d, %d] on the input's device" % (plan.K, Hs, Ws))
         plan.images_args[0] = x.data_ptr()
         for args, dst in ((plan.up_scores, scores), (plan.up_feats, feats)):
             args[1], args[7], args[8], args[9], args[10] = dst.data_ptr(), Hs, Ws, float(alpha), 1 if accumulate else 0
-        Plan.run(plan.fwd, stream)
         plan.last_input = x
+        return plan
+
+    def infer(self, x: torch.Tensor, seg_size, dtype: torch.dtype, scores=None, feats=None, alpha: float = 1.0):
+        """One forward at x's resolution; scores / feats [B, 13, *seg_size] (+)= alpha * upsampled result."""
+        accumulate = scores is not None
+        if scores is None:
+            shape = (x.shape[0], 13, int(seg_size[0]), int(seg_size[1]))
+            scores = torch.empty(shape, dtype=torch.float32, device=x.device)
+            feats = torch.empty(shape, dtype=torch.float32, device=x.device)
+        plan = self._prepare(x, seg_size, dtype, scores, feats, alpha, accumulate)
+        Plan.run(plan.fwd, torch.cuda.current_stream(x.device).cuda_stream)
+        return scores, feats
+
+    use_graphs = os.environ.get("DML_PPM_GRAPH", "1") == "1"
+
+    def _replay_body(self, plan, s):
+        """The body of a scale (everything but the two upsample-accumulate launches) as one hipGraph: ~190 launches of a
+        few microseconds each are host-bound when five scales run side by side.  The input is copied into a buffer the
+        graph owns; weights are prepared outside (refresh_weights), so a replay is valid until they change."""
+        x = plan.last_input
+        key = plan.prepped_version
+        if getattr(plan, "_graph", None) is None or plan._graph_key != key:
+            plan._static_in = torch.empty_like(x)
+            plan.images_args[0] = plan._static_in.data_ptr()
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.stream(s):
+                plan._static_in.copy_(x)
+                Plan.run(plan.fwd, s.cuda_stream, 0, len(plan.fwd) - 2)        # warm-up outside the capture
+                s.synchronize()
+                with torch.cuda.graph(g, stream=s):
+                    Plan.run(plan.fwd, s.cuda_stream, 0, len(plan.fwd) - 2)
+            plan._graph, plan._graph_key = g, key
+        with torch.cuda.stream(s):
+            plan._static_in.copy_(x)
+            plan._graph.replay()
+
+    def infer_multiscale(self, imgs, seg_size, dtype: torch.dtype):
+        """eval_ood_traditional.py:190-210 for the resized copies of one frame: scores = sum_i pred_i / n (same for the
+        features).  The copies are small (grids of 40-200 workgroups), so their plans run CONCURRENTLY, one HIP stream
+        each; only the two upsample-accumulate launches of every scale are ordered, on the caller's stream."""
+        n = len(imgs)
+        dev = imgs[0].device
+        main = torch.cuda.current_stream(dev)
+        shape = (imgs[0].shape[0], 13, int(seg_size[0]), int(seg_size[1]))
+        scores = torch.empty(shape, dtype=torch.float32, device=dev)
+        feats = torch.empty(shape, dtype=torch.float32, device=dev)
+        if not hasattr(self, "_scale_streams"):
+            self._scale_streams = {}
+        pool = self._scale_streams.setdefault(dev, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=dev))
+        first, todo = True, list(range(n))
+        while todo:
+            wave, later, seen = [], [], set()
+            for i in todo:                      # one use of a plan (= input shape) per wave: its buffers are not re-entrant
+                if tuple(imgs[i].shape) in seen:
+                    later.append(i)
+                    continue
+                seen.add(tuple(imgs[i].shape))
+                plan = self._prepare(imgs[i], seg_size, dtype, scores, feats, 1.0 / n, True)
+                # snapshot the per-call arguments of the tail (a later wave re-patches the same lists)
+                tail = [(fn, list(args)) for fn, args in plan.fwd[-2:]]
+                wave.append((plan, tail, pool[len(wave)]))
+            for plan, tail, s in wave:
+                s.wait_stream(main)
+                if self.use_graphs:
+                    self._replay_body(plan, s)
+                else:
+                    Plan.run(plan.fwd, s.cuda_stream, 0, len(plan.fwd) - 2)
+            for plan, tail, s in wave:
+                main.wait_stream(s)
+                for fn, args in tail:
+                    args[10] = 0 if first else 1
+                    rc = fn(*args, main.cuda_stream)
+                    if rc:
+                        _lib.check(rc, "upsample-accumulate")
+                first = False
+            todo = later
         return scores, feats

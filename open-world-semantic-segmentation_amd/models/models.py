@@ -184,12 +184,10 @@ class SegmentationModuleOOD(nn.Module):
 
 def evaluate_multiscale(segmentation_module, img_resized_list, segSize):
     """The multi-scale mean of eval_ood_traditional.py:190-210: scores = sum_i pred_i / n, ft1 = sum_i ft_i / n over the
-    resized copies of one image; each scale's upsample writes its share straight into the two accumulators."""
-    n = len(img_resized_list)
-    scores = ft = None
-    for img in img_resized_list:
-        if scores is None:
-            scores, ft = segmentation_module._accumulate(img, segSize, None, None, 1.0 / n)
-        else:
-            segmentation_module._accumulate(img, segSize, scores, ft, 1.0 / n)
-    return scores, ft
+    resized copies of one image; each scale's upsample writes its share straight into the two accumulators, and the
+    scales' forward passes overlap on separate streams."""
+    m = segmentation_module
+    if m.training or not m.decoder.use_softmax:
+        raise NotImplementedError("only the inference branch (eval(), decoder built with use_softmax=True) runs on the MI355X path")
+    with torch.no_grad():
+        return m._engine.infer_multiscale(list(img_resized_list), segSize, m._dtype)

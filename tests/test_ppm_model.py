@@ -96,6 +96,12 @@ def test_hip_plan_matches_reference_fixture():
     ms, mf = models.evaluate_multiscale(m, [t.cuda() for t in imgs[:2]], seg)
     relclose(ms, g["ms_scores"], TOL, "multi-scale scores")
     relclose(mf, g["ms_ft"], TOL, "multi-scale features")
+    # the same shape twice in one list (plans are not re-entrant: second use goes to a later wave), twice in a row
+    for _ in range(2):
+        ms3, mf3 = models.evaluate_multiscale(m, [imgs[0].cuda(), imgs[1].cuda(), imgs[0].cuda()], seg)
+        want = (2 * g["pred0"] + g["pred1"]) / 3
+        relclose(ms3, want, TOL, "three copies, one shape repeated")
+        relclose(mf3, (2 * g["ft0"] + g["ft1"]) / 3, TOL, "three copies, features")
     # bf16 plan tracks the fp32 one
     mb = _product(torch.bfloat16)
     pb, fb = mb({"img_data": imgs[1].cuda()}, segSize=seg)
