@@ -95,3 +95,15 @@ def test_incremental_head_driver_synthetic(tmp_path):
     assert torch.equal(out["backbone.layer3.5.conv2.weight"], sd["backbone.layer3.5.conv2.weight"])
     assert torch.equal(out["classifier.classifier.3.weight"], sd["classifier.classifier.3.weight"])
     assert torch.equal(out["backbone.bn1.running_mean"], sd["backbone.bn1.running_mean"])
+
+
+@pytest.mark.parametrize("ood", ["dissum", "msp", "maxlogit"])
+def test_open_set_evaluation_driver_synthetic(ood):
+    """eval_ood_traditional.py end to end at a small frame size (five concurrent scales, graphs, device scores / AUROC)."""
+    drv = os.path.join(H.PKG, "eval_ood_traditional.py")
+    r = subprocess.run([sys.executable, drv, "--synthetic", "--ood", ood, "--num_images", "2", "--height", "360", "--width",
+                        "640"], capture_output=True, text=True, cwd=H.PKG, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    assert "mean auroc = " in r.stdout and "Mean IoU:" in r.stdout
+    auroc = float(r.stdout.split("mean auroc = ")[1].split()[0])
+    assert 0.0 <= auroc <= 1.0
