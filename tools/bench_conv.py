@@ -21,6 +21,8 @@ SHAPES = [  # B, H, W, C, N, k, dil
     (16, 48, 48, 256, 256, 3, 1), (16, 48, 48, 1024, 256, 1, 1), (16, 48, 48, 256, 1024, 1, 1),
     (16, 192, 192, 320, 256, 3, 1), (16, 48, 48, 2048, 256, 3, 12), (16, 192, 192, 64, 256, 1, 1),
     (16, 96, 96, 128, 512, 1, 1), (16, 48, 48, 512, 512, 3, 2)]
+if os.environ.get("BENCH_SHAPES"):          # "B,H,W,C,N,k,d;..." overrides the list
+    SHAPES = [tuple(int(v) for v in t.split(",")) for t in os.environ["BENCH_SHAPES"].split(";")]
 which = sys.argv[1] if len(sys.argv) > 1 else "all"
 for (B, H, W, Cc, N, k, dil) in SHAPES:
     pad = dil * (k // 2)
@@ -39,6 +41,7 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
                          stride=1, dil=dil, pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
             line += "fwd%s %.1fus %.0fTF | " % ("+st" if use_stats else "", t * 1e6, fl / t / 1e12)
+
     if which == "abl":
         import ctypes
         lib.dml_debug_conv_ablate.restype = ctypes.c_int
