@@ -6,7 +6,7 @@ Jun-CEN/Open-World-Semantic-Segmentation.  Only ``tests/``,
 this file; the product package (``open-world-semantic-segmentation_amd/``)
 never does and fails loudly when its HIP library is missing.
 
-Parity status: PINNED.  ``tools/mint_golden.py`` imports the real reference
+Parity status: PINNED.  ``tests/tools/mint_golden.py`` imports the real reference
 from ``/root/reference`` (authoring container only), checks this restatement
 against it (same state_dict keys, same outputs/gradients on seeded inputs) and
 writes the golden vectors in ``tests/golden/`` that ``tests/test_oracle.py``
@@ -213,7 +213,7 @@ class DeepLabV3PlusEmbeddingSelfDistillationRef(nn.Module):
     """deeplabv3plus_embedding_self_distillation_resnet101 (modeling.py:150-158; utils.py:120-193): one backbone, a
     16-prototype base head `classifier` and cls_novel = 1 incremental head `classifier_1` with 17; forward returns
     lists (logits, centers, features_out), one entry per head.  Pinned by tests/golden/g12_multihead.npz
-    (tools/mint_golden_multihead.py)."""
+    (tests/tools/mint_golden_multihead.py)."""
 
     def __init__(self, output_stride=8, cls_novel=1, base_classes=16):
         super().__init__()

@@ -1,6 +1,6 @@
 """Shared test helpers: deterministic synthetic weights / inputs (numpy PCG64, platform-stable).
 
-The same generators are used by ``tools/mint_golden.py`` (authoring container, real reference)
+The same generators are used by ``tests/tools/mint_golden.py`` (authoring container, real reference)
 and by the tests (oracle on CPU, HIP path on the GPU box), so a golden vector only needs to
 store seeds and expected outputs, never a 235 MB state_dict.
 """

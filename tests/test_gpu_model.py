@@ -272,7 +272,7 @@ def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_s
                         np.percentile(e_ref, 95), e_ref.max()))
     if strict is None:
         # Wiring check for the other factory configurations.  On this input ONE ReLU of the decoder sits within fp32
-        # rounding of zero (tools/debug_head.py: dz agrees with the fp64 oracle to 7e-5, dy differs at single elements
+        # rounding of zero (tests/tools/debug_head.py: dz agrees with the fp64 oracle to 7e-5, dy differs at single elements
         # by the full dz value), which shifts every upstream gradient by ~2e-3 -- in the K = 16 / OS 16 configuration
         # just the same.  A mis-wired dilation, stride or channel count gives O(1) errors, so: logits / loss at 1e-3
         # (above), every gradient within 5e-2 of the fp64 one in max-norm and the median within 5e-3 -- or within 3x of

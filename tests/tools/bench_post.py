@@ -1,7 +1,7 @@
 """Micro-benchmark (GPU box): the kernels of the step after the path at 1024 x 2048 -- confusion matrix update and
 OOD measures (device radix sort + rank statistics) -- next to their numpy restatements on one host core."""
 import os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "open-world-semantic-segmentation_amd")]
 import numpy as np
 import torch

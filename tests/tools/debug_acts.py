@@ -1,7 +1,7 @@
 """Debug helper (GPU box): per-layer activation error of the HIP forward vs the fp64 oracle, next to the fp32
 oracle's own error."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "open-world-semantic-segmentation_amd")]
 import torch
 import helpers as H

@@ -1,6 +1,6 @@
 """Debug helper (GPU box): gradients of the head's intermediate tensors, HIP vs fp64 oracle vs fp32 oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "open-world-semantic-segmentation_amd")]
 import torch, torch.nn.functional as F
 import helpers as H

@@ -1,7 +1,7 @@
 """Debug helper (GPU box): per-parameter gradient error of the HIP path vs the fp64 oracle, next to the
 fp32 oracle's own error, to tell real bugs from fp32 conditioning."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "open-world-semantic-segmentation_amd")]
 import torch
 import helpers as H

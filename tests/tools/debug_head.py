@@ -1,6 +1,6 @@
 """Where does the decoder's 3x3 conv weight gradient deviate from the fp64 oracle?  Compare x, dz, dy of that unit."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "open-world-semantic-segmentation_amd"), os.path.join(ROOT, "tests")]
 import torch, helpers as H, network, utils
 from oracle import dmlnet_ref as O
