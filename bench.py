@@ -485,6 +485,11 @@ def main():
             # several of the 1x1 layers bandwidth-bound (e.g. the 256->1024 data gradient moves ~250 MB in 90 us)
             out["roofline"]["hbm_frac_of_same_launches"] = traffic * n_launch / conv_sec / 8e12
         out["hbm_kernel"] = bench_distance_kernel(args.batch, args.size, device)
+        dpath = os.path.join(ROOT, "profiles", "r01_traffic_dist_pmc.json")          # tools/run_traffic_dist.sh
+        if os.path.exists(dpath) and args.batch == 16 and args.size == 768:
+            with open(dpath) as fh:
+                out["hbm_kernel"]["traffic"] = json.load(fh)["bytes_per_launch"]
+            out["hbm_kernel"]["traffic_source"] = "profiles/r01_traffic_dist_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
         out["input_pipeline"] = bench_input_pipeline(args.batch, args.size, device)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
