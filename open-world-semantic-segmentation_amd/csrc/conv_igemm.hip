@@ -456,7 +456,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
     uint4 a_reg[A_LD], b_reg[B_LD];
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
+    int c0_staged = 0;          // channel offset of the tile currently held in a_reg (ABL == 4 only)
     auto load_tiles = [&](int kt, int tap_r, int tap_s, int c0) {
+        c0_staged = c0;
         if constexpr (ALIGNED) {
             const uint32_t tapbit = 1u << (tap_r * a.S + tap_s);
             const int soff = tap_delta(tap_r, tap_s) + c0 * ES;
@@ -523,6 +525,27 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
         }
     };
     auto store_tiles = [&](int buf) {
+        if constexpr (ABL == 4 && sizeof(T) == 2) {
+            // feasibility probe for "normalise on load" (DESIGN.md, next round): a per-channel affine + ReLU applied to the
+            // activation tile between its global load and the LDS write, as a consumer conv would apply the producer's
+            // BatchNorm instead of reading a normalised copy.  Padding stays zero (all-zero pieces are left alone).
+            const int cb = (c0_staged + kvec * VEC) % a.C;
+            float sc[8], sh[8];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) { sc[e] = a.bnr_mean[cb + e]; sh[e] = a.bnr_invstd[cb + e]; }      // probe: fields unused in forward mode
+#pragma unroll
+            for (int j = 0; j < A_LD; ++j) {
+                uint32_t u[4] = {a_reg[j].x, a_reg[j].y, a_reg[j].z, a_reg[j].w};
+                const bool pad = (u[0] | u[1] | u[2] | u[3]) == 0u;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const float lo = fmaxf(fmaf(__uint_as_float(u[e] << 16), sc[2 * e], sh[2 * e]), 0.f);
+                    const float hi = fmaxf(fmaf(__uint_as_float(u[e] & 0xffff0000u), sc[2 * e + 1], sh[2 * e + 1]), 0.f);
+                    u[e] = pad ? 0u : pack_bf16x2(lo, hi);
+                }
+                a_reg[j] = make_uint4(u[0], u[1], u[2], u[3]);
+            }
+        }
 #pragma unroll
         for (int j = 0; j < A_LD; ++j) {
             const int row = prow + j * RPP;
@@ -1355,6 +1378,12 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     if (abl == 0) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 0>), grid, dim3(NTHREADS), 0, st, a);
     else if (abl == 1) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 1>), grid, dim3(NTHREADS), 0, st, a);
     else if (abl == 3) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 3>), grid, dim3(NTHREADS), 0, st, a);
+    else if (abl == 4) {
+        a.dbg = nullptr;
+        a.bnr_mean = d->pre_scale; a.bnr_invstd = d->pre_shift;       // per INPUT channel: the probe's scale / shift
+        if (!a.bnr_mean || !a.bnr_invstd) return DML_EINVAL;
+        hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 4>), grid, dim3(NTHREADS), 0, st, a);
+    }
     else hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 2>), grid, dim3(NTHREADS), 0, st, a);
     DML_LAUNCH_CHECK();
     return 0;

@@ -52,6 +52,17 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         for abl, nm in ((0, "full"), (1, "no-global/no-ldswrite"), (2, "no-mfma")):
             t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), abl, st))
             line += "%s %.1fus (%.0fTF-equiv) | " % (nm, t * 1e6, fl / t / 1e12)
+        # normalise-on-load probe: per-input-channel affine + ReLU between the global load and the LDS write
+        psc, psh = torch.rand(Cc, device="cuda") + 0.5, torch.randn(Cc, device="cuda") * 0.1
+        d.pre_scale, d.pre_shift = psc.data_ptr(), psh.data_ptr()
+        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), 4, st))
+        line += "affine+relu on load %.1fus | " % (t * 1e6)
+        # what it would replace: one BN apply pass over the input tensor
+        yb = torch.empty_like(x); mk = torch.empty(x.numel() // 8, dtype=torch.uint8, device="cuda")
+        mean0 = torch.zeros(Cc, device="cuda")
+        t = timeit(lambda: lib.dml_bn_apply(x.data_ptr(), None, yb.data_ptr(), psc.data_ptr(), psh.data_ptr(), mean0.data_ptr(),
+                                            mk.data_ptr(), B * H * W, Cc, Cc, 0, Cc, 1, 1, 0.0, 0, st))
+        line += "bn_apply of the input %.1fus | " % (t * 1e6)
     if which == "phases":
         import ctypes
         lib.dml_debug_conv_ablate.restype = ctypes.c_int
