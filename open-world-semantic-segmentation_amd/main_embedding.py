@@ -150,10 +150,10 @@ def main():
         optimizer.step()
         interval_loss = loss.detach() if interval_loss is None else interval_loss + loss.detach()
         if cur_itrs % opts.print_interval == 0:                                    # one D2H sync per interval
+            mean_loss = float(interval_loss) / opts.print_interval       # the D2H copy waits for the interval's kernels
             dt = time.perf_counter() - t0
             if rank == 0:
-                print("Itrs %d/%d, Loss=%f, %.1f img/s" % (cur_itrs, opts.total_itrs,
-                                                           float(interval_loss) / opts.print_interval,
+                print("Itrs %d/%d, Loss=%f, %.1f img/s" % (cur_itrs, opts.total_itrs, mean_loss,
                                                            opts.batch_size * opts.print_interval / dt))
             interval_loss, t0 = None, time.perf_counter()
         if opts.val_interval and cur_itrs % opts.val_interval == 0 and opts.val_images > 0:
