@@ -230,6 +230,7 @@ class Plan:
         self.world = dist.get_world_size(engine.sync_group) if self.sync else 1
         self.last_dgrad = {}           # gradient buffer address -> ConvDesc of the data gradient that wrote it last
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
+        self.fork_branches = os.environ.get("DML_FORK_BRANCHES", "1") != "0"
         # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
         # of this network; backward: <= ~1100*N*2)
         self.scratch = torch.empty(max(B * H * W // 2 + 16384, 1100 * 2048 * 2 + 65536), dtype=torch.float32,
@@ -608,14 +609,25 @@ class Plan:
         aspp = head.aspp
         cat1 = self.new(B, out.H, out.W, 5 * 256)
         branches = []
+        marks = [len(self.fwd)]
         for i in range(4):
             branches.append(self.cbr(out, aspp.convs[i][0], aspp.convs[i][1], out=cat1.slice(256 * i, 256)))
+            marks.append(len(self.fwd))
         # image-pooling branch (network/utils.py:318-329): avg-pool -> 1x1 -> BN -> ReLU -> broadcast
         pooled = self.new(B, 1, 1, out.C)
         self.call(self.fwd, lib.dml_global_avgpool_fwd, out.ptr, pooled.ptr, B, out.H * out.W, out.C, out.ld, self.dt)
         upool = self.cbr(pooled, aspp.convs[4][1], aspp.convs[4][2])
         self.call(self.fwd, lib.dml_broadcast_hw, upool.z.ptr, cat1.slice(1024, 256).ptr, B, out.H * out.W, 256,
                   cat1.ld, self.dt)
+        marks.append(len(self.fwd))
+        if not self.training and self.fork_branches and (out.M + 127) // 128 * 2 < 300:
+            # inference on small maps (a branch's grid below ~300 workgroups; 1024 x 2048 at batch 1: 270 vs 261
+            # images/s, at batch 4 the grids fill the chip alone and forking costs 1.5 %): the five branches only read
+            # `out` and write disjoint channel slices of cat1 (one launch each, the pooled one three) -- independent, so
+            # they may overlap (training keeps them in line: its units share the statistics scratch)
+            if not hasattr(self, "fwd_forks"):
+                self.fwd_forks = []
+            self.fwd_forks.append([(marks[k], marks[k + 1]) for k in range(5)])
         uproj = self.cbr(cat1, aspp.project[0], aspp.project[1], drop=aspp.project[3])
         up_slice = cat2.slice(48, 256)
         self.call(self.fwd, lib.dml_bilinear_fwd, uproj.z.ptr, up_slice.ptr, B, out.H, out.W, low.H, low.W, 256,
@@ -755,6 +767,27 @@ class Plan:
                 hook(i)
         main.wait_stream(side)
 
+    def run_forward(self, stream):
+        """Replay the forward plan.  Inference plans carry fork groups (`fwd_forks`: the independent ASPP branches): their
+        op ranges run side by side on the engine's branch streams and join on the caller's stream -- at batch 1 each
+        branch is a grid of 128-256 workgroups, too small to fill the chip alone."""
+        forks = getattr(self, "fwd_forks", None)
+        if not forks:
+            Plan.run(self.fwd, stream)
+            return
+        main = torch.cuda.current_stream(self.device)
+        pos = 0
+        for ranges in forks:
+            Plan.run(self.fwd, stream, pos, ranges[0][0])
+            streams = self.e.branch_streams(self.device, len(ranges))
+            for (lo, hi), s in zip(ranges, streams):
+                s.wait_stream(main)
+                Plan.run(self.fwd, s.cuda_stream, lo, hi)
+            for s in streams[:len(ranges)]:
+                main.wait_stream(s)
+            pos = ranges[-1][1]
+        Plan.run(self.fwd, stream, pos, len(self.fwd))
+
     @staticmethod
     def run(ops, stream, start=0, stop=None, hook=None, skipped=()):
         stop = len(ops) if stop is None else stop
@@ -786,6 +819,7 @@ class Engine:
         self.overlap_wgrad = os.environ.get("DML_OVERLAP_WGRAD", "1") != "0"
         self.sync_bn, self.sync_group = False, None     # synchronised BatchNorm statistics over the process group
         self._side = {}
+        self._branch = {}
         self.step_count = 0
         self.seed = 0x5DEECE66D
 
@@ -793,6 +827,12 @@ class Engine:
         if device not in self._side:
             self._side[device] = torch.cuda.Stream(device=device)
         return self._side[device]
+
+    def branch_streams(self, device, n):
+        pool = self._branch.setdefault(device, [])
+        while len(pool) < n:
+            pool.append(torch.cuda.Stream(device=device))
+        return pool[:n]
 
     def prototypes(self, k: int) -> torch.Tensor:
         """centers = 3 * I_K (network/utils.py:103-106); built once per device instead of every forward."""
@@ -882,7 +922,7 @@ class Engine:
                 self.store.flat_nbt.add_(1)
             else:
                 self.store.flat_nbt.add_(plan.nbt_inc)      # layers with fixed statistics do not count the batch
-        Plan.run(plan.fwd, stream)
+        plan.run_forward(stream)
         plan.last_input = x
         for hi, rec in enumerate(plan.heads):
             if rec.Kp != rec.K:              # features_out has exactly num_classes channels (utils.py:95-97)
