@@ -145,3 +145,24 @@ def test_shard_and_buckets():
     assert b[0][0] == 192 and b[0][1] == 1280 and b[-1][0] == 0
     assert sum(hi - lo for lo, hi, _ in b) == 1280
     assert sorted(i for _, _, mem in b for i in mem) == [0, 1, 2, 3]
+
+
+def test_committed_bench_line_carries_the_contract_fields():
+    """profiles/r01_bench_v8.json is the last default `python bench.py` line of the round; the driver's contract fields,
+    the roofline object and the CPU baseline must all be there and be self-consistent."""
+    import json
+    d = json.load(open(os.path.join(H.ROOT, "profiles", "r01_bench_v8.json")))
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert k in d, k
+    assert d["unit"] == "images/sec" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
+    assert d["config"]["workload"] and "model" not in d["config"]
+    assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    r = d["roofline"]
+    assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
+    assert r["traffic"] and r["traffic"] > 0
+    assert abs(r["achieved"] * 1e12 - r["flops_per_step"] / (r["conv_ms_per_step"] * 1e-3)) < 1e-6 * r["achieved"] * 1e12
+    c = d["cpu_baseline"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"]
+    h = d["hbm_kernel"]
+    assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9 and h["traffic"] > 0.99 * 192 * 16 * 768 * 768
