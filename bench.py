@@ -30,6 +30,80 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK = {"bf16": 2.5e15, "f32": 157.3e12}      # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
+ROUND = "r02"
+
+
+def csrc_sha():
+    """Fingerprint of the kernel sources: a committed PMC traffic file is only quoted when it was collected on exactly
+    these kernels (tools/run_traffic.sh stores the same value inside the file)."""
+    import hashlib
+    h = hashlib.sha256()
+    d = os.path.join(PKG, "csrc")
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h")):
+            with open(os.path.join(d, name), "rb") as fh:
+                h.update(name.encode() + b"\0" + fh.read())
+    return h.hexdigest()[:16]
+
+
+def physical_cores():
+    """(physical cores, logical CPUs) of this host from /proc/cpuinfo"""
+    logical = os.cpu_count() or 1
+    try:
+        pairs, phys, core = set(), None, None
+        with open("/proc/cpuinfo") as fh:
+            for ln in fh:
+                if ln.startswith("physical id"):
+                    phys = ln.split(":")[1].strip()
+                elif ln.startswith("core id"):
+                    core = ln.split(":")[1].strip()
+                elif not ln.strip():
+                    if phys is not None and core is not None:
+                        pairs.add((phys, core))
+                    phys = core = None
+        if pairs:
+            return min(len(pairs), logical), logical
+    except OSError:
+        pass
+    return logical, logical
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` without a launcher: start N rank processes of this script (one per GPU, RCCL between
+    them) BEFORE anything here touches a GPU, relay their output, exit non-zero if any of them fails."""
+    import socket
+    import subprocess
+    shared = os.environ.get("DML_BENCH_ALLOW_SHARED_GPU") == "1"        # test hook: gloo ranks on one device
+    have = torch.cuda.device_count()                                      # does not initialise the GPU
+    if have < n and not shared:
+        sys.stderr.write("bench.py: --gpus %d but this node exposes %d GPU(s); refusing to oversubscribe\n" % (n, have))
+        sys.exit(2)
+    sock = socket.socket()
+    sock.bind(("127.0.0.1", 0))
+    port = sock.getsockname()[1]
+    sock.close()
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    try:
+        while procs:
+            for pr in list(procs):
+                code = pr.poll()
+                if code is None:
+                    continue
+                procs.remove(pr)
+                if code != 0 and rc == 0:
+                    rc = code
+                    for other in procs:              # one rank died: the others would wait in a collective forever
+                        other.terminate()
+            time.sleep(0.05)
+    finally:
+        for pr in procs:
+            pr.kill()
+    sys.exit(rc)
 
 
 def synth_batch(batch, size, rank, device):
@@ -40,10 +114,27 @@ def synth_batch(batch, size, rank, device):
     return img.to(device), lab.to(device)
 
 
+def conv_bytes_of_plan(plan):
+    """Algorithmic HBM bytes of the conv launches of one train step: every operand read once, every result written
+    once (accumulating data gradients read their target too), storage types of the plan; weight gradients fp32."""
+    lib = plan.lib
+    es = plan.es
+    total = 0.0
+    for ops in (plan.fwd, plan.bwd):
+        for fn, args in ops:
+            if fn is lib.dml_conv_igemm:
+                d = args[0]._obj
+                rd = d.B * d.Hi * d.Wi * d.C * es + d.N * d.R * d.S * d.C * es
+                wr = d.B * d.Ho * d.Wo * d.N * (4 if d.y_f32 else es)
+                total += rd + wr * (2 if d.accum else 1)
+            elif fn is lib.dml_conv_wgrad:
+                d = args[0]._obj
+                total += d.B * d.Hi * d.Wi * d.C * es + d.B * d.Ho * d.Wo * d.N * es + 2 * 4 * d.N * d.R * d.S * d.C
+    return total
+
+
 def conv_flops_of_plan(plan):
     """Algorithmic FLOPs (2*MAC on the un-padded channel counts) of every conv launch of one train step."""
-    from dmlnet._lib import ConvDesc, WgradDesc
-    import ctypes as C
     lib = plan.lib
     total = 0.0
     per_op = {}
@@ -129,8 +220,24 @@ def dump_conv_table(plan, path):
         json.dump(rows, f)
 
 
+def _time_launches(fn, n=20, warm=3):
+    """mean duration of `fn` (one kernel launch on torch's current stream) from a HIP event pair on that stream"""
+    for _ in range(warm):
+        fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(n):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) * 1e-3 / n
+
+
 def bench_distance_kernel(batch, size, device):
-    """Standalone pixel->prototype distance kernel (192 B/px algorithmic: 64 read + 64 logits + 64 features)."""
+    """The pixel->prototype distance kernels.  `proto_dist_fwd` is the standalone head BASELINE.json names (192 B/px
+    algorithmic: 64 read + 64 logits + 64 features); `step_path` lists the kernels the train / inference plans actually
+    launch for network/utils.py:88-118 of the reference -- the upsample-fused forward (132 B/px: 4 read at 1/16 of the
+    pixels + 128 written) and the backward chain -- timed alone at the step's shapes."""
     from dmlnet import _lib
     lib = _lib.load()
     x = torch.randn(batch, 16, size, size, device=device)
@@ -139,19 +246,54 @@ def bench_distance_kernel(batch, size, device):
     ft = torch.empty(batch, size, size, 16, device=device)
     st = torch.cuda.current_stream().cuda_stream
     args = (x.data_ptr(), protos.data_ptr(), lg.data_ptr(), ft.data_ptr(), None, None, batch, 16, 16, size, size, st)
-    for _ in range(3):
-        lib.dml_proto_dist_fwd(*args)
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    n = 20
-    e0.record()
-    for _ in range(n):
-        lib.dml_proto_dist_fwd(*args)
-    e1.record()
-    torch.cuda.synchronize()
-    sec = e0.elapsed_time(e1) * 1e-3 / n
-    bytes_ = 192.0 * batch * size * size
-    return {"kernel": "proto_dist_fwd", "bound": "hbm", "achieved": bytes_ / sec / 1e9, "peak": HBM_PEAK / 1e9,
-            "unit": "GB/s", "frac": bytes_ / sec / HBM_PEAK, "bytes_per_px": 192, "ms": sec * 1e3}
+    sec = _time_launches(lambda: lib.dml_proto_dist_fwd(*args))
+    px = float(batch) * size * size
+    out = {"kernel": "proto_dist_fwd", "bound": "hbm", "achieved": 192.0 * px / sec / 1e9, "peak": HBM_PEAK / 1e9,
+           "unit": "GB/s", "frac": 192.0 * px / sec / HBM_PEAK, "bytes_per_px": 192, "ms": sec * 1e3}
+    low = size // 4
+    emb = torch.randn(batch, low, low, 16, device=device)
+    sec_u = _time_launches(lambda: lib.dml_upsample_dist_fwd(emb.data_ptr(), protos.data_ptr(), lg.data_ptr(), ft.data_ptr(),
+                                                             None, None, batch, low, low, 16, 16, size, size, st))
+    step = [{"kernel": "upsample_dist_fwd (fused x4 bilinear + distances, the forward the plans run)", "bytes_per_px": 132,
+             "ms": sec_u * 1e3, "achieved": 132.0 * px / sec_u / 1e9, "frac": 132.0 * px / sec_u / HBM_PEAK}]
+    lab = torch.randint(0, 16, (batch, size, size), device=device)
+    for entry in head_backward_entries(lib, batch, size, low, lg, ft, lab, protos, st):
+        step.append(entry)
+    out["step_path"] = step
+    return out
+
+
+def head_backward_entries(lib, batch, size, low, lg, ft, lab, protos, st):
+    """the backward of the loss + distance head + final upsample as the training plan runs it"""
+    from dmlnet import _lib
+    px = float(batch) * size * size
+    dev = lg.device
+    sums = torch.zeros(5, dtype=torch.float64, device=dev)
+    part = torch.empty(_lib.LOSS_BLOCKS * 4, dtype=torch.float32, device=dev)
+    lib.dml_loss_fwd(lg.data_ptr(), lab.data_ptr(), sums.data_ptr(), part.data_ptr(), batch, 16, size, size, 255, st)
+    gout = torch.ones((), device=dev)
+    de = torch.empty(batch, low, low, 16, dtype=torch.bfloat16, device=dev)
+    if hasattr(lib, "dml_head_bwd_fused"):
+        sec = _time_launches(lambda: lib.dml_head_bwd_fused(ft.data_ptr(), lab.data_ptr(), sums.data_ptr(), gout.data_ptr(),
+                                                            protos.data_ptr(), de.data_ptr(), batch, low, low, 16, 16, size,
+                                                            size, 255, 0.01, float(batch), 1, st))
+        # reads features 64 + labels 8 per pixel, writes the low-resolution embedding gradient (2 B x 16 ch / 16 px)
+        return [{"kernel": "head_bwd_fused (loss grad + distance grad + bilinear grad in one pass)", "bytes_per_px": 74,
+                 "ms": sec * 1e3, "achieved": 74.0 * px / sec / 1e9, "frac": 74.0 * px / sec / HBM_PEAK}]
+    gl = torch.empty_like(lg)
+    df = torch.empty_like(ft)
+    s1 = _time_launches(lambda: lib.dml_loss_bwd(lg.data_ptr(), lab.data_ptr(), sums.data_ptr(), gout.data_ptr(), gl.data_ptr(),
+                                                 batch, 16, size, size, 255, 0.01, float(batch), st))
+    s2 = _time_launches(lambda: lib.dml_proto_dist_bwd(gl.data_ptr(), None, ft.data_ptr(), protos.data_ptr(), df.data_ptr(),
+                                                       batch, 16, 16, size, size, st))
+    s3 = _time_launches(lambda: lib.dml_bilinear_bwd(df.data_ptr(), de.data_ptr(), batch, low, low, size, size, 16, 16, 16, 1,
+                                                     1, 0, st))
+    return [{"kernel": "loss_bwd", "bytes_per_px": 136, "ms": s1 * 1e3, "achieved": 136.0 * px / s1 / 1e9,
+             "frac": 136.0 * px / s1 / HBM_PEAK},
+            {"kernel": "proto_dist_bwd", "bytes_per_px": 192, "ms": s2 * 1e3, "achieved": 192.0 * px / s2 / 1e9,
+             "frac": 192.0 * px / s2 / HBM_PEAK},
+            {"kernel": "bilinear_bwd (fp32 -> low-resolution bf16)", "bytes_per_px": 66, "ms": s3 * 1e3,
+             "achieved": 66.0 * px / s3 / 1e9, "frac": 66.0 * px / s3 / HBM_PEAK}]
 
 
 def bench_input_pipeline(batch, size, device):
@@ -229,10 +371,13 @@ def cpu_input_pipeline(size):
 
 
 def cpu_baseline(size, threads):
-    """The CPU oracle (port of the reference's PyTorch path) on the host cores: 768x768 bs=2 train step."""
-    import helpers as H
+    """The CPU oracle (port of the reference's PyTorch path) on the host cores: 768x768 bs=2 train step on `threads`
+    threads (default: every physical core of the box) and, for comparability with the 8-vCPU authoring container
+    (SURVEY 8(d)), one more step on 8 threads."""
+    import helpers as H  # noqa: F401
     from oracle import dmlnet_ref as O
-    torch.set_num_threads(threads)
+    phys, logical = physical_cores()
+    threads = threads or phys
     bs = 2
     o = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
     o.train()
@@ -242,15 +387,26 @@ def cpu_baseline(size, threads):
     img = torch.randn(bs, 3, size, size, generator=g)
     lab = torch.randint(0, 16, (bs, size, size), generator=g)
     lab[:, :38] = 255
-    times = []
-    for it in range(3):
+
+    def one(it):
         t0 = time.perf_counter()
         O.train_step(o, opt, img, lab, it, 100, [0.001, 0.01], lambda a, b: O.dml_loss(a, b, 0.01, 255))
-        times.append(time.perf_counter() - t0)
+        return time.perf_counter() - t0
+
+    torch.set_num_threads(threads)
+    times = [one(it) for it in range(3)]
     sec = min(times[1:])
-    return {"value": bs / sec, "unit": "images/sec", "cores": threads, "kind": "port",
-            "sample": "oracle (PyTorch CPU fp32 restatement of the reference) train step, %dx%d bs=%d, "
-                      "best of 2 after 1 warm-up, %.2f s/step" % (size, size, bs, sec)}
+    out = {"value": bs / sec, "unit": "images/sec", "cores": threads, "kind": "port",
+           "host": "%d physical cores / %d logical CPUs" % (phys, logical),
+           "sample": "oracle (PyTorch CPU fp32 restatement of the reference) train step, %dx%d bs=%d, "
+                     "best of 2 after 1 warm-up, %.2f s/step" % (size, size, bs, sec)}
+    if threads != 8 and logical >= 8:
+        torch.set_num_threads(8)
+        sec8 = one(3)
+        out["value_8_threads"] = bs / sec8
+        out["sample"] += "; 8 threads: 1 step, %.2f s" % sec8
+        torch.set_num_threads(threads)
+    return out
 
 
 def infer_bench(args):
@@ -366,7 +522,8 @@ def main():
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-profile", action="store_true")
-    ap.add_argument("--cpu-threads", type=int, default=0)
+    ap.add_argument("--no-fp32-companion", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every physical core of the host")
     ap.add_argument("--dump-conv", default=None, help="write a per-launch conv table (json) from the profiled pass")
     ap.add_argument("--mode", default="train", choices=["train", "infer", "ood"],
                     help="train = the headline metric (default); infer = SURVEY 8(d) config #5: open-world inference "
@@ -374,6 +531,8 @@ def main():
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     args = ap.parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mode != "ood":
+        launch_ranks(args.gpus)                  # never returns
     if args.mode == "ood":
         return ood_bench(args)
     if args.mode == "infer":
@@ -385,7 +544,61 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
+    backend = dist.get_backend() if world > 1 else None
 
+    res = train_pass(args, args.dtype, device, rank, world, steps=args.steps, warmup=args.warmup,
+                     profile=(world == 1 and not args.no_profile), dump_conv=args.dump_conv)
+    out = None
+    if rank == 0:
+        out = {"metric": "images/sec train-step, DeepLabV3+R101 768x768 bs=16; % HBM & MFMA roofline",
+               "value": res["value"], "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": res["ms_per_step"], "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": args.dtype, "data": "synthetic",
+               "config": {"workload": "DMLNet train step: DeepLabV3+/ResNet-101 OS16 fwd+bwd, prototype-distance "
+                                      "head, DML loss (DCE+VL), SGD; %dx%d crops, %d images/GPU, 16 prototypes, "
+                                      "random-init weights" % (args.size, args.size, args.batch),
+                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
+                          "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
+                          "final_loss": res["final_loss"]},
+               "host_enqueue_ms_per_step": res["host_ms"]}
+        if "roofline" in res:
+            out["roofline"] = res["roofline"]
+    if world == 1 and not args.no_profile:
+        out["hbm_kernel"] = bench_distance_kernel(args.batch, args.size, device)
+        dpath = os.path.join(ROOT, "profiles", ROUND + "_traffic_dist_pmc.json")          # tools/run_traffic_dist.sh
+        if os.path.exists(dpath) and args.batch == 16 and args.size == 768:
+            with open(dpath) as fh:
+                dj = json.load(fh)
+            if dj.get("csrc_sha") == csrc_sha():
+                out["hbm_kernel"]["traffic"] = dj["bytes_per_launch"]
+                out["hbm_kernel"]["traffic_source"] = "profiles/%s_traffic_dist_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, csrc %s)" % (ROUND, dj["csrc_sha"])
+        if "traffic" not in out["hbm_kernel"]:
+            out["hbm_kernel"]["traffic"] = None
+        out["input_pipeline"] = bench_input_pipeline(args.batch, args.size, device)
+        if args.dtype == "bf16" and not args.no_fp32_companion:
+            # the reference's arithmetic is fp32 (network/utils.py:84-118): the same step in the exact-fp32 mode
+            # (v_mfma_f32_16x16x4_f32, the mode the 1e-3 parity tests run), driver-timed next to the bf16 headline
+            torch.cuda.empty_cache()
+            f = train_pass(args, "f32", device, rank, world, steps=max(3, args.steps // 4), warmup=2, profile=True)
+            out["fp32_companion"] = {"dtype": "f32", "value": f["value"], "unit": "images/sec", "ms_per_step": f["ms_per_step"],
+                                     "steps": max(3, args.steps // 4), "warmup": 2, "final_loss": f["final_loss"],
+                                     "roofline": {k: f["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac",
+                                                                               "conv_ms_per_step", "flops_per_step")}}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
+        if "input_pipeline" in out:
+            out["input_pipeline"]["cpu_baseline"] = cpu_input_pipeline(args.size)
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_conv=None):
+    """W warm-up + exactly K timed train steps in `dtype` (barrier + synchronize on both sides, max over ranks), then --
+    single GPU only -- the profiled conv pass.  The model and its plans are released on return."""
+    from dmlnet import parallel
     import network
     import utils
     from dmlnet.optim import FusedSGD
@@ -393,7 +606,7 @@ def main():
     torch.manual_seed(1)
     model = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
     model.to(device)
-    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.set_compute_dtype(torch.bfloat16 if dtype == "bf16" else torch.float32)
     model.train()
     utils.set_bn_momentum(model.backbone, momentum=0.01)                     # main_embedding.py:379
     lr = 0.01
@@ -416,15 +629,18 @@ def main():
         sched.step()
         return loss
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         loss = step()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    host = 0.0
+    for _ in range(steps):
+        h0 = time.perf_counter()
         loss = step()
+        host += time.perf_counter() - h0
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -434,73 +650,50 @@ def main():
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-    final_loss = float(loss.item())
-
-    out = None
-    if rank == 0:
-        ms = elapsed / args.steps * 1e3
-        value = args.batch * world * args.steps / elapsed
-        out = {"metric": "images/sec train-step, DeepLabV3+R101 768x768 bs=16; % HBM & MFMA roofline",
-               "value": value, "unit": "images/sec", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": ms, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": args.dtype, "data": "synthetic",
-               "config": {"workload": "DMLNet train step: DeepLabV3+/ResNet-101 OS16 fwd+bwd, prototype-distance "
-                                      "head, DML loss (DCE+VL), SGD; %dx%d crops, %d images/GPU, 16 prototypes, "
-                                      "random-init weights" % (args.size, args.size, args.batch),
-                          "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                          "final_loss": final_loss}}
-    if world == 1 and not args.no_profile:
+    res = {"value": args.batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
+           "final_loss": float(loss.item()), "host_ms": host / steps * 1e3}
+    if profile:
         plan = next(p for k, p in model._engine.plans.items() if k[4])
         flops, _ = conv_flops_of_plan(plan)
+        alg_bytes = conv_bytes_of_plan(plan)
         model._engine.overlap_wgrad = False          # profiled pass: every conv launch alone on one stream
         tsec, counts = profile_convs(model, model._engine, step, 2)
         model._engine.overlap_wgrad = True
-        if args.dump_conv:
-            dump_conv_table(plan, args.dump_conv)
+        if dump_conv:
+            dump_conv_table(plan, dump_conv)
         conv_sec = tsec["igemm"] + tsec["wgrad"]
         n_launch = counts["igemm"] + counts["wgrad"]
-        peak = PEAK[args.dtype]
-        # HBM bytes per conv launch from the committed PMC passes of this same command (tools/run_traffic.sh:
-        # separate --pmc FETCH_SIZE / WRITE_SIZE runs, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024); null when absent
+        peak = PEAK[dtype]
+        # HBM bytes per conv launch from the committed PMC passes of this same command (tools/run_traffic.sh: separate
+        # --pmc FETCH_SIZE / WRITE_SIZE runs, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024).  Quoted only when the file was
+        # collected on exactly these kernel sources (csrc_sha inside the file), else null.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", "r01_traffic_pmc.json")
-        if os.path.exists(tpath) and args.batch == 16 and args.size == 768 and args.dtype == "bf16":
+        tpath = os.path.join(ROOT, "profiles", ROUND + "_traffic_pmc.json")
+        if os.path.exists(tpath) and args.batch == 16 and args.size == 768 and dtype == "bf16":
             with open(tpath) as fh:
                 tj = json.load(fh)
-            traffic = tj["conv_GB_per_step"] * 1e9 / tj["conv_launches_per_step"]
-            traffic_src = "profiles/r01_traffic_pmc.json (rocprofv3 --pmc, %.1f GB per step over the conv launches)" % tj["conv_GB_per_step"]
-        out["roofline"] = {"bound": "mfma", "kernel": "conv_igemm_dma_kernel / conv_igemm_kernel + conv_wgrad_big_kernel / conv_wgrad_kernel (all conv launches of a step)",
-                           "achieved": flops / conv_sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                           "frac": flops / conv_sec / peak, "traffic": traffic, "traffic_unit": "bytes per launch (mean)",
-                           "traffic_source": traffic_src,
-                           "flops_per_step": flops, "launches_per_step": n_launch,
-                           "avg_launch_ms": conv_sec / n_launch * 1e3, "conv_ms_per_step": conv_sec * 1e3,
-                           "igemm_ms_per_step": tsec["igemm"] * 1e3, "wgrad_ms_per_step": tsec["wgrad"] * 1e3,
-                           "whole_step_frac": flops / (elapsed / args.steps) / peak,
-                           "note": "data-gradient launches also compute the BatchNorm-backward sums of the tensor they "
-                                   "write (88 of 112 bn_bwd_reduce launches folded into their epilogues); their time is "
-                                   "charged to the convolutions here"}
+            if tj.get("csrc_sha") == csrc_sha():
+                traffic = tj["conv_GB_per_step"] * 1e9 / tj["conv_launches_per_step"]
+                traffic_src = "profiles/%s_traffic_pmc.json (rocprofv3 --pmc, %.1f GB per step over the conv launches, csrc %s)" \
+                    % (ROUND, tj["conv_GB_per_step"], tj["csrc_sha"])
+        roof = {"bound": "mfma", "kernel": "every convolution launch of a step (conv_igemm*_kernel forward / data gradient, "
+                                           "conv_wgrad*_kernel weight gradient)",
+                "achieved": flops / conv_sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
+                "frac": flops / conv_sec / peak, "traffic": traffic, "traffic_unit": "bytes per launch (mean)",
+                "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes / n_launch,
+                "flops_per_step": flops, "launches_per_step": n_launch,
+                "avg_launch_ms": conv_sec / n_launch * 1e3, "conv_ms_per_step": conv_sec * 1e3,
+                "igemm_ms_per_step": tsec["igemm"] * 1e3, "wgrad_ms_per_step": tsec["wgrad"] * 1e3,
+                "whole_step_frac": flops / (elapsed / steps) / peak, "csrc_sha": csrc_sha(),
+                "note": "data-gradient launches also compute the BatchNorm-backward sums of the tensor they "
+                        "write (bn_bwd_reduce folded into their epilogues); their time is charged to the convolutions here"}
         if traffic is not None:
-            # the same launches against the OTHER roof: residual accumulates, fused BN sums and split-K partials make
-            # several of the 1x1 layers bandwidth-bound (e.g. the 256->1024 data gradient moves ~250 MB in 90 us)
-            out["roofline"]["hbm_frac_of_same_launches"] = traffic * n_launch / conv_sec / 8e12
-        out["hbm_kernel"] = bench_distance_kernel(args.batch, args.size, device)
-        dpath = os.path.join(ROOT, "profiles", "r01_traffic_dist_pmc.json")          # tools/run_traffic_dist.sh
-        if os.path.exists(dpath) and args.batch == 16 and args.size == 768:
-            with open(dpath) as fh:
-                out["hbm_kernel"]["traffic"] = json.load(fh)["bytes_per_launch"]
-            out["hbm_kernel"]["traffic_source"] = "profiles/r01_traffic_dist_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE)"
-        out["input_pipeline"] = bench_input_pipeline(args.batch, args.size, device)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        threads = args.cpu_threads or min(os.cpu_count() or 8, 64)
-        out["cpu_baseline"] = cpu_baseline(args.size, threads)
-        if "input_pipeline" in out:
-            out["input_pipeline"]["cpu_baseline"] = cpu_input_pipeline(args.size)
-    if rank == 0:
-        print(json.dumps(out))
-    if world > 1:
-        dist.barrier()
-        dist.destroy_process_group()
+            roof["traffic_over_algorithmic"] = traffic * n_launch / alg_bytes
+            roof["hbm_frac_of_same_launches"] = traffic * n_launch / conv_sec / 8e12
+        res["roofline"] = roof
+    del model, opt, sched, crit, step
+    torch.cuda.empty_cache()
+    return res
 
 
 if __name__ == "__main__":

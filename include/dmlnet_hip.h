@@ -252,7 +252,9 @@ int dml_novel_relabel(const float* feats, const float* logits, const float* prot
  * ---------------------------------------------------------------------------------------------- */
 int dml_loss_fwd(const float* logits, const int64_t* labels, double* sums, float* block_partials,
                  int B, int K, int H, int W, int64_t ignore_index, void* stream);
-/* loss = (sums[0]/sums[1] + alpha*sums[2]) / n_images  (written to *loss, device float) */
+/* loss = (sums[0]/sums[1] + alpha*sums[2]) / n_images  (written to *loss, device float).
+ * n_images <= 0 (here and in dml_loss_bwd): the image count is read from sums[4] on the device -- the data-parallel
+ * caller all-reduces {sums[0..3], local batch} in one 5-double message and never brings the count to the host. */
 int dml_loss_finalize(const double* sums, float* loss, float alpha, float n_images, void* stream);
 /* glogits = gout * d loss / d logits; gout is a device scalar. */
 int dml_loss_bwd(const float* logits, const int64_t* labels, const double* sums, const float* gout,

@@ -679,7 +679,8 @@ __global__ __launch_bounds__(256) void loss_sum_kernel(const float* __restrict__
 __global__ void loss_finalize_kernel(const double* sums, float* loss, float alpha, float n_images) {
     if (threadIdx.x == 0 && blockIdx.x == 0) {
         const double ce = sums[0] / sums[1];          // NaN when nothing is valid, as torch
-        *loss = (float)((ce + (double)alpha * sums[2]) / (double)n_images);
+        const double n = n_images > 0.f ? (double)n_images : sums[4];      // data parallel: global image count on the device
+        *loss = (float)((ce + (double)alpha * sums[2]) / n);
     }
 }
 template <int PX>
@@ -688,8 +689,9 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
                                                        const double* __restrict__ sums,
                                                        const float* __restrict__ gout,
                                                        float* __restrict__ glogits, int B, int K, int64_t HW,
-                                                       int64_t ignore_index, float alpha, float n_images) {
+                                                       int64_t ignore_index, float alpha, float n_images_arg) {
     const float go = gout ? *gout : 1.f;
+    const float n_images = n_images_arg > 0.f ? n_images_arg : (float)sums[4];
     const float w_ce = go / ((float)sums[1] * n_images);
     const float w_var = go * alpha / ((float)HW * n_images);
     const int64_t gpi = HW / PX, total = (int64_t)B * gpi;

@@ -823,6 +823,12 @@ class Engine:
         self.step_count = 0
         self.seed = 0x5DEECE66D
 
+    def rank_seed(self) -> int:
+        """dropout seed of this rank: the reference's DataParallel replicas draw independent masks per sample
+        (network/utils.py:354 under main_embedding.py:425), so the data-parallel ranks must not share one"""
+        rank = dist.get_rank() if (dist.is_available() and dist.is_initialized()) else 0
+        return (self.seed ^ (rank * 0xD1B54A32D192ED03)) & 0xFFFFFFFFFFFFFFFF
+
     def side_stream(self, device):
         if device not in self._side:
             self._side[device] = torch.cuda.Stream(device=device)
@@ -915,7 +921,7 @@ class Engine:
             for u in plan.drop_units:
                 p = float(u.drop.p) if u.drop.training else 0.0      # F14: dropout module in eval() => off
                 u.apply_args[14] = p
-                u.apply_args[15] = (self.seed + 0x9E3779B97F4A7C15 * self.step_count) & 0xFFFFFFFFFFFFFFFF
+                u.apply_args[15] = (self.rank_seed() + 0x9E3779B97F4A7C15 * self.step_count) & 0xFFFFFFFFFFFFFFFF
                 for (a, i) in u.gscale_slots:
                     a[i] = 1.0 / (1.0 - p) if p > 0 else 1.0
             if plan.nbt_inc is None:
@@ -959,8 +965,14 @@ class Engine:
             skip.append(plan.backbone_bwd_range)
             skip += [(i, i + 1) for i in plan.to_backbone_ops]
         plan.skip_ranges = skip
-        self.store.begin_backward()
+        state = self.store.begin_backward()
         if self.reducer is not None:
+            if state == "accumulate" and self.reducer.world > 1:
+                # the bucketed all-reduce works in place on the flat gradient: a second backward without zero_grad()
+                # would sum the already reduced gradients over the ranks again (x world), unlike the single-GPU path
+                raise RuntimeError("gradient accumulation over several backward passes is not supported with the "
+                                   "data-parallel reducer attached: call optimizer.zero_grad() (set_to_none=True) "
+                                   "before every backward")
             self.reducer.run_backward(plan, stream)
         else:
             plan.run_backward()

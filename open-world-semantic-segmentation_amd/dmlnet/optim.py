@@ -68,7 +68,17 @@ class FusedSGD(torch.optim.Optimizer):
                 mine = {id(q) for g in self.param_groups for q in g["params"]}
                 for p, off in zip(st.params, st.offsets):
                     if id(p) in mine:            # a parameter outside every group has no optimizer state (state_dict())
-                        self.state[p]["momentum_buffer"] = st._view(st.flat_v, off, p)
+                        view = st._view(st.flat_v, off, p)
+                        # momentum restored by load_state_dict() before the store was bound (--continue_training,
+                        # main_embedding.py:421-434 of the reference), or left over from a re-bind: carry it into the
+                        # flat buffer (OIHW -> the K-R-S-C view) instead of restarting from zero
+                        old = self.state[p].get("momentum_buffer") if p in self.state else None
+                        if old is not None and old.data_ptr() != view.data_ptr():
+                            if tuple(old.shape) != tuple(p.shape):
+                                raise RuntimeError("FusedSGD: restored momentum buffer of shape %s does not match its "
+                                                   "parameter %s" % (tuple(old.shape), tuple(p.shape)))
+                            view.copy_(old.to(device=view.device, dtype=view.dtype))
+                        self.state[p]["momentum_buffer"] = view
             # gradients that are not views of the flat buffer (foreign autograd use) are folded in
             for p, gv in zip(st.params, st.grad_views):
                 if p.grad is None:

@@ -45,6 +45,24 @@ def get_argparser():
     p.add_argument("--frame_height", type=int, default=1024, help="synthetic source frames (Cityscapes: 1024 x 2048)")
     p.add_argument("--frame_width", type=int, default=2048)
     p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    # the rest of the reference's surface (main_embedding.py:27-99 there): accepted so that its command lines keep
+    # working; what they select lives outside the hot path (dataset IO, visdom, result dumps) or is fixed here
+    p.add_argument("--data_root", default="./datasets/data", help="accepted; dataset file IO is out of scope (use --synthetic)")
+    p.add_argument("--dataset", default="cityscapes", choices=["voc", "cityscapes"],
+                   help="accepted; the synthetic frames are Cityscapes-shaped")
+    p.add_argument("--separable_conv", action="store_true",
+                   help="network.convert_to_separable_conv raises NotImplementedError, as SURVEY 8(b) allows")
+    p.add_argument("--test_only", action="store_true", help="run the validation pass once and exit")
+    p.add_argument("--save_val_results", action="store_true", help="accepted and ignored (PNG dumps are out of scope)")
+    p.add_argument("--crop_val", action="store_true", help="accepted and ignored (synthetic validation frames are full size)")
+    p.add_argument("--val_batch_size", type=int, default=1, help="accepted; validation runs one frame per step like the reference default")
+    p.add_argument("--gpu_id", default="0", help="accepted and ignored: one process per GPU, LOCAL_RANK picks the device")
+    p.add_argument("--download", action="store_true", help="accepted and ignored (no network)")
+    p.add_argument("--year", default="2012", help="accepted and ignored (VOC only)")
+    p.add_argument("--enable_vis", action="store_true", help="accepted and ignored (visdom is out of scope)")
+    p.add_argument("--vis_port", default="13570")
+    p.add_argument("--vis_env", default="main")
+    p.add_argument("--vis_num_samples", type=int, default=8)
     return p
 
 
@@ -59,6 +77,8 @@ def main():
 
     model = getattr(network, opts.model)(num_classes=opts.num_classes, output_stride=opts.output_stride,
                                          pretrained_backbone=False)
+    if opts.separable_conv and "plus" in opts.model:                               # :377-378
+        network.convert_to_separable_conv(model.classifier)
     utils.set_bn_momentum(model.backbone, momentum=0.01)                           # :379
     model.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32)
     optimizer = FusedSGD([{"params": model.backbone.parameters(), "lr": 0.1 * opts.lr},
@@ -138,6 +158,16 @@ def main():
                 seg_metrics.update(vl, preds)                                      # :269
         model.train()
         return seg_metrics.get_results()                                           # :324
+
+    if opts.test_only:                                                             # :440-446
+        model.eval()
+        val_score = validate()
+        if world > 1:
+            seg_metrics.all_reduce()
+            val_score = seg_metrics.get_results()
+        if rank == 0:
+            print(seg_metrics.to_str(val_score))
+        return
 
     interval_loss, t0 = None, time.perf_counter()
     while cur_itrs < opts.total_itrs:

@@ -37,55 +37,39 @@ class StreamSegMetrics(object):
 
     @staticmethod
     def to_str(results):
-        string = "\n"
-        for k, v in results.items():
-            if k != "Class IoU":
-                string += "%s: %f\n" % (k, v)
-        return string
+        """one "name: value" line per scalar score; the per-class table is left out (stream_metrics.py:38-47)"""
+        lines = ["%s: %f" % (name, value) for name, value in results.items() if name != "Class IoU"]
+        return "\n" + "\n".join(lines) + "\n"
+
+    def all_reduce(self, group=None):
+        """Sum the confusion matrix over the ranks of a data-parallel evaluation (each rank has seen its shard of the
+        images); afterwards every rank reports the scores of the whole set.  No-op outside a process group."""
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 \
+                and self.confusion_matrix is not None:
+            dist.all_reduce(self.confusion_matrix, group=group)
 
     def get_results(self):
-        """overall accuracy, mean accuracy, mean IoU, frequency-weighted accuracy (stream_metrics.py:57-83)"""
-        hist = self._host if self.confusion_matrix is None else self.confusion_matrix.cpu().numpy().astype(np.float64)
+        """The scores of stream_metrics.py:57-83 of the reference from the n x n count matrix (rows = true class,
+        columns = prediction), in float64 like there: pixel accuracy, mean per-class accuracy, mean IoU and the
+        frequency-weighted IoU (classes that never occur give NaN rows and are skipped by the nan-means)."""
+        if self.confusion_matrix is None:
+            counts = self._host
+        else:
+            counts = self.confusion_matrix.cpu().numpy().astype(np.float64)
+        tp = np.diag(counts)
+        per_true, per_pred, total = counts.sum(axis=1), counts.sum(axis=0), counts.sum()
         with np.errstate(divide="ignore", invalid="ignore"):
-            acc = np.diag(hist).sum() / hist.sum()
-            acc_cls = np.diag(hist) / hist.sum(axis=1)
-            acc_cls = np.nanmean(acc_cls)
-            iu = np.diag(hist) / (hist.sum(axis=1) + hist.sum(axis=0) - np.diag(hist))
-            mean_iu = np.nanmean(iu)
-            freq = hist.sum(axis=1) / hist.sum()
-            fwavacc = (freq[freq > 0] * iu[freq > 0]).sum()
-        cls_iu = dict(zip(range(self.n_classes), iu))
-        return {"Overall Acc": acc, "Mean Acc": acc_cls, "FreqW Acc": fwavacc, "Mean IoU": mean_iu, "Class IoU": cls_iu}
+            iou = tp / (per_true + per_pred - tp)
+            scores = {
+                "Overall Acc": tp.sum() / total,
+                "Mean Acc": np.nanmean(tp / per_true),
+                "FreqW Acc": ((per_true / total)[per_true > 0] * iou[per_true > 0]).sum(),
+                "Mean IoU": np.nanmean(iou),
+            }
+        scores["Class IoU"] = {c: iou[c] for c in range(self.n_classes)}
+        return scores
 
     def reset(self):
         if self.confusion_matrix is not None:
             self.confusion_matrix.zero_()
-
-
-class AverageMeter(object):
-    """Computes average values (stream_metrics.py:88-116 of the reference; host-side bookkeeping)"""
-
-    def __init__(self):
-        self.book = dict()
-
-    def reset_all(self):
-        self.book.clear()
-
-    def reset(self, id):
-        item = self.book.get(id, None)
-        if item is not None:
-            item[0] = 0
-            item[1] = 0
-
-    def update(self, id, val):
-        record = self.book.get(id, None)
-        if record is None:
-            self.book[id] = [val, 1]
-        else:
-            record[0] += val
-            record[1] += 1
-
-    def get_results(self, id):
-        record = self.book.get(id, None)
-        assert record is not None
-        return record[0] / record[1]

@@ -2,7 +2,7 @@
 """Open-world evaluation step of the reference (test_embedding.py:225-653 there) on the MI355X path:
 eval-mode forward, argmax, max-softmax score, dissum anomaly map and the novel-prototype relabel -- all on
 the device (the reference copies a 16 x H x W logit tensor to the host per image).  Images are sharded
-round-robin over ranks; there is no collective on this path.
+round-robin over ranks; the only collectives are the two sums at the very end (confusion matrix, per-image measures).
 
     python test_embedding.py --synthetic --height 1024 --width 2048 --num_images 4 [--ckpt X.pth]
 """
@@ -77,9 +77,22 @@ def main():
             else:
                 n += 1
     torch.cuda.synchronize()
-    if aurocs and rank == 0:
+    n_meas = len(aurocs)
+    if world > 1:
+        # every rank has scored its shard of the images: sum the confusion matrix and the per-image measures (sum,
+        # count) over the ranks, so that rank 0 reports the whole evaluation set, as the reference's single process does
+        import torch.distributed as dist
+        seg_metrics.all_reduce()
+        tot = torch.tensor([float(np.sum(aurocs)), float(np.sum(auprs)), float(np.sum(fprs)), float(n_meas)],
+                           dtype=torch.float64, device=dev)
+        dist.all_reduce(tot)
+        n_meas = int(tot[3].item())
+        mean_meas = (tot[:3] / max(n_meas, 1)).tolist()
+    else:
+        mean_meas = [float(np.mean(v)) if v else float("nan") for v in (aurocs, auprs, fprs)]
+    if n_meas and rank == 0:
         print(seg_metrics.to_str(seg_metrics.get_results()))
-        anom_utils.print_measures(float(np.mean(aurocs)), float(np.mean(auprs)), float(np.mean(fprs)), "dissum")
+        anom_utils.print_measures(mean_meas[0], mean_meas[1], mean_meas[2], "dissum")
     if n:
         print("rank %d: %.2f img/s at %dx%d (%d novel-class pixels in the last image, score mean %.4f)"
               % (rank, n / (time.perf_counter() - t0), o.height, o.width, int((preds == o.num_classes).sum()),

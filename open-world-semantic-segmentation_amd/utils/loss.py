@@ -29,7 +29,7 @@ class _DMLLossFn(torch.autograd.Function):
         B, K, H, W = logit.shape
         if target.shape != (B, H, W):
             raise RuntimeError("target shape %s does not match logits %s" % (tuple(target.shape), tuple(logit.shape)))
-        sums = torch.empty(4, dtype=torch.float64, device=logit.device)
+        sums = torch.empty(5, dtype=torch.float64, device=logit.device)
         part = torch.empty(_lib.LOSS_BLOCKS * 4, dtype=torch.float32, device=logit.device)
         st = _stream(logit)
         _lib.check(lib.dml_loss_fwd(logit.data_ptr(), target.data_ptr(), sums.data_ptr(), part.data_ptr(), B, K, H, W,
@@ -37,8 +37,12 @@ class _DMLLossFn(torch.autograd.Function):
         n_images = float(B)
         if group is not None:
             import torch.distributed as dist
+            # the reference normalises by the size of the gathered batch (utils/loss.py:38-41 on DataParallel's
+            # gather); shards may be uneven (parallel.shard_range spreads a remainder), so the image count travels
+            # with the sums (sums[4], read by the kernels on the device: no host sync) instead of assuming B * world
+            sums[4] = float(B)
             dist.all_reduce(sums, group=group if group is not True else None)
-            n_images = float(B * dist.get_world_size(group if group is not True else None))
+            n_images = 0.0
         loss = torch.empty((), dtype=torch.float32, device=logit.device)
         _lib.check(lib.dml_loss_finalize(sums.data_ptr(), loss.data_ptr(), float(alpha), n_images, st),
                    "dml_loss_finalize")

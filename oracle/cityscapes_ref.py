@@ -11,7 +11,7 @@ Also the evaluation-time relabel of test_embedding.py:448-451 (the held-out clas
 ids 14..16 move down, 254 -> 255).
 
 Parity pin: tests/golden/g13_cityscapes_labels.npz, minted from the reference's own class by
-tools/mint_golden_labels.py (unknown_target None, [14, 15] as shipped, [13, 14, 15] as the README asks for training).
+tests/tools/mint_golden_labels.py (unknown_target None, [14, 15] as shipped, [13, 14, 15] as the README asks for training).
 """
 import numpy as np
 

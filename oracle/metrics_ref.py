@@ -4,7 +4,7 @@
 Restates DeepLabV3Plus-Pytorch/metrics/stream_metrics.py:33-35 (update), :49-55 (_fast_hist: bincount of
 n*true + pred over pixels with 0 <= true < n) and :57-83 (overall / mean accuracy, IoU, frequency-weighted
 accuracy from the confusion matrix) -- SURVEY 8(f) rank 3, "the step after the path".
-Pinned by tests/golden/g10_metrics.npz, minted from the reference class itself (tools/mint_golden_metrics.py).
+Pinned by tests/golden/g10_metrics.npz, minted from the reference class itself (tests/tools/mint_golden_metrics.py).
 """
 import numpy as np
 

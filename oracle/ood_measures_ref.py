@@ -12,7 +12,7 @@ kernels use:
           R = tp / P, tp/fp = positives / negatives with score >= t
   FPR@r = fps[cutoff] / N at the threshold whose recall is nearest to r, scanning thresholds from the lowest that
           reaches full recall upwards and taking the first minimum (anom_utils.py:58-66).
-Pinned by tests/golden/g11_ood_measures.npz minted from anom_utils.get_measures itself (tools/mint_golden_metrics.py).
+Pinned by tests/golden/g11_ood_measures.npz minted from anom_utils.get_measures itself (tests/tools/mint_golden_metrics.py).
 """
 import numpy as np
 

@@ -10,7 +10,7 @@ What it restates (inference branch only):
                                                embedding, -||f - 3 e_k||^2 at 1/8 resolution, THEN bilinear to segSize
   anomaly/eval_ood_traditional.py:190-210      multi-scale mean of the upsampled scores / features
   anomaly/lib/nn/modules/batchnorm.py:56-61    SynchronizedBatchNorm2d in eval() = F.batch_norm with running statistics
-Parity pin: tests/golden/g14_ppm.npz, minted from the reference's own classes by tools/mint_golden_ppm.py (weights are
+Parity pin: tests/golden/g14_ppm.npz, minted from the reference's own classes by tests/tools/mint_golden_ppm.py (weights are
 regenerated on both sides from tests/helpers.synth_state_dict; the fixture holds inputs and outputs only).
 """
 import torch

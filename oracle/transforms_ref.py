@@ -21,7 +21,7 @@ Their published algorithm, restated here:
   Image.blend(a, b, f): float32  t = a + f * (b - a);  0 <= f <= 1: (uint8) t (truncation);
                         otherwise clip t to [0, 255] first.
 Parity pin: tests/golden/g9_*.npz are outputs of the reference's own ext_transforms classes driven through a
-torchvision shim over the real Pillow in the authoring container (tools/mint_golden_aug.py; Pillow 12.2.0 there),
+torchvision shim over the real Pillow in the authoring container (tests/tools/mint_golden_aug.py; Pillow 12.2.0 there),
 and tests/test_oracle.py re-checks the three enhance functions against the live Pillow when it is importable.
 """
 import numpy as np

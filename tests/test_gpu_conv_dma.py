@@ -38,6 +38,46 @@ def test_sync_batchnorm_two_ranks_match_one_process():
     assert "rank 0:" in r.stdout and "rank 1:" in r.stdout
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def test_data_parallel_reducer_two_ranks():
+    """The product's N > 1 path (GradReducer.run_backward on the real ParamStore: reverse-order buckets launched from
+    Plan.param_last_op on the comm stream while the backward plan and the weight-gradient side stream keep running),
+    two gloo ranks sharing this GPU with UNEVEN shards: tools/check_ddp.py."""
+    env = dict(os.environ, DML_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(H.ROOT, "tools", "check_ddp.py")],
+                       env=env, capture_output=True, text=True, cwd=H.ROOT, timeout=1200)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]
+    assert "parameters identical across ranks after 3 steps: True" in r.stdout and "uneven shards" in r.stdout
+
+
+def test_bench_gpus_flag_launches_ranks_itself():
+    """`python bench.py --gpus N` (no torchrun): N = 2 on this 1-GPU box must fail cleanly before any GPU work, and with
+    DML_BENCH_ALLOW_SHARED_GPU=1 (test hook: ranks share device 0 over gloo) it must print ONE line with n_gpus 2."""
+    import json
+    args = [sys.executable, os.path.join(H.ROOT, "bench.py"), "--gpus", "2", "--size", "128", "--batch", "2", "--steps", "2",
+            "--warmup", "1", "--no-cpu-baseline"]
+    if __import__("torch").cuda.device_count() < 2:
+        r = subprocess.run(args, capture_output=True, text=True, cwd=H.ROOT, timeout=600)
+        assert r.returncode != 0 and "GPU" in (r.stderr + r.stdout)
+    env = dict(os.environ, DML_BENCH_ALLOW_SHARED_GPU="1", DML_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run(args, capture_output=True, text=True, cwd=H.ROOT, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo"
+    assert d["config"]["global_batch"] == 4 and d["value"] > 0
+
+
 def test_bench_script_default_path_small():
     """bench.py end to end (timed region, profiled conv pass, distance kernel, input pipeline) at a small size: the
     JSON line must carry the contract's fields."""

@@ -256,3 +256,42 @@ def test_g12_multihead_self_distillation_model():
         assert np.allclose(H.checksum(grads[k])[1:], g["grad_%d_checksum" % i][1:], rtol=1e-4), k
     for k in (str(k) for k in g["untouched"]):
         assert grads[k] is None
+
+
+def test_bf16_storage_emulation_is_the_same_model_when_rounding_is_off(monkeypatch):
+    """oracle/bf16_emu.py only inserts roundings: with the rounding replaced by the identity the patched model must
+    reproduce the pinned oracle (logits, loss, every gradient, running statistics) -- so what the bf16 parity tests
+    compare against is the reference's graph, not a second restatement of it."""
+    from oracle import bf16_emu
+    img = H.synth_tensor(5, "g5.img", (2, 3, 64, 64))
+    lab = H.synth_labels(5, "g5.lab", (2, 64, 64), 16, 255, ignore_rows=3)
+
+    def run(patch):
+        o = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+        o.load_state_dict(H.synth_state_dict(H.shapes_of(o), seed=1))
+        o.train()
+        o.classifier.aspp.project[3].eval()
+        O.set_bn_momentum(o.backbone, 0.01)
+        if patch:
+            bf16_emu.emulate_bf16_storage(o)
+        lg, _, _ = o(img)
+        loss = O.dml_loss(lg, lab, alpha=0.01, ignore_index=255)
+        loss.backward()
+        return o, lg.detach(), loss.detach()
+
+    ref, lg_ref, loss_ref = run(False)
+    monkeypatch.setattr(bf16_emu, "q", lambda t: t)
+    emu, lg_emu, loss_emu = run(True)
+    close(lg_emu, lg_ref, 2e-5)
+    close(loss_emu, loss_ref, 1e-5)
+    for (k, p), (_, r) in zip(emu.named_parameters(), ref.named_parameters()):
+        assert H.max_abs(p.grad, r.grad) <= 2e-4 * (float(r.grad.abs().max()) + 1e-12), k
+    for (k, b), (_, r) in zip(emu.named_buffers(), ref.named_buffers()):
+        close(b.float(), r.float(), 1e-5)
+    monkeypatch.undo()
+    # with the rounding on the result moves by a bf16-sized amount, not more
+    _, lg_q, loss_q = run(True)
+    d = H.rel_err(lg_q, lg_ref)
+    assert 1e-4 < d < 0.15, d          # measured 6.5e-2: ~100 layers amplify the 2^-9 roundings ~16x
+    assert abs(float(loss_q) - float(loss_ref)) < 5e-2 * abs(float(loss_ref))
+    assert torch.equal(bf16_emu.q(torch.tensor([1.0 + 2 ** -9, 1.0 + 3 * 2 ** -9])), torch.tensor([1.0, 1.0 + 2 ** -7]))

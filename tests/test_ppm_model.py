@@ -1,5 +1,5 @@
 """Anomaly sub-project model: dilated deep-stem ResNet-50 + pyramid-pooling embedding decoder,
-inference branch.  CPU: oracle vs fixture G14 (minted from the reference's own classes, tools/mint_golden_ppm.py) and the
+inference branch.  CPU: oracle vs fixture G14 (minted from the reference's own classes, tests/tools/mint_golden_ppm.py) and the
 module-tree contract; GPU: the HIP plan vs fixture / oracle through the C ABI, and its three kernels vs torch ops."""
 import ctypes as C
 import os

@@ -6,7 +6,7 @@ Imports ``/root/reference`` with the shims of SURVEY.md Appendix B (fake torchvi
 (``oracle/dmlnet_ref.py``) against them, and writes small ``.npz`` fixtures.  Nothing from the
 reference travels: fixtures hold inputs/seeds and expected outputs only.
 
-    python tools/mint_golden.py            # regenerate everything (~2 min on 8 cores)
+    python tests/tools/mint_golden.py            # regenerate everything (~2 min on 8 cores)
 """
 from __future__ import annotations
 

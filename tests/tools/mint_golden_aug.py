@@ -12,7 +12,7 @@ import numpy as np
 import torch
 from PIL import Image, ImageEnhance
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference/DeepLabV3Plus-Pytorch/utils/ext_transforms.py"
 
 F = types.ModuleType("torchvision.transforms.functional")

@@ -3,7 +3,7 @@
 import contextlib, importlib.util, io, os, sys, types
 import numpy as np
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 REF = "/root/reference/DeepLabV3Plus-Pytorch/datasets/cityscapes.py"
 sys.dont_write_bytecode = True
 # the module imports torchvision.transforms and matplotlib at the top; neither is used by encode_target

@@ -1,7 +1,7 @@
 """Mint tests/golden/g10_metrics.npz from the reference's StreamSegMetrics (authoring container only)."""
 import contextlib, importlib.util, io, os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.dont_write_bytecode = True
 spec = importlib.util.spec_from_file_location("ref_stream_metrics",
                                               "/root/reference/DeepLabV3Plus-Pytorch/metrics/stream_metrics.py")

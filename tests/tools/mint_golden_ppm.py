@@ -4,7 +4,7 @@ import contextlib, io, os, sys, types
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path[:0] = [os.path.join(ROOT, "tests")]
 import helpers as H  # noqa: E402
 sys.path = [p for p in sys.path if not p.rstrip("/").endswith("open-world-semantic-segmentation_amd")]   # our `models` must not shadow
