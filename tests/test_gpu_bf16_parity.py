@@ -1,13 +1,16 @@
 """GPU: the bf16 throughput mode -- the kernels bench.py times (conv_igemm_dma_kernel, conv_wgrad_big_kernel, the fused
-BN-backward epilogue, the bit-mask BN kernels) -- against the oracle run with bf16 storage emulated at the points the
-HIP plan rounds (oracle/bf16_emu.py): logits, loss and EVERY parameter gradient at model level.
+BN-backward epilogue, the bit-mask BN kernels) -- gated at model level, plus the fp32 mode at the benchmark's crop size.
 
-Why not 1e-3: the reference's arithmetic is fp32 (network/utils.py:84-118 of the reference); in bf16 storage mode a single
-rounding is 2^-9 = 2e-3 relative, and the HIP path and the emulation differ in fp32 summation order, so individual bf16
-values flip by one ulp and the flips propagate through ~100 layers.  The bars below are 2-3x what was measured on
-MI355X (printed by the tests) -- an order of magnitude inside what a mis-scaled gradient on any layer class would give
-(a wrong factor on one layer moves that tensor's relative error to O(1)) -- and the fp32 mode keeps the 1e-3 bar
-(test_gpu_model.py, test_fp32_768_against_oracle below).
+The reference's arithmetic is fp32 (network/utils.py:84-118 there) and the fp32 mode keeps the 1e-3 bar.  bf16 storage
+cannot: one rounding is 2^-9, and a train-mode BatchNorm network amplifies perturbations so strongly that the bf16-storage
+ORACLE itself (oracle/bf16_emu.py) moves its gradients by 1 - cos = 0.08 under a 1e-3 relative change of the image
+(tests/tools/bf16_noise.py; on a 2 x 64 x 64 input the gradients are pure noise, 1 - cos = 0.8).  Two gates replace an
+element-wise comparison:
+  1. locally exact: after a bf16 train step at 768 x 768 every one of the 112 conv + BN units is recomputed from the
+     plan's own stored tensors and must match to one bf16 ulp (forward conv, statistics, BN apply, BN backward, gamma /
+     beta / weight / data gradients) -- every kernel of the timed configuration on its actual inputs;
+  2. statistically equivalent end to end: logits, loss and for EVERY parameter tensor the direction and the norm of the
+     gradient are as close to the fp32 oracle as the emulated bf16-storage oracle's are.
 """
 import numpy as np
 import pytest
@@ -64,9 +67,36 @@ def _grad_errors(m, o):
     return np.array(emax), np.array(ecos), names
 
 
-def _train_step_compare(shape, seed, tag, bars):
-    import utils
+def _oracle_grads(seed, shape, tag, emulate):
     from oracle import dmlnet_ref as O
+    img = H.synth_tensor(seed, tag + ".img", shape)
+    lab = H.synth_labels(seed, tag + ".lab", (shape[0], shape[2], shape[3]), 16, 255, ignore_frac=0.05)
+    o = _build_oracle(seed, emulate=emulate)
+    lg, _, ft = o(img)
+    loss = O.dml_loss(lg, lab, alpha=0.01, ignore_index=255)
+    loss.backward()
+    return lg.detach(), float(loss), {k: p.grad.detach().double() for k, p in o.named_parameters()}, o
+
+
+def _vs_truth(grads, truth):
+    """per tensor: 1 - cosine to the fp32 oracle's gradient and the ratio of the norms"""
+    one_minus_cos, ratio = [], []
+    for k, t in truth.items():
+        a, b = grads[k].flatten(), t.flatten()
+        na, nb = a.norm().item(), b.norm().item()
+        one_minus_cos.append(1.0 - (a @ b).item() / (na * nb + 1e-30))
+        ratio.append(na / (nb + 1e-30))
+    return np.array(one_minus_cos), np.array(ratio)
+
+
+def _statistical_equivalence(shape, seed, tag):
+    """End to end, bf16 mode.  A deep BatchNorm network in train mode amplifies perturbations: on these inputs a 1e-3
+    relative change of the IMAGE moves the bf16-storage oracle's own gradients by 1 - cos = 0.08 (4 x 256^2; tools:
+    tests/tools/bf16_noise.py), so two correct bf16 implementations cannot agree element by element.  What a correct
+    one must do is sit exactly as far from the fp32 truth as the emulated bf16 oracle does -- logits, loss and, for EVERY
+    parameter tensor, direction (cosine) and magnitude (norm ratio) of the gradient.  A mis-scaled or mis-wired
+    gradient on any layer class shows as a norm ratio of 2 / 0.5 or a cosine near 0 on those tensors."""
+    import utils
     torch.set_num_threads(min(64, torch.get_num_threads() or 8))
     img = H.synth_tensor(seed, tag + ".img", shape)
     lab = H.synth_labels(seed, tag + ".lab", (shape[0], shape[2], shape[3]), 16, 255, ignore_frac=0.05)
@@ -75,53 +105,141 @@ def _train_step_compare(shape, seed, tag, bars):
     loss = utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft)
     loss.backward()
     torch.cuda.synchronize()
-    o = _build_oracle(seed, emulate=True)
-    olg, _, oft = o(img)
-    oloss = O.dml_loss(olg, lab, alpha=0.01, ignore_index=255)
-    oloss.backward()
-    # how far bf16 storage itself moves the result (emulated oracle vs the plain fp32 oracle): context for the bars
-    o32 = _build_oracle(seed, emulate=False)
-    with torch.no_grad():
-        ref32, _, _ = o32(img)
-    e_lg = H.rel_err(lg, olg)
-    e_ft = H.rel_err(ft, oft)
-    e_loss = abs(loss.item() - oloss.item()) / abs(oloss.item())
-    emax, ecos, names = _grad_errors(m, o)
-    worst = int(np.argmax(emax))
-    print("%s: logits rel %.2e (bf16 storage vs fp32 oracle: %.2e), features %.2e, loss %.2e | grads max-norm: median "
-          "%.2e p95 %.2e max %.2e (%s) | 1-cos: median %.2e p95 %.2e max %.2e"
-          % (tag, e_lg, H.rel_err(olg, ref32), e_ft, e_loss, np.median(emax), np.percentile(emax, 95), emax.max(),
-             names[worst], np.median(ecos), np.percentile(ecos, 95), ecos.max()))
+    g_hip = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
+    t_lg, t_loss, g_true, o32 = _oracle_grads(seed, shape, tag, emulate=False)
+    e_lg, e_loss, g_emu, oemu = _oracle_grads(seed, shape, tag, emulate=True)
+    d_hip, d_emu = H.rel_err(lg, t_lg), H.rel_err(e_lg, t_lg)
+    l_hip, l_emu = abs(loss.item() - t_loss) / abs(t_loss), abs(e_loss - t_loss) / abs(t_loss)
+    c_hip, r_hip = _vs_truth(g_hip, g_true)
+    c_emu, r_emu = _vs_truth(g_emu, g_true)
+    names = list(g_true.keys())
+    print("%s vs fp32 oracle | logits: hip %.2e emu %.2e | loss: hip %.2e emu %.2e | 1-cos median/p95/max: hip %.2e %.2e "
+          "%.2e (%s) emu %.2e %.2e %.2e | norm ratio median [min,max]: hip %.3f [%.3f (%s), %.3f (%s)] emu %.3f [%.3f, %.3f]"
+          % (tag, d_hip, d_emu, l_hip, l_emu, np.median(c_hip), np.percentile(c_hip, 95), c_hip.max(),
+             names[int(np.argmax(c_hip))], np.median(c_emu), np.percentile(c_emu, 95), c_emu.max(), np.median(r_hip),
+             r_hip.min(), names[int(np.argmin(r_hip))], r_hip.max(), names[int(np.argmax(r_hip))], np.median(r_emu),
+             r_emu.min(), r_emu.max()))
     assert torch.isfinite(lg).all()
-    assert e_lg <= bars["logits"] and e_ft <= bars["logits"], (e_lg, e_ft)
-    assert e_loss <= bars["loss"], e_loss
-    assert np.median(emax) <= bars["g_med"], np.median(emax)
-    assert np.percentile(emax, 95) <= bars["g_p95"], np.percentile(emax, 95)
-    assert emax.max() <= bars["g_max"], (emax.max(), names[worst])
-    assert ecos.max() <= bars["cos_max"], (ecos.max(), names[int(np.argmax(ecos))])
-    # running statistics come from the fp32 accumulators on both sides
-    bufs, obufs = dict(m.named_buffers()), dict(o.named_buffers())
+    assert d_hip <= 2.0 * d_emu + 1e-3, (d_hip, d_emu)
+    assert l_hip <= 3.0 * l_emu + 2e-3, (l_hip, l_emu)
+    # direction: the distribution over the 338 tensors must match the emulation's
+    assert np.median(c_hip) <= 1.5 * np.median(c_emu) + 2e-3
+    assert np.percentile(c_hip, 95) <= 1.5 * np.percentile(c_emu, 95) + 5e-3
+    assert c_hip.max() <= 2.0 * c_emu.max() + 2e-2, names[int(np.argmax(c_hip))]
+    # magnitude: no tensor off by a factor, the bulk within the emulation's own spread
+    spread = max(abs(r_emu.max() - 1), abs(1 - r_emu.min()))
+    assert abs(np.median(r_hip) - 1) <= abs(np.median(r_emu) - 1) + 0.03
+    assert r_hip.max() <= 1 + 2.0 * spread + 0.05 and r_hip.min() >= 1 - 2.0 * spread - 0.05, (r_hip.min(), r_hip.max(), spread)
+    # running statistics come from the fp32 accumulators of bf16 convolutions on both sides
+    bufs, obufs = dict(m.named_buffers()), dict(oemu.named_buffers())
     for k in ("backbone.bn1.running_var", "backbone.layer3.11.bn2.running_mean", "backbone.layer4.2.bn3.running_var",
               "classifier.classifier.1.running_var"):
-        assert H.rel_err(bufs[k], obufs[k]) <= bars["logits"], k
+        assert H.rel_err(bufs[k], obufs[k]) <= max(2.0 * H.rel_err(dict(o32.named_buffers())[k], obufs[k]), 1e-3), k
+    return m
 
 
-BARS_SMALL = dict(logits=2e-2, loss=5e-3, g_med=2e-2, g_p95=6e-2, g_max=0.25, cos_max=3e-2)
-BARS_768 = dict(logits=2e-2, loss=5e-3, g_med=2e-2, g_p95=6e-2, g_max=0.25, cos_max=3e-2)
+def test_bf16_end_to_end_4x256_statistically_equivalent_to_emulated_oracle():
+    _statistical_equivalence((4, 3, 256, 256), 9, "bf16.256")
 
 
-def test_bf16_train_step_g5_sized_against_emulated_oracle():
-    _train_step_compare((2, 3, 64, 64), 5, "bf16.g5", BARS_SMALL)
+def test_bf16_end_to_end_768_bs2_statistically_equivalent_to_emulated_oracle():
+    _statistical_equivalence((2, 3, 768, 768), 77, "bf16.768")
 
 
-def test_bf16_train_step_nonsquare_against_emulated_oracle():
-    _train_step_compare((3, 3, 96, 128), 9, "bf16.fresh", BARS_SMALL)
+def _act(a):
+    """plan Act (possibly a channel slice of a concat buffer) -> [M, C] float32 on the CPU"""
+    off = (a.ptr - a.t.data_ptr()) // a.es
+    flat = a.t.view(-1)
+    idx = off + torch.arange(a.M, device=flat.device).unsqueeze(1) * a.ld + torch.arange(a.C, device=flat.device).unsqueeze(0)
+    return flat[idx].float().cpu()
 
 
-def test_bf16_train_step_768_bs2_against_emulated_oracle():
-    """the benchmark's crop size: large-map-only code paths (two-stage BN finalize, conv_wgrad_big_kernel, the
-    192 x 192 layers, 31-bit offset fast path)"""
-    _train_step_compare((2, 3, 768, 768), 77, "bf16.768", BARS_768)
+def _nchw(a2d, B, Hh, Ww):
+    return a2d.view(B, Hh, Ww, -1).permute(0, 3, 1, 2).contiguous()
+
+
+@pytest.mark.parametrize("shape,seed", [((2, 3, 768, 768), 77), ((3, 3, 96, 160), 9)])
+def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
+    """The tight gate for the kernels bench.py times.  One bf16 train step; then for EVERY conv + BN (+ residual + ReLU)
+    unit of the plan, from the plan's OWN stored tensors: the unit's outputs are recomputed with torch on the CPU in
+    fp32 / fp64 and compared at bf16 resolution -- forward conv (conv_igemm_dma_kernel), batch statistics from the fp32
+    accumulators, BN apply; backward BN (fused reduce in the data-gradient epilogue or stand-alone), gamma / beta
+    gradients, weight gradient (conv_wgrad_big_kernel / conv_wgrad_kernel + split-K fold), data gradient.  Teacher
+    forcing removes the chaos of the end-to-end comparison: every kernel is held to 1 bf16 ulp on its actual inputs at
+    the benchmark's map sizes."""
+    import torch.nn.functional as F
+    import utils
+    torch.set_num_threads(min(64, torch.get_num_threads() or 8))
+    img = H.synth_tensor(seed, "unit.img", shape)
+    lab = H.synth_labels(seed, "unit.lab", (shape[0], shape[2], shape[3]), 16, 255, ignore_frac=0.05)
+    m = _build_hip(torch.bfloat16, seed)
+    lg, _, ft = m(img.cuda())
+    utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft).backward()
+    torch.cuda.synchronize()
+    plan = next(p for k, p in m._engine.plans.items() if k[4])
+    names = {id(mod): n for n, mod in m.named_modules()}
+    from collections import Counter
+    consumers = Counter(id(u.x.root) for u in plan.units)
+    for u in plan.units:
+        if u.res is not None:
+            consumers[id(u.res.root)] += 1          # the identity branch adds its gradient to that buffer too
+    ULP = 2.0 ** -8                      # one bf16 ulp relative to the value (round to nearest: half of it)
+    worst = {}
+
+    def note(kind, name, err, bar):
+        if err > worst.get(kind, (0, ""))[0]:
+            worst[kind] = (err, name)
+        assert err <= bar, "%s of %s: %.3e > %.1e" % (kind, name, err, bar)
+
+    def relmax(got, ref):
+        return (got.double() - ref.double()).abs().max().item() / (ref.double().abs().max().item() + 1e-30)
+
+    n_fused = 0
+    for u in plan.units:
+        name = names[id(u.conv)]
+        conv, bn = u.conv, u.bn
+        cin = conv.in_channels
+        x = _nchw(_act(u.x), u.x.B, u.x.H, u.x.W)[:, :cin]
+        wq = conv.weight.detach().float().cpu().to(torch.bfloat16).float().contiguous().requires_grad_(True)
+        xr = x.clone().requires_grad_(consumers[id(u.x.root)] == 1 and u.x is u.x.root and u.x.root.grad is not None)
+        y_ref = F.conv2d(xr, wq, None, conv.stride, conv.padding, conv.dilation)
+        y = _nchw(_act(u.y), u.y.B, u.y.H, u.y.W)
+        note("conv fwd (stored y vs fp32 conv of the stored operands)", name, relmax(y, y_ref.detach()), 0.75 * ULP)
+        mean, var = y_ref.detach().mean((0, 2, 3)), y_ref.detach().var((0, 2, 3), unbiased=False)
+        note("batch mean", name, (u.mean.cpu() - mean).abs().max().item() / (var.sqrt().max().item() + 1e-30), 1e-4)
+        note("batch invstd", name, relmax(u.invstd.cpu(), torch.rsqrt(var + bn.eps)), 1e-4)
+        gam, bet = bn.weight.detach().float().cpu(), bn.bias.detach().float().cpu()
+        sh = (1, -1, 1, 1)
+        mu, inv = u.mean.float().cpu(), u.invstd.float().cpu()
+        z_ref = (y - mu.view(sh)) * (gam * inv).view(sh) + bet.view(sh)
+        if u.res is not None:
+            z_ref = z_ref + _nchw(_act(u.res), u.res.B, u.res.H, u.res.W)
+        if u.relu:
+            z_ref = z_ref.clamp_min(0)
+        z = _nchw(_act(u.z), u.z.B, u.z.H, u.z.W)
+        note("bn apply (z)", name, relmax(z, z_ref), 0.75 * ULP)
+        # ---- backward, from the stored dz / y / z
+        dz = _nchw(_act(u.dz), u.z.B, u.z.H, u.z.W).double()
+        g = dz * (z > 0) if u.relu else dz
+        xhat = (y.double() - mu.double().view(sh)) * inv.double().view(sh)
+        M = y.numel() // y.shape[1]
+        dbeta, dgamma = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
+        dy_ref = (gam.double() * inv.double()).view(sh) * (g - dbeta.view(sh) / M - xhat * dgamma.view(sh) / M)
+        dy = _nchw(_act(u.dy), u.y.B, u.y.H, u.y.W)
+        note("bn backward (dy)", name, relmax(dy, dy_ref), 1.5 * ULP)
+        note("d gamma", name, relmax(bn.weight.grad.cpu(), dgamma), 2e-3)
+        note("d beta", name, relmax(bn.bias.grad.cpu(), dbeta), 2e-3)
+        # ---- weight / data gradient from the stored x and dy
+        y_ref.backward(dy)
+        note("weight gradient", name, relmax(conv.weight.grad.cpu(), wq.grad), 2e-3)
+        if xr.requires_grad:
+            gx = _nchw(_act(u.x.root.grad), u.x.B, u.x.H, u.x.W)[:, :cin]
+            note("data gradient", name, relmax(gx, xr.grad), 0.75 * ULP)
+    dsc_fused = sum(1 for fn, args in plan.bwd if fn is plan.lib.dml_conv_igemm and args[0]._obj.bnr_partials)
+    print("units %d, data gradients with the fused BN-backward sums %d; worst: %s"
+          % (len(plan.units), dsc_fused, "; ".join("%s %.2e (%s)" % (k, v[0], v[1]) for k, v in worst.items())))
+    assert len(plan.units) == 113 - 1          # 112 conv+BN units (the final 1x1 conv has no BN)
+    assert dsc_fused >= 60                      # the timed configuration: most reduces run inside the data gradients
 
 
 def test_fp32_768_bs2_against_oracle():
