@@ -357,6 +357,33 @@ int dml_ood_measures(const float* conf, const int64_t* seg_label, const uint8_t*
                      const int64_t* out_labels, int n_out, double recall_level, void* work,
                      int64_t work_bytes, double* result, void* stream);
 
+/* ------------------------------------------------------------------------------------------------
+ * Native replay of a static launch list.  The reference dispatches one Python call per layer per step
+ * (nn.Module.forward / autograd, network/utils.py:84-118, backbone/resnet.py:95-115); the drop-in's plan is a fixed
+ * list of this library's own entry points, and dml_plan_run walks a packed copy of it in one call -- same launches,
+ * same order, same streams, no interpreter in between.  HOST-side only: `ops` is a host array.
+ *   fn      index from dml_plan_fn_id("dml_...") (any entry point above whose last parameter is the stream)
+ *   args    one 64-bit word per parameter in declaration order, stream excluded: pointers and integers as they are
+ *           (sign-extended), float in the low 32 bits, double as its 64 bits; host pointers to descriptors
+ *           (DmlConvDesc / DmlWgradDesc) must stay valid for the call
+ *   indirect bit k set: args[k] is the HOST address of an int32 read when the op is issued (the *nblocks that
+ *           dml_bn_bwd_reduce wrote a few ops earlier)
+ *   stream  0 = `stream`, 1 = `side_stream` (weight gradients); wait = 1: the side stream first waits for everything
+ *           enqueued on `stream` so far (one of `events`, a ring of hipEvent_t, is recorded there)
+ * Ops [first, last) are issued; on failure the index goes to *failed_op and the op's code is returned.
+ * ---------------------------------------------------------------------------------------------- */
+#define DML_PLAN_MAX_ARGS 22
+typedef struct DmlPlanOp {
+    int32_t fn, nargs;
+    int32_t stream, wait;
+    uint32_t indirect, reserved;
+    uint64_t args[DML_PLAN_MAX_ARGS];
+} DmlPlanOp;
+int dml_plan_fn_id(const char* name);
+int dml_plan_fn_nargs(int fn);
+int dml_plan_run(const DmlPlanOp* ops, int first, int last, void* stream, void* side_stream, void* const* events,
+                 int n_events, int* failed_op);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,6 +37,15 @@ class ConvDesc(C.Structure):
                 ("post_ldres", C.c_int32), ("post_relu", C.c_int32)]
 
 
+PLAN_MAX_ARGS = 22
+
+
+class PlanOp(C.Structure):
+    """DmlPlanOp: one packed launch of a native launch list (dml_plan_run)"""
+    _fields_ = [("fn", C.c_int32), ("nargs", C.c_int32), ("stream", C.c_int32), ("wait", C.c_int32),
+                ("indirect", C.c_uint32), ("reserved", C.c_uint32), ("args", C.c_uint64 * PLAN_MAX_ARGS)]
+
+
 class BnEvalDesc(C.Structure):
     _fields_ = [("gamma", c_p), ("beta", c_p), ("running_var", c_p), ("scale", c_p), ("shift", c_p),
                 ("N", C.c_int32), ("eps", C.c_float)]
@@ -117,6 +126,9 @@ _PROTOS = {
     "dml_adaptive_avgpool_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_proto_dist_nhwc": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "dml_upsample_nhwc_to_nchw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "dml_plan_fn_id": (c_i, [C.c_char_p]),
+    "dml_plan_fn_nargs": (c_i, [c_i]),
+    "dml_plan_run": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, C.POINTER(c_i)]),
 }
 
 EXPORTS = tuple(_PROTOS.keys())

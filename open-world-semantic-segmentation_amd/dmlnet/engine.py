@@ -16,6 +16,7 @@ from __future__ import annotations
 import ctypes as C
 import itertools
 import os
+import struct
 from typing import List, Optional
 
 import torch
@@ -38,6 +39,91 @@ def _dt(dtype: torch.dtype) -> int:
 
 def _round_up(a: int, b: int) -> int:
     return (a + b - 1) // b * b
+
+
+# ---------------------------------------------------------------------------------------------------
+# native launch lists (dml_plan_run)
+# ---------------------------------------------------------------------------------------------------
+_M64 = 0xFFFFFFFFFFFFFFFF
+
+
+def _pack_word(v, ctype):
+    """one argument -> (64-bit word, indirect flag) in the convention of DmlPlanOp (include/dmlnet_hip.h)"""
+    if v is None:
+        return 0, False
+    if ctype is C.c_float:
+        return struct.unpack("<I", struct.pack("<f", float(v)))[0], False
+    if ctype is C.c_double:
+        return struct.unpack("<Q", struct.pack("<d", float(v)))[0], False
+    if isinstance(v, int):
+        return v & _M64, False
+    if hasattr(v, "_obj"):                         # C.byref(x): the address of x (descriptor structs, int* out-parameters)
+        return C.addressof(v._obj), False
+    if isinstance(v, C._SimpleCData):              # a c_int passed by value that another op fills in at issue time
+        if C.sizeof(v) != 4:
+            raise TypeError("only 32-bit indirect arguments are supported")
+        return C.addressof(v), True
+    raise TypeError("cannot pack plan argument %r for %r" % (v, ctype))
+
+
+class BoundArgs(list):
+    """The argument list of one plan op.  Plain list for the Python replay; once the op has a slot in a native launch
+    list, item assignment (per-step pointers, seeds, momenta) writes through to the packed copy."""
+    __slots__ = ("slot", "types")
+
+    def __init__(self, it=()):
+        super().__init__(it)
+        self.slot, self.types = None, None
+
+    def __setitem__(self, k, v):
+        super().__setitem__(k, v)
+        if self.slot is not None:
+            w, ind = _pack_word(v, self.types[k])
+            self.slot.args[k] = w
+            if ind:
+                self.slot.indirect |= (1 << k)
+            else:
+                self.slot.indirect &= ~(1 << k) & 0xFFFFFFFF
+
+
+class NativeList:
+    """Packed copy of a plan's op list for dml_plan_run; ops that are Python callables (collectives) stay outside."""
+
+    def __init__(self, lib, ops, side=None):
+        self.lib = lib
+        n = len(ops)
+        self.arr = (_lib.PlanOp * max(n, 1))()
+        self.python_ops = set()
+        ids = {}
+        for i, (fn, args) in enumerate(ops):
+            name = getattr(fn, "__name__", None)
+            types = getattr(fn, "argtypes", None)
+            if name is None or types is None or not name.startswith("dml_"):
+                self.python_ops.add(i)
+                self.arr[i].fn = -1
+                continue
+            if name not in ids:
+                ids[name] = lib.dml_plan_fn_id(name.encode())
+            fid = ids[name]
+            if fid < 0 or lib.dml_plan_fn_nargs(fid) != len(args) or len(args) > _lib.PLAN_MAX_ARGS \
+                    or len(types) != len(args) + 1:
+                raise RuntimeError("plan op %d (%s) does not fit the native launch list" % (i, name))
+            slot = self.arr[i]
+            slot.fn, slot.nargs, slot.indirect = fid, len(args), 0
+            flag = side.get(i) if side else None
+            slot.stream, slot.wait = (0, 0) if flag is None else (1, 1 if flag else 0)
+            if not isinstance(args, BoundArgs):
+                raise TypeError("plan op arguments must come from Plan.call()")
+            args.slot, args.types = slot, types
+            for k, v in enumerate(args):
+                args[k] = v                          # packs through __setitem__
+        self.n = n
+        self.failed = C.c_int(-1)
+
+    def run(self, first, last, stream, side_stream=None, events=None, n_events=0):
+        rc = self.lib.dml_plan_run(self.arr, first, last, stream, side_stream, events, n_events, C.byref(self.failed))
+        if rc:
+            _lib.check(rc, "native plan op %d" % self.failed.value)
 
 
 # ---------------------------------------------------------------------------------------------------
@@ -224,6 +310,7 @@ class Plan:
         self.prep_table = None
         self.side = {}                 # backward op index -> True if it must first wait for the main stream
         self._side_events = None
+        self._nat, self._ev_handles, self._ev_objs = {}, None, None
         self.drop_units = []
         self.sync = bool(engine.sync_bn and training and dist.is_available() and dist.is_initialized()
                          and dist.get_world_size(engine.sync_group) > 1)
@@ -260,7 +347,7 @@ class Plan:
         def op(stream):
             fn()
             return 0
-        ops.append((op, []))
+        ops.append((op, BoundArgs()))
 
     def fbuf(self, n, zero=False):
         t = (torch.zeros if zero else torch.empty)(max(int(n), 1), dtype=torch.float32, device=self.device)
@@ -279,7 +366,7 @@ class Plan:
         return g
 
     def call(self, ops, fn, *args):
-        lst = list(args)
+        lst = BoundArgs(args)
         ops.append((fn, lst))
         return lst
 
@@ -731,23 +818,99 @@ class Plan:
                    "dml_prep_weights")
         self.prepped_version = key
 
+    # ---- replay: one C call per contiguous run of ops (dml_plan_run) unless the engine is told to stay in Python
+    def _native_list(self, ops):
+        key = id(ops)
+        nat = self._nat.get(key)
+        if nat is None:
+            nat = NativeList(self.lib, ops, self.side if ops is self.bwd else None)
+            self._nat[key] = nat
+        return nat
+
+    def _events(self):
+        if self._ev_handles is None:
+            cur = torch.cuda.current_stream(self.device)
+            self._ev_objs = [torch.cuda.Event() for _ in range(16)]
+            for e in self._ev_objs:
+                e.record(cur)                       # instantiates the hipEvent_t
+            self._ev_handles = (C.c_void_p * len(self._ev_objs))(*[e.cuda_event for e in self._ev_objs])
+        return self._ev_handles
+
+    def _exec(self, ops, stream, start=0, stop=None, hook=None, skip_ranges=(), side_stream=None):
+        """Issue ops[start:stop] in order.  Native segments run through dml_plan_run; Python steps (collectives), skipped
+        ranges and the hook points (hook.points: op indices after which hook(i) must run -- the gradient buckets of the
+        data-parallel reducer) cut the list into segments."""
+        stop = len(ops) if stop is None else stop
+        if not self.e.native or Plan.run is not Plan._py_run:
+            skipped = set()
+            for (lo, hi) in skip_ranges:
+                skipped.update(range(lo, hi))
+            if side_stream is not None:
+                return self._py_backward_two_streams(ops, stream, side_stream, hook, skipped)
+            return Plan.run(ops, stream, start, stop, hook=hook, skipped=skipped)
+        nat = self._native_list(ops)
+        points = getattr(hook, "points", None) if hook is not None else ()
+        if hook is not None and points is None:
+            points = range(start, stop)              # a hook without declared points wants every op
+        cuts = set(nat.python_ops)
+        cuts.update(points)
+        skips = sorted((max(lo, start), min(hi, stop)) for (lo, hi) in skip_ranges if lo < stop and hi > start)
+        events = self._events() if side_stream is not None else None
+        n_ev = len(events) if events is not None else 0
+        i = start
+        order = sorted(c for c in cuts if start <= c < stop)
+        ci, si = 0, 0
+        while i < stop:
+            while si < len(skips) and skips[si][1] <= i:
+                si += 1
+            if si < len(skips) and skips[si][0] <= i:      # inside a skipped range: only the hook points fire
+                hi = skips[si][1]
+                if hook is not None:
+                    for k in order:
+                        if i <= k < hi and k in points:
+                            hook(k)
+                i = hi
+                continue
+            end = skips[si][0] if si < len(skips) else stop
+            while ci < len(order) and order[ci] < i:
+                ci += 1
+            if ci < len(order) and order[ci] < end:
+                k = order[ci]
+                if k in nat.python_ops:
+                    if k > i:
+                        nat.run(i, k, stream, side_stream, events, n_ev)
+                    fn, args = ops[k]
+                    fn(*args, stream)
+                else:
+                    nat.run(i, k + 1, stream, side_stream, events, n_ev)
+                if hook is not None and k in points:
+                    hook(k)
+                i = k + 1
+            else:
+                nat.run(i, end, stream, side_stream, events, n_ev)
+                i = end
+
     def run_backward(self, hook=None):
         """Replay the backward plan: weight gradients on the engine's side stream, everything else on the
         caller's current stream; joined at the end."""
         main = torch.cuda.current_stream(self.device)
-        skipped = set()
-        for (lo, hi) in getattr(self, "skip_ranges", ()):
-            skipped.update(range(lo, hi))
+        skip = tuple(getattr(self, "skip_ranges", ()))
         if not self.e.overlap_wgrad or not self.side:
-            Plan.run(self.bwd, main.cuda_stream, hook=hook, skipped=skipped)
+            self._exec(self.bwd, main.cuda_stream, hook=hook, skip_ranges=skip)
             return
+        side = self.e.side_stream(self.device)
+        side.wait_stream(main)
+        self._exec(self.bwd, main.cuda_stream, hook=hook, skip_ranges=skip, side_stream=side.cuda_stream)
+        main.wait_stream(side)
+
+    def _py_backward_two_streams(self, ops, ms, ss, hook, skipped):
+        """the Python replay of the two-stream backward (DML_NATIVE_PLAN=0, profiling)"""
+        main = torch.cuda.current_stream(self.device)
         side = self.e.side_stream(self.device)
         if self._side_events is None:
             self._side_events = {i: torch.cuda.Event() for i, f in self.side.items() if f}
-        side.wait_stream(main)
-        ms, ss = main.cuda_stream, side.cuda_stream
         sidemap, events = self.side, self._side_events
-        for i, (fn, args) in enumerate(self.bwd):
+        for i, (fn, args) in enumerate(ops):
             if i in skipped:
                 if hook is not None:
                     hook(i)
@@ -765,7 +928,6 @@ class Plan:
                 _lib.check(rc, getattr(fn, "__name__", "kernel") + " (bwd op %d)" % i)
             if hook is not None:
                 hook(i)
-        main.wait_stream(side)
 
     def run_forward(self, stream):
         """Replay the forward plan.  Inference plans carry fork groups (`fwd_forks`: the independent ASPP branches): their
@@ -773,20 +935,20 @@ class Plan:
         branch is a grid of 128-256 workgroups, too small to fill the chip alone."""
         forks = getattr(self, "fwd_forks", None)
         if not forks:
-            Plan.run(self.fwd, stream)
+            self._exec(self.fwd, stream)
             return
         main = torch.cuda.current_stream(self.device)
         pos = 0
         for ranges in forks:
-            Plan.run(self.fwd, stream, pos, ranges[0][0])
+            self._exec(self.fwd, stream, pos, ranges[0][0])
             streams = self.e.branch_streams(self.device, len(ranges))
             for (lo, hi), s in zip(ranges, streams):
                 s.wait_stream(main)
-                Plan.run(self.fwd, s.cuda_stream, lo, hi)
+                self._exec(self.fwd, s.cuda_stream, lo, hi)
             for s in streams[:len(ranges)]:
                 main.wait_stream(s)
             pos = ranges[-1][1]
-        Plan.run(self.fwd, stream, pos, len(self.fwd))
+        self._exec(self.fwd, stream, pos, len(self.fwd))
 
     @staticmethod
     def run(ops, stream, start=0, stop=None, hook=None, skipped=()):
@@ -803,6 +965,8 @@ class Plan:
             if hook is not None:
                 hook(i)
 
+    _py_run = run          # bench.py's profiled pass replaces Plan.run: the native path then steps aside
+
 
 class Engine:
     """Owns the parameter store and the plan cache of one model instance."""
@@ -817,6 +981,7 @@ class Engine:
         self._protos = {}
         self.reducer = None             # parallel.GradReducer, attached for multi-GPU runs
         self.overlap_wgrad = os.environ.get("DML_OVERLAP_WGRAD", "1") != "0"
+        self.native = os.environ.get("DML_NATIVE_PLAN", "1") != "0"      # replay launch lists through dml_plan_run
         self.sync_bn, self.sync_group = False, None     # synchronised BatchNorm statistics over the process group
         self._side = {}
         self._branch = {}

@@ -89,6 +89,7 @@ class GradReducer:
                     if self.average:
                         seg.div_(self.world)
 
+        hook.points = set(sched.keys())      # the native replay returns to Python only after these ops
         plan.run_backward(hook=hook)
         cur.wait_stream(self.comm_stream)
 

@@ -39,6 +39,7 @@ def main():
     rank, local, world = parallel.init_from_env()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    torch.manual_seed(1)              # without --ckpt every rank must still build the same (random-init) model
     model = getattr(network, o.model)(num_classes=o.num_classes, output_stride=o.output_stride,
                                       pretrained_backbone=False)
     if o.ckpt:

@@ -183,7 +183,7 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
     for u in plan.units:
         if u.res is not None:
             consumers[id(u.res.root)] += 1          # the identity branch adds its gradient to that buffer too
-    ULP = 2.0 ** -8                      # one bf16 ulp relative to the value (round to nearest: half of it)
+    ULP = 2.0 ** -8                      # round to nearest: the error is at most half an ulp = 2^-9 .. 2^-8 of the value
     worst = {}
 
     def note(kind, name, err, bar):
@@ -204,7 +204,7 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
         xr = x.clone().requires_grad_(consumers[id(u.x.root)] == 1 and u.x is u.x.root and u.x.root.grad is not None)
         y_ref = F.conv2d(xr, wq, None, conv.stride, conv.padding, conv.dilation)
         y = _nchw(_act(u.y), u.y.B, u.y.H, u.y.W)
-        note("conv fwd (stored y vs fp32 conv of the stored operands)", name, relmax(y, y_ref.detach()), 0.75 * ULP)
+        note("conv fwd (stored y vs fp32 conv of the stored operands)", name, relmax(y, y_ref.detach()), 1.05 * ULP)
         mean, var = y_ref.detach().mean((0, 2, 3)), y_ref.detach().var((0, 2, 3), unbiased=False)
         note("batch mean", name, (u.mean.cpu() - mean).abs().max().item() / (var.sqrt().max().item() + 1e-30), 1e-4)
         note("batch invstd", name, relmax(u.invstd.cpu(), torch.rsqrt(var + bn.eps)), 1e-4)
@@ -217,7 +217,7 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
         if u.relu:
             z_ref = z_ref.clamp_min(0)
         z = _nchw(_act(u.z), u.z.B, u.z.H, u.z.W)
-        note("bn apply (z)", name, relmax(z, z_ref), 0.75 * ULP)
+        note("bn apply (z)", name, relmax(z, z_ref), 1.05 * ULP)
         # ---- backward, from the stored dz / y / z
         dz = _nchw(_act(u.dz), u.z.B, u.z.H, u.z.W).double()
         g = dz * (z > 0) if u.relu else dz
@@ -234,7 +234,7 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
         note("weight gradient", name, relmax(conv.weight.grad.cpu(), wq.grad), 2e-3)
         if xr.requires_grad:
             gx = _nchw(_act(u.x.root.grad), u.x.B, u.x.H, u.x.W)[:, :cin]
-            note("data gradient", name, relmax(gx, xr.grad), 0.75 * ULP)
+            note("data gradient", name, relmax(gx, xr.grad), 1.05 * ULP)
     dsc_fused = sum(1 for fn, args in plan.bwd if fn is plan.lib.dml_conv_igemm and args[0]._obj.bnr_partials)
     print("units %d, data gradients with the fused BN-backward sums %d; worst: %s"
           % (len(plan.units), dsc_fused, "; ".join("%s %.2e (%s)" % (k, v[0], v[1]) for k, v in worst.items())))
@@ -271,10 +271,13 @@ def test_fp32_768_bs2_against_oracle():
           "checksum mismatches %d" % (e_lg, e_ft, e_loss, np.median(emax), np.percentile(emax, 95), emax.max(),
                                        names[int(np.argmax(emax))], len(cs_bad)))
     assert e_lg <= 1e-3 and e_ft <= 1e-3 and e_loss <= 1e-3
-    # the fp32 oracle itself sits a few 1e-3 from an fp64 evaluation on single tensors at this size (ReLU sign flips);
-    # a wiring / scaling error is O(1)
-    assert np.median(emax) <= 1e-3 and np.percentile(emax, 95) <= 5e-3 and emax.max() <= 5e-2
-    assert len(cs_bad) <= 3, cs_bad[:3]
+    # 1.2 M pixels per image pair: fp32 summation order alone moves single gradient entries by a few 1e-3 of the tensor's
+    # maximum (measured on MI355X: median 3.9e-3, p95 1.7e-2, max 6.5e-2 -- the fp32 oracle is as far from an fp64
+    # evaluation, test_gpu_model.py), while the checksums (sum, sum |.|, sum of squares of every tensor) agree to 5e-3:
+    # a wiring / scaling error is O(1) on both
+    assert np.median(emax) <= 1e-2 and np.percentile(emax, 95) <= 5e-2 and emax.max() <= 0.2
+    assert np.median(ecos) <= 1e-4 and ecos.max() <= 1e-2, (np.median(ecos), ecos.max())
+    assert not cs_bad, cs_bad[:3]
 
 
 def test_config2_forward_only_768_bs8_bf16():
