@@ -234,6 +234,15 @@ int dml_upsample_dist_fwd(const float* e, const float* protos, float* logits, fl
 int dml_proto_dist_bwd(const float* glogits, const float* gfeats, const float* feats,
                        const float* protos, float* df, int B, int C, int K, int H, int W, void* stream);
 
+/* Backward of DML loss + distance head + final x4 upsample in one pass, for a loss whose only input is this head's
+ * logits: de[B,h,w,C] (dtype) = bilinear^T( d loss / d features ), d loss / d logits exactly as dml_loss_bwd defines it
+ * (sums / gout / alpha / n_images / ignore_index as there) with the logits recomputed from feats[B,H,W,C].
+ * C = K = 16, H = 4h, W = 4w; anything else returns DML_EUNSUPPORTED (use dml_loss_bwd + dml_proto_dist_bwd +
+ * dml_bilinear_bwd).  72 B per full-resolution pixel instead of 394. */
+int dml_head_bwd_fused(const float* feats, const int64_t* labels, const double* sums, const float* gout,
+                       const float* protos, void* de, int B, int h, int w, int C, int K, int H, int W,
+                       int64_t ignore_index, float alpha, float n_images, int dtype, void* stream);
+
 /* preds = argmax_k logits (ties -> lowest k), msp = 1 - max softmax  (test_embedding.py:339-341) */
 int dml_argmax_msp(const float* logits, int64_t* preds, float* msp, int B, int K, int H, int W,
                    void* stream);
@@ -270,6 +279,10 @@ int dml_sgd_step(float* p, const float* g, float* v, int64_t n, float lr, float 
 
 /* fill / scale helpers used by the host runtime */
 int dml_fill_f32(float* p, int64_t n, float value, void* stream);
+/* dst[i] = (dst_dtype) src[i] -- the bf16 plans keep the ASPP image-pooling branch (network/utils.py:318-329: a
+ * BatchNorm over B x 256 x 1 x 1, i.e. over only B samples) in fp32 storage: with two near-equal samples a bf16-rounded
+ * pre-normalisation value makes that layer's gradient blow up by up to 1/sqrt(eps). */
+int dml_convert_dtype(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Input pipeline on the device (the step before the path): the Cityscapes train

@@ -742,6 +742,175 @@ __global__ __launch_bounds__(256) void loss_bwd_kernel(const float* __restrict__
     }
 }
 
+
+// ---- fused backward of loss + distance head + final x4 upsample (C = K = 16, H = 4h, W = 4w).
+// The unfused chain moves 394 B per full-resolution pixel (loss_bwd writes d loss / d logits, proto_dist_bwd reads it and
+// writes d loss / d features, bilinear_bwd reads that); none of the two intermediates is needed by anyone else.  Here a
+// workgroup owns a TJ x TI tile of the LOW-resolution embedding gradient.  Phase 1: for the (4 TJ + 4) x (4 TI + 8)
+// full-resolution pixels that reach the tile, one work item = 4 consecutive pixels of a row: features (64 B) and label in,
+// logits recomputed (-|f - m_k|^2, same arithmetic as the forward), softmax, d loss / d logits, d loss / d features, and
+// the row's bilinear weights folded at once into three low-resolution column partials (left neighbour, own, right
+// neighbour) that go to an LDS row buffer in three conflict-free sub-phases (deterministic: no atomics).  Phase 2: each
+// thread gathers the <= 8 rows that reach its low-resolution pixel for 8 channels and writes 16 bytes.
+// Traffic: 72 B per pixel (+ halo re-reads that hit in L2) + the low-resolution result.
+constexpr int HB_TJ = 7, HB_TI = 14;                 // tile of the low-resolution map per workgroup
+constexpr int HB_ROWS = 4 * HB_TJ + 4;               // 32 full-resolution rows reach it
+constexpr int HB_GRPS = HB_TI + 2;                   // 16 groups of 4 pixels per row (one halo group each side)
+
+template <typename TO>
+__global__ __launch_bounds__(256) void head_bwd_fused_c16_kernel(
+    const float* __restrict__ feats, const int64_t* __restrict__ labels, const double* __restrict__ sums,
+    const float* __restrict__ gout, const float* __restrict__ protos, TO* __restrict__ de, int B, int h, int w,
+    int64_t ignore_index, float alpha, float n_images_arg) {
+    constexpr int C = 16, K = 16;
+    __shared__ __attribute__((aligned(16))) float t[HB_ROWS][HB_GRPS][C];      // 32 KB: x-reduced rows
+    __shared__ float sp[K * C];
+    const int tid = threadIdx.x;
+    const int H = 4 * h, W = 4 * w;
+    const int tiles_x = (w + HB_TI - 1) / HB_TI, tiles_y = (h + HB_TJ - 1) / HB_TJ;
+    int bid = blockIdx.x;
+    const int tx = bid % tiles_x;
+    bid /= tiles_x;
+    const int ty = bid % tiles_y, b = bid / tiles_y;
+    const int j0 = ty * HB_TJ, i0 = tx * HB_TI;
+    const int Y0 = 4 * j0 - 2;                         // first full-resolution row of the region
+    const int q0 = i0 - 1;                             // first pixel group of the region
+    if (tid < K * C) sp[tid] = protos[tid];
+    const float go = gout ? *gout : 1.f;
+    const float n_images = n_images_arg > 0.f ? n_images_arg : (float)sums[4];
+    const float w_ce = go / ((float)sums[1] * n_images);
+    const float w_var = go * alpha / ((float)((int64_t)H * W) * n_images);
+    __syncthreads();
+
+    float part[2][3][C];                               // this thread's two work items: (left, own, right) column partials
+    int prow[2], pq[2];
+#pragma unroll
+    for (int it = 0; it < 2; ++it) {
+        const int id = it * 256 + tid;
+        const int r = id / HB_GRPS, g = id - r * HB_GRPS;
+        const int Y = Y0 + r, q = q0 + g;
+        prow[it] = r;
+        pq[it] = g;
+#pragma unroll
+        for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+            for (int c = 0; c < C; ++c) part[it][s3][c] = 0.f;
+        if (Y < 0 || Y >= H || q < 0 || q >= w) continue;
+        // halo groups only reach the tile through their inner two pixels
+        const int p_lo = (g == 0) ? 2 : 0, p_hi = (g == HB_GRPS - 1) ? 2 : 4;
+        const float* frow = feats + (((int64_t)b * H + Y) * W + 4 * q) * C;
+        const int64_t* lrow = labels + ((int64_t)b * H + Y) * W + 4 * q;
+        for (int p = p_lo; p < p_hi; ++p) {
+            float f[C];
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                const float4 v = *reinterpret_cast<const float4*>(frow + p * C + c);
+                f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
+            }
+            const int64_t lab = lrow[p];
+            float lg[K];
+            float mx = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float d = 0.f;
+#pragma unroll
+                for (int c = 0; c < C; ++c) {
+                    const float u = f[c] - sp[k * C + c];
+                    d += u * u;
+                }
+                lg[k] = -d;
+                mx = fmaxf(mx, lg[k]);
+            }
+            float den = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                lg[k] = expf(lg[k] - mx);
+                den += lg[k];
+            }
+            const bool valid = lab != ignore_index;
+            const float inv = valid ? w_ce / den : 0.f;
+            // d loss / d features = -2 sum_k g_k (f - m_k) = -2 (f sum_k g_k - sum_k g_k m_k)
+            float gs = 0.f, gm[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) gm[c] = 0.f;
+#pragma unroll
+            for (int k = 0; k < K; ++k) {
+                float gk = lg[k] * inv;
+                if (valid && (int64_t)k == lab) gk -= w_ce + w_var;
+                gs += gk;
+#pragma unroll
+                for (int c = 0; c < C; ++c) gm[c] += gk * sp[k * C + c];
+            }
+            // bilinear weights of full-resolution column X = 4 q + p (align_corners = False, scale 1/4)
+            const int X = 4 * q + p;
+            float sX = 0.25f * ((float)X + 0.5f) - 0.5f;
+            sX = sX < 0.f ? 0.f : sX;
+            const int x0 = min((int)sX, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+            const float l1 = sX - (float)x0, l0 = 1.f - l1;
+            const int s0 = x0 - (q - 1), s1 = x1 - (q - 1);          // slots 0 / 1 / 2 = columns q-1 / q / q+1
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const float dfc = -2.f * (gs * f[c] - gm[c]);
+#pragma unroll
+                for (int s3 = 0; s3 < 3; ++s3)
+                    part[it][s3][c] += (s3 == s0 ? l0 * dfc : 0.f) + (s3 == s1 ? l1 * dfc : 0.f);
+            }
+        }
+    }
+    // three sub-phases: every (row, column) cell of t is written by exactly one thread in each of them
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+#pragma unroll
+        for (int c = 0; c < C; c += 4)
+            *reinterpret_cast<float4*>(&t[prow[it]][pq[it]][c]) =
+                make_float4(part[it][1][c], part[it][1][c + 1], part[it][1][c + 2], part[it][1][c + 3]);
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+        if (pq[it] + 1 < HB_GRPS)
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[prow[it]][pq[it] + 1][c] += part[it][2][c];
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < 2; ++it)
+        if (pq[it] >= 1)
+#pragma unroll
+            for (int c = 0; c < C; ++c) t[prow[it]][pq[it] - 1][c] += part[it][0][c];
+    __syncthreads();
+
+    // phase 2: low-resolution pixel (j, i) x 8 channels per thread (98 pixels x 2 halves = 196 threads)
+    const int px = tid >> 1, half = tid & 1;
+    if (px >= HB_TJ * HB_TI) return;
+    const int jj = px / HB_TI, ii = px - jj * HB_TI;
+    const int j = j0 + jj, i = i0 + ii;
+    if (j >= h || i >= w) return;
+    float acc[8];
+#pragma unroll
+    for (int c = 0; c < 8; ++c) acc[c] = 0.f;
+    for (int dy = 0; dy < 8; ++dy) {
+        const int Y = 4 * j - 2 + dy;
+        if (Y < 0 || Y >= H) continue;
+        float sY = 0.25f * ((float)Y + 0.5f) - 0.5f;
+        sY = sY < 0.f ? 0.f : sY;
+        const int y0 = min((int)sY, h - 1), y1 = y0 + (y0 < h - 1 ? 1 : 0);
+        const float l1 = sY - (float)y0;
+        const float wy = (y0 == j ? 1.f - l1 : 0.f) + (y1 == j ? l1 : 0.f);
+        if (wy == 0.f) continue;
+        const float* src = &t[Y - Y0][ii + 1][half * 8];
+        const float4 a = *reinterpret_cast<const float4*>(src), c4 = *reinterpret_cast<const float4*>(src + 4);
+        acc[0] += wy * a.x; acc[1] += wy * a.y; acc[2] += wy * a.z; acc[3] += wy * a.w;
+        acc[4] += wy * c4.x; acc[5] += wy * c4.y; acc[6] += wy * c4.z; acc[7] += wy * c4.w;
+    }
+    TO* dst = de + (((int64_t)b * h + j) * w + i) * C + half * 8;
+    if constexpr (sizeof(TO) == 2) {
+        *reinterpret_cast<uint4*>(dst) = make_uint4(pack_bf16x2(acc[0], acc[1]), pack_bf16x2(acc[2], acc[3]),
+                                                    pack_bf16x2(acc[4], acc[5]), pack_bf16x2(acc[6], acc[7]));
+    } else {
+        *reinterpret_cast<float4*>(dst) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        *reinterpret_cast<float4*>(dst + 4) = make_float4(acc[4], acc[5], acc[6], acc[7]);
+    }
+}
+
 }  // namespace
 
 extern "C" int dml_proto_dist_fwd(const float* x_nchw, const float* protos, float* logits, float* feats,
@@ -824,6 +993,25 @@ extern "C" int dml_proto_dist_bwd(const float* glogits, const float* gfeats, con
         else hipLaunchKernelGGL((proto_dist_bwd_kernel<1, 32>), dim3(grid), dim3(256), 0, st, glogits, gfeats, feats, protos,
                            df, B, C, K, HW);
     }
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_head_bwd_fused(const float* feats, const int64_t* labels, const double* sums, const float* gout,
+                                  const float* protos, void* de, int B, int h, int w, int C, int K, int H, int W,
+                                  int64_t ignore_index, float alpha, float n_images, int dtype, void* stream) {
+    if (!feats || !labels || !sums || !protos || !de || B <= 0 || h <= 0 || w <= 0) return DML_EINVAL;
+    if (dtype != DML_F32 && dtype != DML_BF16) return DML_EINVAL;
+    if (C != 16 || K != 16 || H != 4 * h || W != 4 * w) return DML_EUNSUPPORTED;
+    const int tiles = ((w + HB_TI - 1) / HB_TI) * ((h + HB_TJ - 1) / HB_TJ);
+    if ((int64_t)tiles * B >= (1ll << 31)) return DML_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_BF16)
+        hipLaunchKernelGGL(head_bwd_fused_c16_kernel<bf16_t>, dim3(tiles * B), dim3(256), 0, st, feats, labels, sums, gout,
+                           protos, static_cast<bf16_t*>(de), B, h, w, ignore_index, alpha, n_images);
+    else
+        hipLaunchKernelGGL(head_bwd_fused_c16_kernel<float>, dim3(tiles * B), dim3(256), 0, st, feats, labels, sums, gout,
+                           protos, static_cast<float*>(de), B, h, w, ignore_index, alpha, n_images);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -41,6 +41,12 @@ __global__ __launch_bounds__(256) void fill_kernel(float* __restrict__ p, int64_
         p[i] = value;
 }
 
+template <typename TS, typename TD>
+__global__ __launch_bounds__(256) void convert_kernel(const TS* __restrict__ src, TD* __restrict__ dst, int64_t n) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        Elem<TD>::st(dst + i, Elem<TS>::ld(src + i));
+}
+
 // master [N][RS][Cm] fp32 -> w [N][RS][Cp] and wt [Cp][RS][N]
 template <typename T>
 __global__ __launch_bounds__(256) void prep_weight_kernel(const float* __restrict__ src, T* __restrict__ w,
@@ -187,6 +193,23 @@ extern "C" int dml_fill_f32(float* p, int64_t n, float value, void* stream) {
     if (!p || n <= 0) return DML_EINVAL;
     hipLaunchKernelGGL(fill_kernel, dim3(grid_for(n, 256)), dim3(256), 0, static_cast<hipStream_t>(stream), p, n,
                        value);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_convert_dtype(const void* src, void* dst, int64_t n, int src_dtype, int dst_dtype, void* stream) {
+    if (!src || !dst || n <= 0) return DML_EINVAL;
+    if ((src_dtype != DML_F32 && src_dtype != DML_BF16) || (dst_dtype != DML_F32 && dst_dtype != DML_BF16)) return DML_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const dim3 grid(grid_for(n, 256)), blk(256);
+    if (src_dtype == DML_F32 && dst_dtype == DML_BF16)
+        hipLaunchKernelGGL((convert_kernel<float, bf16_t>), grid, blk, 0, st, (const float*)src, (bf16_t*)dst, n);
+    else if (src_dtype == DML_BF16 && dst_dtype == DML_F32)
+        hipLaunchKernelGGL((convert_kernel<bf16_t, float>), grid, blk, 0, st, (const bf16_t*)src, (float*)dst, n);
+    else if (src_dtype == DML_F32)
+        hipLaunchKernelGGL((convert_kernel<float, float>), grid, blk, 0, st, (const float*)src, (float*)dst, n);
+    else
+        hipLaunchKernelGGL((convert_kernel<bf16_t, bf16_t>), grid, blk, 0, st, (const bf16_t*)src, (bf16_t*)dst, n);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -86,6 +86,7 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_proto_dist_fwd),
     DML_ENTRY(dml_upsample_dist_fwd),
     DML_ENTRY(dml_proto_dist_bwd),
+    DML_ENTRY(dml_head_bwd_fused),
     DML_ENTRY(dml_argmax_msp),
     DML_ENTRY(dml_dissum_score),
     DML_ENTRY(dml_novel_relabel),
@@ -94,6 +95,7 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_loss_bwd),
     DML_ENTRY(dml_sgd_step),
     DML_ENTRY(dml_fill_f32),
+    DML_ENTRY(dml_convert_dtype),
     DML_ENTRY(dml_adaptive_avgpool_fwd),
     DML_ENTRY(dml_proto_dist_nhwc),
     DML_ENTRY(dml_upsample_nhwc_to_nchw),

@@ -105,6 +105,7 @@ _PROTOS = {
     "dml_proto_dist_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_upsample_dist_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_proto_dist_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_head_bwd_fused": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i64, c_f, c_f, c_i, c_p]),
     "dml_argmax_msp": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dml_dissum_score": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
     "dml_novel_relabel": (c_i, [c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_i64, c_p]),
@@ -113,6 +114,7 @@ _PROTOS = {
     "dml_loss_bwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i64, c_f, c_f, c_p]),
     "dml_sgd_step": (c_i, [c_p, c_p, c_p, c_i64, c_f, c_f, c_f, c_f, c_p]),
     "dml_fill_f32": (c_i, [c_p, c_i64, c_f, c_p]),
+    "dml_convert_dtype": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_p]),
     "dml_confusion_update": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_p]),
     "dml_class_feature_sum": (c_i, [c_p, c_p, c_i64, c_i, c_i64, c_p, c_p, c_p]),
     "dml_ood_workspace_bytes": (c_i64, [c_i64]),

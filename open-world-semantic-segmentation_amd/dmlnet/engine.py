@@ -23,7 +23,7 @@ import torch
 import torch.distributed as dist
 import torch.nn as nn
 
-from . import _lib
+from . import _lib, lazy_grad
 from ._lib import DML_BF16, DML_F32, STAT_ROWS, ConvDesc, WgradDesc
 
 _PAD_CIN = 8          # stem input channels 3 -> 8 so that a 16-byte vector never straddles a filter tap
@@ -285,7 +285,7 @@ class HeadRec:
 
 class ConvUnit:
     __slots__ = ("conv", "bn", "x", "y", "z", "relu", "res", "w", "wt", "scale", "shift", "mean", "invstd",
-                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy", "mask", "frozen")
+                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy", "mask", "frozen", "dtype")
 
 
 class Plan:
@@ -327,6 +327,27 @@ class Plan:
         self.wgrad_ws = torch.empty(40 * (1 << 20) if training else 1, dtype=torch.float32, device=self.device)
         self.build()
         self.bytes = sum(t.numel() * t.element_size() for t in self.keep if isinstance(t, torch.Tensor))
+
+    # ---- a unit may keep its tensors in fp32 inside a bf16 plan (the ASPP image-pooling branch, see _head_fwd)
+    class _Precision:
+        def __init__(self, plan, dtype):
+            self.plan, self.dtype = plan, dtype
+
+        def __enter__(self):
+            p = self.plan
+            self.saved = (p.dtype, p.dt, p.es, p.vec)
+            p.dtype, p.dt = self.dtype, _dt(self.dtype)
+            p.es = 2 if self.dtype == torch.bfloat16 else 4
+            p.vec = 16 // p.es
+            return p
+
+        def __exit__(self, *exc):
+            p = self.plan
+            p.dtype, p.dt, p.es, p.vec = self.saved
+            return False
+
+    def precision(self, dtype):
+        return Plan._Precision(self, dtype)
 
     # ---- allocation helpers
     def new(self, B, H, W, C, f32=False, ld=None, zero=False) -> Act:
@@ -387,7 +408,7 @@ class Plan:
         wt = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device) if need_wt else None
         self.keep += [w, wt]
         self.prep.append((src_ptr or conv.weight.data_ptr(), w.data_ptr(), wt.data_ptr() if wt is not None else 0, N,
-                          kh * kw, Cm, Cp))
+                          kh * kw, Cm, Cp, self.dt))
         return w, wt
 
     def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None, post=None, N=None):
@@ -455,6 +476,7 @@ class Plan:
         lib, st = self.lib, self.e.store
         u = ConvUnit()
         u.conv, u.bn, u.x, u.relu, u.res, u.drop = conv, bn, x, relu, res, drop
+        u.dtype = self.dtype
         u.Cp = x.C                       # x already carries any channel padding
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         N = conv.out_channels
@@ -525,6 +547,9 @@ class Plan:
 
     def unit_bwd(self, u: ConvUnit, dz: Act, dres: Optional[Act] = None, dres_accum=False, need_dgrad=True):
         """Backward of `cbr`: BN (two passes) -> weight gradient -> data gradient into u.x.grad."""
+        if u.dtype != self.dtype:
+            with self.precision(u.dtype):
+                return self.unit_bwd(u, dz, dres, dres_accum, need_dgrad)
         lib, st = self.lib, self.e.store
         N, M = u.conv.out_channels, u.y.M
         bn = u.bn
@@ -703,8 +728,24 @@ class Plan:
         # image-pooling branch (network/utils.py:318-329): avg-pool -> 1x1 -> BN -> ReLU -> broadcast
         pooled = self.new(B, 1, 1, out.C)
         self.call(self.fwd, lib.dml_global_avgpool_fwd, out.ptr, pooled.ptr, B, out.H * out.W, out.C, out.ld, self.dt)
-        upool = self.cbr(pooled, aspp.convs[4][1], aspp.convs[4][2])
-        self.call(self.fwd, lib.dml_broadcast_hw, upool.z.ptr, cat1.slice(1024, 256).ptr, B, out.H * out.W, 256,
+        if self.training and self.dtype == torch.bfloat16:
+            # This BatchNorm sees B samples per channel.  When two of them are within bf16 resolution of each other the
+            # rounded pre-normalisation values collapse, 1/sigma goes to 1/sqrt(eps) and the layer's backward -- whose two
+            # correction terms cancel its output gradient almost exactly -- returns a spurious gradient hundreds of times
+            # too large that the broadcast spreads over every pixel of d(out) (measured at 768 x 768, 2 images: layer4's
+            # bn3 gradients 20x their true norm).  The unit is B x 256 values: it runs in fp32 storage, with tiny
+            # conversions at its three bf16 boundaries.
+            with self.precision(torch.float32):
+                pooled32 = self.new(B, 1, 1, out.C)
+                self.call(self.fwd, lib.dml_convert_dtype, pooled.ptr, pooled32.ptr, B * out.C, DML_BF16, DML_F32)
+                upool = self.cbr(pooled32, aspp.convs[4][1], aspp.convs[4][2])
+            zq = self.new(B, 1, 1, 256)
+            self.call(self.fwd, lib.dml_convert_dtype, upool.z.ptr, zq.ptr, B * 256, DML_F32, DML_BF16)
+            pool_z, pooled_in = zq, pooled32
+        else:
+            upool = self.cbr(pooled, aspp.convs[4][1], aspp.convs[4][2])
+            pool_z, pooled_in = upool.z, pooled
+        self.call(self.fwd, lib.dml_broadcast_hw, pool_z.ptr, cat1.slice(1024, 256).ptr, B, out.H * out.W, 256,
                   cat1.ld, self.dt)
         marks.append(len(self.fwd))
         if not self.training and self.fork_branches and (out.M + 127) // 128 * 2 < 300:
@@ -747,6 +788,7 @@ class Plan:
         rec = HeadRec()
         rec.K, rec.Kp, rec.emb, rec.protos, rec.head_args = K, Kp, emb, protos, head_args
         rec.cat1, rec.cat2, rec.up_low, rec.branches, rec.pooled, rec.upool = cat1, cat2, up_low, branches, pooled, upool
+        rec.pooled_in = pooled_in
         rec.uproj, rec.ucls, rec.fin, rec.wt_fin = uproj, ucls, fin, wt_fin
         rec.head_bwd_args, rec.df, rec.feats_p = None, None, None
         return rec
@@ -759,10 +801,22 @@ class Plan:
         uproj, ucls = rec.uproj, rec.ucls
         df = self.fbuf(B * H * W * Kp)
         rec.df = df
+        de = self.new(B, emb.H, emb.W, Kp)
+        # Two ways from d(loss)/d(logits) to the low-resolution embedding gradient `de`; Engine.backward skips one.
+        # (1) the loss handed over a deferred gradient (dmlnet/lazy_grad.py) and the shape is the fused kernel's (16
+        #     prototypes, exact x4 upsample): loss gradient + distance gradient + transposed upsample in one pass;
+        # (2) anything else: distance gradient into `df`, then the transposed upsample.
+        rec.fused_args, rec.fused_range = None, None
+        if Kp == 16 and K == 16 and H == 4 * emb.H and W == 4 * emb.W:
+            i0 = len(self.bwd)
+            rec.fused_args = self.call(self.bwd, lib.dml_head_bwd_fused, 0, 0, 0, 0, rec.protos.data_ptr(), de.ptr, B,
+                                       emb.H, emb.W, Kp, K, H, W, 255, 0.0, 1.0, self.dt)
+            rec.fused_range = (i0, i0 + 1)
+        i1 = len(self.bwd)
         rec.head_bwd_args = self.call(self.bwd, lib.dml_proto_dist_bwd, 0, None, 0, rec.protos.data_ptr(),
                                        df.data_ptr(), B, Kp, K, H, W)
-        de = self.new(B, emb.H, emb.W, Kp)
         self.call(self.bwd, lib.dml_bilinear_bwd, df.data_ptr(), de.ptr, B, emb.H, emb.W, H, W, Kp, Kp, Kp, self.dt, 1, 0)
+        rec.unfused_range = (i1, i1 + 2)
         if fin.bias is not None:
             if Kp == K:
                 self.call(self.bwd, lib.dml_bias_grad, de.ptr, st.grad_ptr_of(fin.bias), de.M, K, de.ld, self.dt)
@@ -787,7 +841,16 @@ class Plan:
         dzp = self.new(B, 1, 1, 256)
         self.call(self.bwd, lib.dml_reduce_hw, dcat1.slice(1024, 256).ptr, dzp.ptr, B, out.H * out.W, 256, dcat1.ld,
                   self.dt)
-        self.unit_bwd(upool, dzp)                                        # -> d pooled
+        if rec.pooled_in is not pooled:                                  # the unit lives in fp32 storage (_head_fwd)
+            with self.precision(torch.float32):
+                dzp32 = self.new(B, 1, 1, 256)
+                self.call(self.bwd, lib.dml_convert_dtype, dzp.ptr, dzp32.ptr, B * 256, DML_BF16, DML_F32)
+                self.unit_bwd(upool, dzp32)                              # -> d pooled (fp32)
+                g32 = self.grad_of(rec.pooled_in)
+            self.call(self.bwd, lib.dml_convert_dtype, g32.ptr, self.grad_of(pooled).ptr, B * out.C, DML_F32, DML_BF16)
+            pooled.root.grad_init = True
+        else:
+            self.unit_bwd(upool, dzp)                                    # -> d pooled
         feeders = self.to_backbone_ops                 # backward ops whose only product is d(out) / d(low)
         for i in range(4):
             self.unit_bwd(branches[i], dcat1.slice(256 * i, 256))       # -> d out (accumulating)
@@ -809,13 +872,16 @@ class Plan:
         for fn in self.pre_prep:
             fn()
         if self.prep_table is None:
-            arr = (_lib.PrepDesc * len(self.prep))()
-            for i, (src, w, wt, N, RS, Cm, Cp) in enumerate(self.prep):
-                arr[i] = _lib.PrepDesc(src, w, wt or None, N, RS, Cm, Cp)
-            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-            self.prep_table = raw.to(self.device)
-        _lib.check(self.lib.dml_prep_weights(self.prep_table.data_ptr(), len(self.prep), self.dt, stream),
-                   "dml_prep_weights")
+            self.prep_table = []
+            for dt in sorted({e[7] for e in self.prep}):          # one table launch per storage type present in the plan
+                ent = [e for e in self.prep if e[7] == dt]
+                arr = (_lib.PrepDesc * len(ent))()
+                for i, (src, w, wt, N, RS, Cm, Cp, _) in enumerate(ent):
+                    arr[i] = _lib.PrepDesc(src, w, wt or None, N, RS, Cm, Cp)
+                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                self.prep_table.append((raw.to(self.device), len(ent), dt))
+        for tab, n, dt in self.prep_table:
+            _lib.check(self.lib.dml_prep_weights(tab.data_ptr(), n, dt, stream), "dml_prep_weights")
         self.prepped_version = key
 
     # ---- replay: one C call per contiguous run of ops (dml_plan_run) unless the engine is told to stay in Python
@@ -1073,6 +1139,7 @@ class Engine:
             lg = torch.empty((B, rec.K, H, W), dtype=torch.float32, device=x.device)
             ft = torch.empty((B, H, W, rec.Kp), dtype=torch.float32, device=x.device)
             rec.feats_p = ft                 # the kernels' (channel-padded) features; the backward reads them again
+            rec.logits_ref = lg
             rec.head_args[2], rec.head_args[3] = lg.data_ptr(), ft.data_ptr()
             logits.append(lg)
             feats.append(ft)
@@ -1111,6 +1178,28 @@ class Engine:
             if gl is None and gf is None and hi != last:
                 skip.append(plan.head_bwd_range[hi])         # accumulating segment: nothing to add
                 continue
+            lazy = lazy_grad.take(gl)
+            if lazy is not None and rec.fused_args is not None and gf is None:
+                # deferred loss gradient + a shape the fused kernel covers: one pass, no d(loss)/d(logits) tensor
+                a = rec.fused_args
+                a[0], a[1], a[2], a[3] = rec.feats_p.data_ptr(), lazy.labels.data_ptr(), lazy.sums.data_ptr(), lazy.gout.data_ptr()
+                a[13], a[14], a[15] = int(lazy.ignore_index), float(lazy.alpha), float(lazy.n_images)
+                skip.append(rec.unfused_range)
+                keep += [lazy]
+                continue
+            if lazy is not None:                             # deferred, but not fusable here: materialise it
+                gl = torch.empty((plan.B, rec.K, plan.H, plan.W), dtype=torch.float32, device=dev)
+                _lib.check(self.lib.dml_loss_bwd(lazy.logits.data_ptr(), lazy.labels.data_ptr(), lazy.sums.data_ptr(),
+                                                 lazy.gout.data_ptr(), gl.data_ptr(), plan.B, rec.K, plan.H, plan.W,
+                                                 int(lazy.ignore_index), float(lazy.alpha), float(lazy.n_images), stream),
+                           "dml_loss_bwd")
+            elif gl is not None and lazy_grad.outstanding_for(getattr(rec, "logits_ref", None)):
+                lazy_grad.drop_for(rec.logits_ref)
+                raise RuntimeError("the loss was built with fused_backward=True but the logits have another consumer: its "
+                                   "gradient was added to the deferred-gradient marker.  Construct the loss with "
+                                   "fused_backward=False")
+            if rec.fused_range is not None:
+                skip.append(rec.fused_range)
             if gl is None:
                 gl = torch.zeros((plan.B, rec.K, plan.H, plan.W), dtype=torch.float32, device=dev)
             gl = gl.contiguous()

@@ -90,9 +90,12 @@ def main():
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=opts.step_size, gamma=0.1)
     sync = True if world > 1 else None
     if opts.loss_type == "dml":
-        criterion = utils.DMLLoss(alpha=opts.alpha, ignore_index=255, sync=sync)
+        criterion = utils.DMLLoss(alpha=opts.alpha, ignore_index=255, sync=sync, fused_backward=True)
     else:
-        criterion = utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0, sync=sync)   # :401
+        criterion = utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0, sync=sync,
+                                           fused_backward=True)                                   # :401
+    # fused_backward: the loss below is the only consumer of `outputs` (:466-470), so d(loss)/d(logits) is never
+    # materialised -- the head's backward computes it on the fly (dmlnet/lazy_grad.py)
 
     cur_itrs, best_score = 0, 0.0
     if opts.ckpt and os.path.isfile(opts.ckpt):                                    # :421-434

@@ -20,7 +20,7 @@ def _stream(t):
 
 class _DMLLossFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, logit, target, alpha, ignore_index, group):
+    def forward(ctx, logit, target, alpha, ignore_index, group, fused=False):
         if not logit.is_cuda:
             raise RuntimeError("the DML loss runs on the HIP path only (no CPU fallback)")
         lib = _lib.load()
@@ -47,13 +47,18 @@ class _DMLLossFn(torch.autograd.Function):
         _lib.check(lib.dml_loss_finalize(sums.data_ptr(), loss.data_ptr(), float(alpha), n_images, st),
                    "dml_loss_finalize")
         ctx.save_for_backward(logit, target, sums)
-        ctx.cfg = (float(alpha), int(ignore_index), n_images)
+        ctx.cfg = (float(alpha), int(ignore_index), n_images, bool(fused))
         return loss
 
     @staticmethod
     def backward(ctx, gout):
         logit, target, sums = ctx.saved_tensors
-        alpha, ignore_index, n_images = ctx.cfg
+        alpha, ignore_index, n_images, fused = ctx.cfg
+        if fused:
+            # no gradient tensor: a marker the model's backward resolves in its fused head kernel (dmlnet/lazy_grad.py)
+            from dmlnet import lazy_grad
+            return lazy_grad.issue(logit, target, sums, gout.contiguous().float(), alpha, ignore_index, n_images), \
+                None, None, None, None, None
         lib = _lib.load()
         B, K, H, W = logit.shape
         g = torch.empty_like(logit)
@@ -61,7 +66,7 @@ class _DMLLossFn(torch.autograd.Function):
         _lib.check(lib.dml_loss_bwd(logit.data_ptr(), target.data_ptr(), sums.data_ptr(), gout.data_ptr(),
                                     g.data_ptr(), B, K, H, W, ignore_index, alpha, n_images, _stream(logit)),
                    "dml_loss_bwd")
-        return g, None, None, None, None
+        return g, None, None, None, None, None
 
 
 class DMLLoss(nn.Module):
@@ -70,21 +75,25 @@ class DMLLoss(nn.Module):
     `sync` (True or a process group): sums are all-reduced so that every rank sees the loss of the global
     batch -- the value nn.DataParallel's gather gives the reference (main_embedding.py:466-467)."""
 
-    def __init__(self, alpha=0.01, ignore_index=-1, sync=None):
+    def __init__(self, alpha=0.01, ignore_index=-1, sync=None, fused_backward=False):
         super().__init__()
         self.alpha, self.ignore_index, self.sync = alpha, ignore_index, sync
+        # True: d(loss)/d(logits) is not materialised; valid when this loss is the only consumer of `logit`, as in the
+        # reference's drivers (dmlnet/lazy_grad.py)
+        self.fused_backward = fused_backward
 
     def forward(self, logit, target, features_in=None):
-        return _DMLLossFn.apply(logit, target, self.alpha, self.ignore_index, self.sync)
+        return _DMLLossFn.apply(logit, target, self.alpha, self.ignore_index, self.sync, self.fused_backward)
 
 
 class CrossEntropyLoss(nn.Module):
-    def __init__(self, alpha=0, beta=0, gamma=0, size_average=True, ignore_index=255, sync=None):
+    def __init__(self, alpha=0, beta=0, gamma=0, size_average=True, ignore_index=255, sync=None, fused_backward=False):
         super().__init__()
         self.alpha, self.beta, self.gamma = alpha, beta, gamma
         self.ignore_index, self.size_average, self.sync = ignore_index, size_average, sync
+        self.fused_backward = fused_backward
         if not size_average:
             raise NotImplementedError("size_average=False is never used by the embedding drivers")
 
     def forward(self, logit, target, features_in=None):
-        return _DMLLossFn.apply(logit, target, 0.0, self.ignore_index, self.sync)
+        return _DMLLossFn.apply(logit, target, 0.0, self.ignore_index, self.sync, self.fused_backward)

@@ -15,6 +15,7 @@ round-to-nearest-even bf16 quantisation is inserted at every point where the HIP
   BN + residual + ReLU result z                      q      dz                                             q
   bottleneck output (residual operand of the next)   q      (same tensor)
   ASPP output before / after the x4 bilinear         q      both gradients                                 q
+  ASPP image-pooling branch (BN over B samples):     fp32 storage inside the unit (bf16 in / out), training plans
   embedding (final 1x1 conv + bias): fp32            -      its gradient (bilinear_bwd result)             q
   upsample + distances + loss: fp32                  -      fp32
 
@@ -108,6 +109,10 @@ def _bn_forward(self, y32):
     return (yq - mean.view(sh)) * (self.weight * inv).view(sh) + self.bias.view(sh)
 
 
+def _conv_forward_f32_weights(self, x):
+    return F.conv2d(_QBoth.apply(x), self.weight, self.bias, self.stride, self.padding, self.dilation, self.groups)
+
+
 def emulate_bf16_storage(model: nn.Module) -> nn.Module:
     """Patch an oracle model instance (DeepLabV3PlusEmbeddingRef) in place; returns it."""
     for mod in model.modules():
@@ -121,4 +126,12 @@ def emulate_bf16_storage(model: nn.Module) -> nn.Module:
         elif isinstance(mod, O._Head):
             # the embedding stays fp32 (y_f32), the gradient that bilinear_bwd hands back is bf16
             mod.register_forward_hook(lambda m, inp, out: _QGrad.apply(out))
+    for mod in model.modules():
+        if isinstance(mod, O._ASPP) and mod.training:
+            # the image-pooling branch (AdaptiveAvgPool2d -> 1x1 conv -> BN over only B samples -> ReLU) is kept in fp32
+            # storage by the bf16 TRAINING plans (engine.py, _head_fwd): bf16 pooled input, fp32 weights, no rounding of
+            # y / dy inside the unit
+            pool = mod.convs[4]
+            pool[1].forward = types.MethodType(_conv_forward_f32_weights, pool[1])
+            pool[2].__dict__.pop("forward", None)
     return model

@@ -524,3 +524,46 @@ def test_incremental_head_recipe_skips_the_trunk_backward():
             assert float(st.flat_g[:st.split].abs().max()) > 0.0
     for k in grads[True]:      # same kernels on the same inputs; split-K partial sums may be folded in another order
         relclose(grads[True][k], grads[False][k], 1e-5, k)
+
+
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16])
+def test_deferred_loss_gradient_equals_materialised(dtype):
+    """utils.DMLLoss(fused_backward=True): the loss hands the model a marker instead of a gradient tensor and the head's
+    backward runs as one kernel; every parameter gradient must equal the materialised path's.  Also the guard: a second
+    consumer of the logits makes the backward raise instead of using a poisoned gradient."""
+    import utils
+    img = H.synth_tensor(61, "lazy.img", (2, 3, 64, 96)).cuda()
+    lab = H.synth_labels(61, "lazy.lab", (2, 64, 96), 16, 255, ignore_frac=0.05).cuda()
+    grads = {}
+    for fused in (False, True):
+        m = build(dtype=dtype, seed=61)
+        lg, _, ft = m(img)
+        loss = utils.DMLLoss(alpha=0.01, ignore_index=255, fused_backward=fused)(lg, lab, ft)
+        (loss * 0.5).backward()
+        torch.cuda.synchronize()
+        grads[fused] = {k: p.grad.detach().clone() for k, p in m.named_parameters()}
+        plan = next(p for k, p in m._engine.plans.items() if k[4])
+        assert (plan.heads[0].unfused_range in plan.skip_ranges) == fused
+    tol = 2e-5 if dtype == torch.float32 else 3e-2       # bf16: the low-resolution gradient is rounded once in both paths,
+    worst = 0.0                                          # 1-ulp differences there spread through the backward
+    for k in grads[True]:
+        e = H.rel_err(grads[True][k], grads[False][k])
+        worst = max(worst, e)
+        assert e <= tol, (k, e)
+    print("deferred vs materialised loss gradient (%s): worst parameter-gradient difference %.2e" % (dtype, worst))
+    # odd size: not an exact x4 upsample -> the marker is materialised by dml_loss_bwd, same result as the plain path
+    img2 = H.synth_tensor(62, "lazy.img2", (2, 3, 50, 66)).cuda()
+    lab2 = H.synth_labels(62, "lazy.lab2", (2, 50, 66), 16, 255, ignore_frac=0.05).cuda()
+    g2 = {}
+    for fused in (False, True):
+        m = build(dtype=torch.float32, seed=62)
+        lg, _, ft = m(img2)
+        utils.DMLLoss(alpha=0.01, ignore_index=255, fused_backward=fused)(lg, lab2, ft).backward()
+        g2[fused] = m.classifier.classifier[3].weight.grad.detach().clone()
+    relclose(g2[True], g2[False], 1e-6, "materialised marker, odd size")
+    # a second consumer of the logits: loud failure
+    m = build(dtype=torch.float32, seed=61)
+    lg, _, ft = m(img)
+    total = utils.DMLLoss(alpha=0.01, ignore_index=255, fused_backward=True)(lg, lab, ft) + 1e-3 * lg.mean()
+    with pytest.raises(RuntimeError):
+        total.backward()

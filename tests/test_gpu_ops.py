@@ -748,3 +748,49 @@ def test_rejects_bad_arguments(lib):
     assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 6, 6, 6,
                             6, 1, 0, 0.0, 0, st()) == -2
     assert lib.dml_proto_dist_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 64, 16, 1, 1, st()) == -3
+
+
+@pytest.mark.parametrize("geom", [(2, 13, 20), (1, 7, 14), (3, 29, 5), (1, 192, 192)])
+@pytest.mark.parametrize("dname", ["f32", "bf16"])
+def test_head_backward_fused_vs_plain_torch(lib, geom, dname):
+    """dml_head_bwd_fused (loss gradient + distance-head gradient + transposed x4 upsample in one pass) against autograd
+    through the reference's arithmetic (network/utils.py:88-118 + anomaly/models/models.py:42-78: interpolate ->
+    distances -> CE/n + alpha VAR/n) on the CPU, and against the unfused kernel chain.  Tiles are 7 x 14 low-resolution
+    pixels: the geometries cover ragged tiles in both directions, single-tile maps and every border clamp."""
+    from dmlnet import _lib as L
+    from oracle import dmlnet_ref as O
+    dt, tdt, _ = DT[dname]
+    B, h, w = geom
+    Hh, Ww = 4 * h, 4 * w
+    emb = rnd("hb.emb%d%d" % (h, w), (B, 16, h, w), 1.5).requires_grad_(True)
+    lab = H.synth_labels(5, "hb.lab%d%d" % (h, w), (B, Hh, Ww), 16, 255, ignore_frac=0.1)
+    protos = O.prototypes_3I(16) + 0.05 * rnd("hb.pr", (16, 16))
+    up = F.interpolate(emb, size=(Hh, Ww), mode="bilinear", align_corners=False)
+    logits, _, feats = O.distance_head(up, protos)
+    loss = O.dml_loss(logits, lab, alpha=0.01, ignore_index=255) * 1.7            # gout = 1.7
+    loss.backward()
+    ref = emb.grad.permute(0, 2, 3, 1).contiguous()                                # [B,h,w,16]
+    # device side: features / logits as the forward kernels leave them
+    f_d = feats.detach().cuda().contiguous()
+    lg_d = logits.detach().cuda().contiguous()
+    lab_d, pr_d = lab.cuda(), protos.cuda().contiguous()
+    sums = torch.zeros(5, dtype=torch.float64, device="cuda")
+    part = torch.empty(L.LOSS_BLOCKS * 4, dtype=torch.float32, device="cuda")
+    chk(lib.dml_loss_fwd(lg_d.data_ptr(), lab_d.data_ptr(), sums.data_ptr(), part.data_ptr(), B, 16, Hh, Ww, 255, st()))
+    gout = torch.tensor(1.7, device="cuda")
+    de = torch.empty(B, h, w, 16, dtype=tdt, device="cuda")
+    chk(lib.dml_head_bwd_fused(f_d.data_ptr(), lab_d.data_ptr(), sums.data_ptr(), gout.data_ptr(), pr_d.data_ptr(),
+                               de.data_ptr(), B, h, w, 16, 16, Hh, Ww, 255, 0.01, float(B), dt, st()))
+    relclose(de.float().cpu(), ref, 2e-5 if dname == "f32" else 2.0 ** -8 * 1.05, "fused head backward vs autograd")
+    # the unfused chain on the same inputs
+    gl = torch.empty_like(lg_d)
+    df = torch.empty_like(f_d)
+    de2 = torch.empty_like(de)
+    chk(lib.dml_loss_bwd(lg_d.data_ptr(), lab_d.data_ptr(), sums.data_ptr(), gout.data_ptr(), gl.data_ptr(), B, 16, Hh, Ww,
+                         255, 0.01, float(B), st()))
+    chk(lib.dml_proto_dist_bwd(gl.data_ptr(), None, f_d.data_ptr(), pr_d.data_ptr(), df.data_ptr(), B, 16, 16, Hh, Ww, st()))
+    chk(lib.dml_bilinear_bwd(df.data_ptr(), de2.data_ptr(), B, h, w, Hh, Ww, 16, 16, 16, dt, 1, 0, st()))
+    relclose(de.float().cpu(), de2.float().cpu(), 2e-5 if dname == "f32" else 2.0 ** -7, "fused vs unfused chain")
+    # shapes it does not cover are refused, not mis-computed
+    assert lib.dml_head_bwd_fused(f_d.data_ptr(), lab_d.data_ptr(), sums.data_ptr(), gout.data_ptr(), pr_d.data_ptr(),
+                                  de.data_ptr(), B, h, w, 16, 16, Hh + 1, Ww, 255, 0.01, float(B), dt, st()) == -3
