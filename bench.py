@@ -127,9 +127,9 @@ def conv_bytes_of_plan(plan):
                 rd = d.B * d.Hi * d.Wi * d.C * es + d.N * d.R * d.S * d.C * es
                 wr = d.B * d.Ho * d.Wo * d.N * (4 if d.y_f32 else es)
                 total += rd + wr * (2 if d.accum else 1)
-            elif fn is lib.dml_conv_wgrad:
-                d = args[0]._obj
-                total += d.B * d.Hi * d.Wi * d.C * es + d.B * d.Ho * d.Wo * d.N * es + 2 * 4 * d.N * d.R * d.S * d.C
+            elif fn is lib.dml_conv_wgrad or fn is lib.dml_conv_wgrad_group:
+                for d in ([args[0]._obj] if fn is lib.dml_conv_wgrad else args.meta):
+                    total += d.B * d.Hi * d.Wi * d.C * es + d.B * d.Ho * d.Wo * d.N * es + 2 * 4 * d.N * d.R * d.S * d.C
     return total
 
 
@@ -140,19 +140,22 @@ def conv_flops_of_plan(plan):
     per_op = {}
     for name, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
         for i, (fn, args) in enumerate(ops):
-            if fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad:
-                d = args[0]._obj
-                # undo the padding of the stem (3->8) and of the decoder concat (304->320)
-                if fn is lib.dml_conv_igemm and d.mode == 1:
-                    # data gradient: same MACs as the forward conv = dY pixels x Cout x taps x Cin
-                    cin = 304 if d.N == 320 else d.N
-                    fl = 2.0 * d.B * d.Hi * d.Wi * d.C * d.R * d.S * cin
-                else:
-                    cin = 3 if d.C == 8 else (304 if d.C == 320 else d.C)
-                    fl = 2.0 * d.B * d.Ho * d.Wo * d.N * d.R * d.S * cin
+            if fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad or fn is lib.dml_conv_wgrad_group:
+                descs = args.meta if fn is lib.dml_conv_wgrad_group else [args[0]._obj]      # a grouped launch: several layers
+                fl = sum(_conv_flops(d, fn is lib.dml_conv_igemm) for d in descs)
                 per_op[(name, i)] = fl
                 total += fl
     return total, per_op
+
+
+def _conv_flops(d, igemm):
+    # undo the padding of the stem (3->8) and of the decoder concat (304->320)
+    if igemm and d.mode == 1:
+        # data gradient: same MACs as the forward conv = dY pixels x Cout x taps x Cin
+        cin = 304 if d.N == 320 else d.N
+        return 2.0 * d.B * d.Hi * d.Wi * d.C * d.R * d.S * cin
+    cin = 3 if d.C == 8 else (304 if d.C == 320 else d.C)
+    return 2.0 * d.B * d.Ho * d.Wo * d.N * d.R * d.S * cin
 
 
 def profile_convs(model, engine, step_fn, n_steps):
@@ -170,7 +173,7 @@ def profile_convs(model, engine, step_fn, n_steps):
                     hook(i)
                 continue
             fn, args = ops[i]
-            is_conv = fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad
+            is_conv = fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad or fn is lib.dml_conv_wgrad_group
             if is_conv:
                 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
                 e0.record()
@@ -179,7 +182,7 @@ def profile_convs(model, engine, step_fn, n_steps):
                 raise RuntimeError("kernel failed rc=%d" % rc)
             if is_conv:
                 e1.record()
-                records.append((id(ops), i, "wgrad" if fn is lib.dml_conv_wgrad else "igemm", e0, e1))
+                records.append((id(ops), i, "igemm" if fn is lib.dml_conv_igemm else "wgrad", e0, e1))
             if hook is not None:
                 hook(i)
 
@@ -209,13 +212,16 @@ def dump_conv_table(plan, path):
     rows = []
     for name, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
         for i, (fn, args) in enumerate(ops):
-            if fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad:
-                d = args[0]._obj
+            if fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad or fn is lib.dml_conv_wgrad_group:
                 sec = profile_convs.per_op.get((id(ops), i), 0.0)
-                kind = "wgrad" if fn is lib.dml_conv_wgrad else ("dgrad" if d.mode == 1 else "fwd")
-                rows.append(dict(kind=kind, B=d.B, Hi=d.Hi, Wi=d.Wi, C=d.C, Ho=d.Ho, Wo=d.Wo, N=d.N, R=d.R,
-                                 stride=d.stride, dil=d.dil, ms=sec * 1e3,
-                                 tflops=fl[(name, i)] / sec / 1e12 if sec > 0 else 0.0, gflop=fl[(name, i)] / 1e9))
+                descs = args.meta if fn is lib.dml_conv_wgrad_group else [args[0]._obj]
+                for d in descs:                      # a grouped launch: its time is shared out by FLOPs
+                    f1 = _conv_flops(d, fn is lib.dml_conv_igemm)
+                    s1 = sec * f1 / fl[(name, i)]
+                    kind = "wgrad" if fn is not lib.dml_conv_igemm else ("dgrad" if d.mode == 1 else "fwd")
+                    rows.append(dict(kind=kind, B=d.B, Hi=d.Hi, Wi=d.Wi, C=d.C, Ho=d.Ho, Wo=d.Wo, N=d.N, R=d.R,
+                                     stride=d.stride, dil=d.dil, ms=s1 * 1e3, grouped=len(descs),
+                                     tflops=f1 / s1 / 1e12 if s1 > 0 else 0.0, gflop=f1 / 1e9))
     with open(path, "w") as f:
         json.dump(rows, f)
 
@@ -536,7 +542,11 @@ def main():
                          "at --height x --width, --batch images per step (default 1), scores on the device")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
+    ap.add_argument("--print-csrc-sha", action="store_true", help="print the fingerprint of the kernel sources and exit")
     args = ap.parse_args()
+    if args.print_csrc_sha:
+        print(csrc_sha())
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ and args.mode != "ood":
         launch_ranks(args.gpus)                  # never returns
     if args.mode == "ood":
@@ -687,7 +697,7 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("csrc_sha") == csrc_sha():
-                traffic = tj["conv_GB_per_step"] * 1e9 / tj["conv_launches_per_step"]
+                traffic = tj["conv_GB_per_step"] * 1e9 / n_launch      # per launch OF THIS PLAN (a grouped launch is one)
                 traffic_src = "profiles/%s_traffic_pmc.json (rocprofv3 --pmc, %.1f GB per step over the conv launches, csrc %s)" \
                     % (ROUND, tj["conv_GB_per_step"], tj["csrc_sha"])
         roof = {"bound": "mfma", "kernel": "every convolution launch of a step (conv_igemm*_kernel forward / data gradient, "

@@ -103,6 +103,14 @@ typedef struct DmlWgradDesc {
 
 int dml_conv_wgrad(const DmlWgradDesc* d, void* stream);
 
+/* Weight gradients of several layers in ONE launch: the 48 x 48 layers have 4-9 output tiles each, so a launch of
+ * its own needs ~28 pixel slabs per tile to fill 256 CUs and every slab is a 256 KB fp32 partial written and re-read
+ * (64 + 64 MB per layer).  Grouped, the same workgroups cover several layers with a few slabs each.  `descs`: HOST
+ * array of n <= 12 pointers to descriptors that pass dml_conv_wgrad_group_eligible (bf16, N % 256 == 0, >= 4 output
+ * tiles, 31-bit addressable); their ws / ws_elems / splitk are ignored, `ws` (ws_elems floats) is partitioned here. */
+int dml_conv_wgrad_group_eligible(const DmlWgradDesc* d);
+int dml_conv_wgrad_group(const DmlWgradDesc* const* descs, int n, float* ws, int64_t ws_elems, void* stream);
+
 /* master fp32 weight [N][RS][Cm] -> compute copy [N][RS][Cp] (zero padded, dtype) and, if wt != NULL,
  * the transposed copy wt[Cp][RS][N] used by the data gradient. */
 int dml_prep_weight(const float* w_master, void* w, void* wt, int N, int RS, int Cm, int Cp, int dtype,
@@ -205,6 +213,10 @@ int dml_broadcast_hw(const void* v, void* z, int B, int HW, int C, int ldz, int 
 int dml_reduce_hw(const void* dz, void* dv, int B, int HW, int C, int lddz, int dtype, void* stream);
 /* dx[b,:,:,c] += dv[b][c] / HW */
 int dml_avgpool_bwd_add(const void* dv, void* dx, int B, int HW, int C, int lddx, int dtype, void* stream);
+/* dx[b,:,:,c] = dv[b][c] / HW.  In bf16 the plan lets this INITIALISE the gradient buffer and the data gradients of the
+ * other ASPP branches accumulate on top: added last, a per-pixel term of 1/HW of a pooled gradient is below half an ulp
+ * of the running sum at every pixel and would vanish entirely, although it is coherent over the image. */
+int dml_avgpool_bwd_set(const void* dv, void* dx, int B, int HW, int C, int lddx, int dtype, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Bilinear resize, align_corners=False (F.interpolate call sites network/utils.py:30,88,329).

@@ -1045,21 +1045,20 @@ constexpr int WB_THREADS = 512;
 constexpr int WB_SUB = 528;                 // elements per 16-column sub-tile (32 k rows x 16 + pad)
 constexpr int WB_OP = 16 * WB_SUB;          // one operand, one stage (256 columns)
 
-__global__ __launch_bounds__(WB_THREADS) void conv_wgrad_big_kernel(const WgradArgs a, const uint32_t x_bytes,
-                                                                    const uint32_t dy_bytes) {
+// `logical`: this workgroup's index among the job's nblk_n * nblk_k * splits workgroups (tiles of one pixel slab adjacent)
+__device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_t x_bytes, const uint32_t dy_bytes,
+                                               const int logical, bf16_t* smem) {
     typedef bf16_t T;
     constexpr int TILE = 256, VEC = 8, RPP = 16, LD = 2;
     constexpr int NT = 8, MT = 4;                 // wave tile: 8 n-tiles x 4 kc-tiles of 16
     constexpr uint32_t OOB = 0x80000000u;
 
-    __shared__ __attribute__((aligned(16))) T smem[2 * 2 * WB_OP];
     auto Ys = [&](int buf) -> T* { return smem + buf * 2 * WB_OP; };
     auto Xs = [&](int buf) -> T* { return smem + buf * 2 * WB_OP + WB_OP; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 2, wk = wave & 3;
     const int ntile = a.nblk_n * a.nblk_k;
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int split = logical / ntile, tile_id = logical - split * ntile;
     const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
     const int n0 = blk_n * TILE, kc0 = blk_k * TILE;
@@ -1217,6 +1216,32 @@ __global__ __launch_bounds__(WB_THREADS) void conv_wgrad_big_kernel(const WgradA
     }
 }
 
+__global__ __launch_bounds__(WB_THREADS) void conv_wgrad_big_kernel(const WgradArgs a, const uint32_t x_bytes,
+                                                                    const uint32_t dy_bytes) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * WB_OP];
+    wgrad_big_body(a, x_bytes, dy_bytes, xcd_remap(blockIdx.x, gridDim.x), smem);
+}
+
+// Several weight gradients in ONE launch.  A single 48 x 48 layer has 4-9 output tiles of 256 x 256, so filling 256 CUs
+// takes ~28 pixel slabs per tile and every slab is a 256 KB fp32 partial that is written and read again by the fold
+// kernel: 64 MB + 64 MB per layer whatever its size (PMC: 11.3 GB per step for a 0.24 GB result).  Weight gradients
+// only feed the optimizer, so the plan launches the jobs of consecutive layers together: the same 256 workgroups then
+// cover several layers with a few slabs each, and the slab traffic (and the launch count) drops by the group size.
+constexpr int WG_MAX_JOBS = 12;
+struct WgradGroup {
+    int njobs;
+    int start[WG_MAX_JOBS + 1];            // first workgroup of each job in the launch
+    uint32_t xb[WG_MAX_JOBS], yb[WG_MAX_JOBS];
+    WgradArgs job[WG_MAX_JOBS];
+};
+__global__ __launch_bounds__(WB_THREADS) void conv_wgrad_group_kernel(const WgradGroup g) {
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * WB_OP];
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    int j = 0;
+    while (j + 1 < g.njobs && logical >= g.start[j + 1]) ++j;
+    wgrad_big_body(g.job[j], g.xb[j], g.yb[j], logical - g.start[j], smem);
+}
+
 // dw[n][rs][c < Cm] += sum_s ws[s][n][rs][c]   (fp32 atomics on the L2 are ~10x more expensive per byte than this)
 // blockIdx.y walks chunks of 16 splits so that a small weight tensor with hundreds of splits stays parallel.
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
@@ -1237,6 +1262,62 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         if (gridDim.y == 1) dw[i] += acc;
         else atomicAdd(dw + i, acc);
     }
+}
+
+struct ReduceGroup {
+    int njobs;
+    const float* ws[WG_MAX_JOBS];
+    float* dw[WG_MAX_JOBS];
+    int splits[WG_MAX_JOBS], Cm[WG_MAX_JOBS], Cp[WG_MAX_JOBS];
+    int64_t NRS[WG_MAX_JOBS];
+};
+// blockIdx.y = job: dw_j[n][rs][c < Cm] += sum_s ws_j[s][n][rs][c]
+__global__ __launch_bounds__(256) void wgrad_reduce_group_kernel(const ReduceGroup g) {
+    const int j = blockIdx.y;
+    const float* __restrict__ ws = g.ws[j];
+    float* __restrict__ dw = g.dw[j];
+    const int Cm = g.Cm[j], Cp = g.Cp[j], splits = g.splits[j];
+    const int64_t total = g.NRS[j] * Cm, plane = g.NRS[j] * Cp;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        int64_t src = i;
+        if (Cm != Cp) {
+            const int64_t t = i / Cm;
+            src = t * Cp + (i - t * Cm);
+        }
+        float acc = 0.f;
+#pragma unroll 4
+        for (int sidx = 0; sidx < splits; ++sidx) acc += ws[sidx * plane + src];
+        dw[i] += acc;
+    }
+}
+
+// shared by dml_conv_wgrad (single job) and dml_conv_wgrad_group: may this job run on the 256 x 256-tile kernel?
+static bool wgrad_big_eligible(const DmlWgradDesc* d) {
+    if (!d || !d->x || !d->dy || !d->dw || d->dtype != DML_BF16) return false;
+    if (d->C % 8 || d->ldx % 8 || d->N % 8 || d->ldy % 8) return false;
+    const int64_t M = (int64_t)d->B * d->Ho * d->Wo;
+    const int64_t Ktot = (int64_t)d->R * d->S * d->C;
+    const int64_t tiles = (M + BK - 1) / BK;
+    const int cm = d->Cm > 0 ? d->Cm : d->C;
+    if (cm > d->C) return false;
+    const int64_t plane = (int64_t)d->N * Ktot;
+    const int64_t xb64 = (((int64_t)(d->B * d->Hi) * d->Wi - 1) * d->ldx + d->C) * 2;
+    const int64_t yb64 = ((M - 1) * d->ldy + d->N) * 2;
+    return plane >= 65536 && d->N % 256 == 0 && (d->N / 256) * ((Ktot + 255) / 256) >= 4 && tiles >= 16 &&
+           xb64 < (1ll << 31) && yb64 < (1ll << 31) && (int64_t)(d->B + 1) * d->Hi * d->Wi < (1 << 24) && M < (1 << 24) &&
+           d->ldx < (1 << 22) && d->ldy < (1 << 22);
+}
+
+static void fill_wgrad_args(WgradArgs& a, const DmlWgradDesc* d) {
+    a.x = d->x; a.dy = d->dy; a.dw = d->dw;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
+    a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
+    a.M = d->B * d->Ho * d->Wo;
+    a.Ktot = d->R * d->S * d->C;
+    a.div_wo = make_fastdiv((uint32_t)d->Wo);
+    a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
+    a.div_c = make_fastdiv((uint32_t)d->C);
 }
 
 template <typename T, int MODE>
@@ -1496,6 +1577,82 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), ychunks), dim3(256), 0, st, d->ws, d->dw,
                            splitk, nrs, cm, d->C);
     }
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_conv_wgrad_group_eligible(const DmlWgradDesc* d) { return wgrad_big_eligible(d) ? 1 : 0; }
+
+// Weight gradients of several layers in one launch (conv_wgrad_group_kernel) + one fold launch.  Every job must pass
+// dml_conv_wgrad_group_eligible; the descriptors' own ws / ws_elems / splitk fields are ignored: the shared workspace
+// `ws` is partitioned here.  Splits are chosen so that the launch is one round of <= 256 workgroups with about the
+// same number of pixel tiles per workgroup in every job.
+extern "C" int dml_conv_wgrad_group(const DmlWgradDesc* const* descs, int n, float* ws, int64_t ws_elems, void* stream) {
+    if (!descs || n <= 0 || n > WG_MAX_JOBS || !ws) return DML_EINVAL;
+    WgradGroup g;
+    ReduceGroup r;
+    int base[WG_MAX_JOBS], tiles[WG_MAX_JOBS], sk[WG_MAX_JOBS];
+    int64_t plane[WG_MAX_JOBS];
+    double work = 0.0;
+    int tbase = 0;
+    for (int j = 0; j < n; ++j) {
+        const DmlWgradDesc* d = descs[j];
+        if (!wgrad_big_eligible(d)) return DML_EUNSUPPORTED;
+        WgradArgs& a = g.job[j];
+        fill_wgrad_args(a, d);
+        a.nblk_n = a.N / 256;
+        a.nblk_k = (a.Ktot + 255) / 256;
+        base[j] = a.nblk_n * a.nblk_k;
+        tiles[j] = (a.M + BK - 1) / BK;
+        plane[j] = (int64_t)a.N * a.Ktot;
+        work += (double)base[j] * tiles[j];
+        tbase += base[j];
+        g.xb[j] = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
+        g.yb[j] = (uint32_t)((((int64_t)a.M - 1) * a.ldy + a.N) * 2);
+    }
+    const int budget = tbase <= 256 ? 256 : ((tbase + 255) / 256) * 256;
+    int blocks = 0;
+    for (int j = 0; j < n; ++j) {
+        int s = (int)((double)tiles[j] * budget / work);             // equal pixel tiles per workgroup
+        const int cap = tiles[j] / 8 > 0 ? tiles[j] / 8 : 1;          // at least 8 K steps per workgroup
+        if (s > cap) s = cap;
+        if (s < 1) s = 1;
+        sk[j] = s;
+        blocks += base[j] * s;
+    }
+    // hand the remaining workgroups of the round to the jobs whose workgroups are the longest
+    for (;;) {
+        int best = -1;
+        double longest = 0.0;
+        for (int j = 0; j < n; ++j) {
+            const double per = (double)tiles[j] / sk[j];
+            if (blocks + base[j] <= budget && sk[j] < tiles[j] / 8 && per > longest) { longest = per; best = j; }
+        }
+        if (best < 0) break;
+        ++sk[best];
+        blocks += base[best];
+    }
+    int64_t off = 0;
+    g.njobs = r.njobs = n;
+    g.start[0] = 0;
+    int64_t max_items = 0;
+    for (int j = 0; j < n; ++j) {
+        WgradArgs& a = g.job[j];
+        a.slab_tiles = (tiles[j] + sk[j] - 1) / sk[j];
+        sk[j] = (tiles[j] + a.slab_tiles - 1) / a.slab_tiles;
+        if (off + (int64_t)sk[j] * plane[j] > ws_elems) return DML_EINVAL;      // workspace too small for this group
+        a.ws = ws + off;
+        g.start[j + 1] = g.start[j] + base[j] * sk[j];
+        const DmlWgradDesc* d = descs[j];
+        const int cm = d->Cm > 0 ? d->Cm : d->C;
+        r.ws[j] = a.ws; r.dw[j] = d->dw; r.splits[j] = sk[j]; r.Cm[j] = cm; r.Cp[j] = d->C;
+        r.NRS[j] = (int64_t)a.N * a.R * a.S;
+        if (r.NRS[j] * cm > max_items) max_items = r.NRS[j] * cm;
+        off += (int64_t)sk[j] * plane[j];
+    }
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3(g.start[n]), dim3(WB_THREADS), 0, st, g);
+    hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(grid_for(max_items, 256, 1024), n), dim3(256), 0, st, r);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -764,7 +764,6 @@ __global__ __launch_bounds__(256) void head_bwd_fused_c16_kernel(
     int64_t ignore_index, float alpha, float n_images_arg) {
     constexpr int C = 16, K = 16;
     __shared__ __attribute__((aligned(16))) float t[HB_ROWS][HB_GRPS][C];      // 32 KB: x-reduced rows
-    __shared__ float sp[K * C];
     const int tid = threadIdx.x;
     const int H = 4 * h, W = 4 * w;
     const int tiles_x = (w + HB_TI - 1) / HB_TI, tiles_y = (h + HB_TJ - 1) / HB_TJ;
@@ -775,107 +774,112 @@ __global__ __launch_bounds__(256) void head_bwd_fused_c16_kernel(
     const int j0 = ty * HB_TJ, i0 = tx * HB_TI;
     const int Y0 = 4 * j0 - 2;                         // first full-resolution row of the region
     const int q0 = i0 - 1;                             // first pixel group of the region
-    if (tid < K * C) sp[tid] = protos[tid];
     const float go = gout ? *gout : 1.f;
     const float n_images = n_images_arg > 0.f ? n_images_arg : (float)sums[4];
     const float w_ce = go / ((float)sums[1] * n_images);
     const float w_var = go * alpha / ((float)((int64_t)H * W) * n_images);
-    __syncthreads();
 
-    float part[2][3][C];                               // this thread's two work items: (left, own, right) column partials
-    int prow[2], pq[2];
-#pragma unroll
+    // two passes of 256 work items (16 rows x 16 groups each); a pass owns its rows of `t`, so the passes do not interact
+#pragma unroll 1
     for (int it = 0; it < 2; ++it) {
         const int id = it * 256 + tid;
         const int r = id / HB_GRPS, g = id - r * HB_GRPS;
         const int Y = Y0 + r, q = q0 + g;
-        prow[it] = r;
-        pq[it] = g;
+        float pl[C], pc[C], pr[C];                     // column partials: left neighbour (q - 1), own (q), right (q + 1)
 #pragma unroll
-        for (int s3 = 0; s3 < 3; ++s3)
+        for (int c = 0; c < C; ++c) { pl[c] = 0.f; pc[c] = 0.f; pr[c] = 0.f; }
+        if (Y >= 0 && Y < H && q >= 0 && q < w) {
+            // halo groups only reach the tile through their inner two pixels
+            const int p_lo = (g == 0) ? 2 : 0, p_hi = (g == HB_GRPS - 1) ? 2 : 4;
+            const float* frow = feats + (((int64_t)b * H + Y) * W + 4 * q) * C;
+            const int64_t* lrow = labels + ((int64_t)b * H + Y) * W + 4 * q;
+#pragma unroll 1
+            for (int p = p_lo; p < p_hi; ++p) {
+                // keep the prototype loads (256 wave-uniform scalars) inside the iteration, 4 prototypes at a time:
+                // hoisted out of the loop they need 256 SGPRs and spill
+                asm volatile("" ::: "memory");
+                float f[C];
 #pragma unroll
-            for (int c = 0; c < C; ++c) part[it][s3][c] = 0.f;
-        if (Y < 0 || Y >= H || q < 0 || q >= w) continue;
-        // halo groups only reach the tile through their inner two pixels
-        const int p_lo = (g == 0) ? 2 : 0, p_hi = (g == HB_GRPS - 1) ? 2 : 4;
-        const float* frow = feats + (((int64_t)b * H + Y) * W + 4 * q) * C;
-        const int64_t* lrow = labels + ((int64_t)b * H + Y) * W + 4 * q;
-        for (int p = p_lo; p < p_hi; ++p) {
-            float f[C];
+                for (int c = 0; c < C; c += 4) {
+                    const float4 v = *reinterpret_cast<const float4*>(frow + p * C + c);
+                    f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
+                }
+                const int64_t lab = lrow[p];
+                float lg[K];
+                float mx = -INFINITY;
+#pragma unroll 4
+                for (int k = 0; k < K; ++k) {          // prototypes: wave-uniform addresses -> scalar loads
+                    float d = 0.f;
 #pragma unroll
-            for (int c = 0; c < C; c += 4) {
-                const float4 v = *reinterpret_cast<const float4*>(frow + p * C + c);
-                f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
-            }
-            const int64_t lab = lrow[p];
-            float lg[K];
-            float mx = -INFINITY;
+                    for (int c = 0; c < C; ++c) {
+                        const float u = f[c] - protos[k * C + c];
+                        d += u * u;
+                    }
+                    lg[k] = -d;
+                    mx = fmaxf(mx, lg[k]);
+                }
+                float den = 0.f;
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float d = 0.f;
+                for (int k = 0; k < K; ++k) {
+                    lg[k] = expf(lg[k] - mx);
+                    den += lg[k];
+                }
+                const bool valid = lab != ignore_index;
+                const float inv = valid ? w_ce / den : 0.f;
+                // d loss / d features = -2 sum_k g_k (f - m_k) = -2 (f sum_k g_k - sum_k g_k m_k)
+                float gs = 0.f, gm[C];
+#pragma unroll
+                for (int c = 0; c < C; ++c) gm[c] = 0.f;
+#pragma unroll 4
+                for (int k = 0; k < K; ++k) {
+                    float gk = lg[k] * inv;
+                    if (valid && (int64_t)k == lab) gk -= w_ce + w_var;
+                    gs += gk;
+#pragma unroll
+                    for (int c = 0; c < C; ++c) gm[c] += gk * protos[k * C + c];
+                }
+                // bilinear weights of full-resolution column X = 4 q + p (align_corners = False, scale 1/4)
+                const int X = 4 * q + p;
+                float sX = 0.25f * ((float)X + 0.5f) - 0.5f;
+                sX = sX < 0.f ? 0.f : sX;
+                const int x0 = min((int)sX, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+                const float l1 = sX - (float)x0, l0 = 1.f - l1;
+                // columns x0 / x1 are q - 1, q or q + 1
+                const float wl = (x0 == q - 1 ? l0 : 0.f) + (x1 == q - 1 ? l1 : 0.f);
+                const float wc = (x0 == q ? l0 : 0.f) + (x1 == q ? l1 : 0.f);
+                const float wr = (x0 == q + 1 ? l0 : 0.f) + (x1 == q + 1 ? l1 : 0.f);
 #pragma unroll
                 for (int c = 0; c < C; ++c) {
-                    const float u = f[c] - sp[k * C + c];
-                    d += u * u;
+                    const float dfc = -2.f * (gs * f[c] - gm[c]);
+                    pl[c] += wl * dfc;
+                    pc[c] += wc * dfc;
+                    pr[c] += wr * dfc;
                 }
-                lg[k] = -d;
-                mx = fmaxf(mx, lg[k]);
             }
-            float den = 0.f;
+        }
+        // three sub-phases: every (row, column) cell of this pass's rows is written by exactly one thread in each
 #pragma unroll
-            for (int k = 0; k < K; ++k) {
-                lg[k] = expf(lg[k] - mx);
-                den += lg[k];
+        for (int c = 0; c < C; c += 4)
+            *reinterpret_cast<float4*>(&t[r][g][c]) = make_float4(pc[c], pc[c + 1], pc[c + 2], pc[c + 3]);
+        __syncthreads();
+        if (g + 1 < HB_GRPS) {
+#pragma unroll
+            for (int c = 0; c < C; c += 4) {
+                float4 v = *reinterpret_cast<float4*>(&t[r][g + 1][c]);
+                v.x += pr[c]; v.y += pr[c + 1]; v.z += pr[c + 2]; v.w += pr[c + 3];
+                *reinterpret_cast<float4*>(&t[r][g + 1][c]) = v;
             }
-            const bool valid = lab != ignore_index;
-            const float inv = valid ? w_ce / den : 0.f;
-            // d loss / d features = -2 sum_k g_k (f - m_k) = -2 (f sum_k g_k - sum_k g_k m_k)
-            float gs = 0.f, gm[C];
+        }
+        __syncthreads();
+        if (g >= 1) {
 #pragma unroll
-            for (int c = 0; c < C; ++c) gm[c] = 0.f;
-#pragma unroll
-            for (int k = 0; k < K; ++k) {
-                float gk = lg[k] * inv;
-                if (valid && (int64_t)k == lab) gk -= w_ce + w_var;
-                gs += gk;
-#pragma unroll
-                for (int c = 0; c < C; ++c) gm[c] += gk * sp[k * C + c];
-            }
-            // bilinear weights of full-resolution column X = 4 q + p (align_corners = False, scale 1/4)
-            const int X = 4 * q + p;
-            float sX = 0.25f * ((float)X + 0.5f) - 0.5f;
-            sX = sX < 0.f ? 0.f : sX;
-            const int x0 = min((int)sX, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
-            const float l1 = sX - (float)x0, l0 = 1.f - l1;
-            const int s0 = x0 - (q - 1), s1 = x1 - (q - 1);          // slots 0 / 1 / 2 = columns q-1 / q / q+1
-#pragma unroll
-            for (int c = 0; c < C; ++c) {
-                const float dfc = -2.f * (gs * f[c] - gm[c]);
-#pragma unroll
-                for (int s3 = 0; s3 < 3; ++s3)
-                    part[it][s3][c] += (s3 == s0 ? l0 * dfc : 0.f) + (s3 == s1 ? l1 * dfc : 0.f);
+            for (int c = 0; c < C; c += 4) {
+                float4 v = *reinterpret_cast<float4*>(&t[r][g - 1][c]);
+                v.x += pl[c]; v.y += pl[c + 1]; v.z += pl[c + 2]; v.w += pl[c + 3];
+                *reinterpret_cast<float4*>(&t[r][g - 1][c]) = v;
             }
         }
     }
-    // three sub-phases: every (row, column) cell of t is written by exactly one thread in each of them
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-#pragma unroll
-        for (int c = 0; c < C; c += 4)
-            *reinterpret_cast<float4*>(&t[prow[it]][pq[it]][c]) =
-                make_float4(part[it][1][c], part[it][1][c + 1], part[it][1][c + 2], part[it][1][c + 3]);
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-        if (pq[it] + 1 < HB_GRPS)
-#pragma unroll
-            for (int c = 0; c < C; ++c) t[prow[it]][pq[it] + 1][c] += part[it][2][c];
-    __syncthreads();
-#pragma unroll
-    for (int it = 0; it < 2; ++it)
-        if (pq[it] >= 1)
-#pragma unroll
-            for (int c = 0; c < C; ++c) t[prow[it]][pq[it] - 1][c] += part[it][0][c];
     __syncthreads();
 
     // phase 2: low-resolution pixel (j, i) x 8 channels per thread (98 pixels x 2 halves = 196 threads)

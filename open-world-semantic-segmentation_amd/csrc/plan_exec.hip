@@ -58,6 +58,7 @@ struct Entry {
 const Entry kEntries[] = {
     DML_ENTRY(dml_conv_igemm),
     DML_ENTRY(dml_conv_wgrad),
+    DML_ENTRY(dml_conv_wgrad_group),
     DML_ENTRY(dml_prep_weight),
     DML_ENTRY(dml_prep_weights),
     DML_ENTRY(dml_unpad_wgrad),
@@ -81,6 +82,7 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_broadcast_hw),
     DML_ENTRY(dml_reduce_hw),
     DML_ENTRY(dml_avgpool_bwd_add),
+    DML_ENTRY(dml_avgpool_bwd_set),
     DML_ENTRY(dml_bilinear_fwd),
     DML_ENTRY(dml_bilinear_bwd),
     DML_ENTRY(dml_proto_dist_fwd),

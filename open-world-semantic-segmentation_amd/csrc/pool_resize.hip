@@ -356,6 +356,10 @@ extern "C" int dml_avgpool_bwd_add(const void* dv, void* dx, int B, int HW, int 
                                    void* stream) {
     return launch_broadcast(dv, dx, B, HW, C, lddx, dtype, 1.0f / (float)HW, true, stream);
 }
+extern "C" int dml_avgpool_bwd_set(const void* dv, void* dx, int B, int HW, int C, int lddx, int dtype,
+                                   void* stream) {
+    return launch_broadcast(dv, dx, B, HW, C, lddx, dtype, 1.0f / (float)HW, false, stream);
+}
 
 template <bool BWD>
 static int launch_bilinear(const void* src, void* dst, int B, int h, int w, int H, int W, int C, int ld_src,

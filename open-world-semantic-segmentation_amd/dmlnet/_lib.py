@@ -100,6 +100,7 @@ _PROTOS = {
     "dml_broadcast_hw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_reduce_hw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_avgpool_bwd_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_avgpool_bwd_set": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_bilinear_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_bilinear_bwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_proto_dist_fwd": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -128,6 +129,8 @@ _PROTOS = {
     "dml_adaptive_avgpool_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_proto_dist_nhwc": (c_i, [c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_p]),
     "dml_upsample_nhwc_to_nchw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f, c_i, c_p]),
+    "dml_conv_wgrad_group_eligible": (c_i, [c_p]),
+    "dml_conv_wgrad_group": (c_i, [c_p, c_i, c_p, c_i64, c_p]),
     "dml_plan_fn_id": (c_i, [C.c_char_p]),
     "dml_plan_fn_nargs": (c_i, [c_i]),
     "dml_plan_run": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, C.POINTER(c_i)]),

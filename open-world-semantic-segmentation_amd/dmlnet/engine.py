@@ -69,11 +69,11 @@ def _pack_word(v, ctype):
 class BoundArgs(list):
     """The argument list of one plan op.  Plain list for the Python replay; once the op has a slot in a native launch
     list, item assignment (per-step pointers, seeds, momenta) writes through to the packed copy."""
-    __slots__ = ("slot", "types")
+    __slots__ = ("slot", "types", "meta")
 
     def __init__(self, it=()):
         super().__init__(it)
-        self.slot, self.types = None, None
+        self.slot, self.types, self.meta = None, None, None
 
     def __setitem__(self, k, v):
         super().__setitem__(k, v)
@@ -324,7 +324,10 @@ class Plan:
                                    device=self.device)
         self.sp = self.scratch.data_ptr()
         # split-K partials of the weight gradients (one launch at a time uses it: all of them run on one stream)
-        self.wgrad_ws = torch.empty(40 * (1 << 20) if training else 1, dtype=torch.float32, device=self.device)
+        self.wgrad_ws = torch.empty(64 * (1 << 20) if training else 1, dtype=torch.float32, device=self.device)
+        self.group_wgrad = os.environ.get("DML_GROUP_WGRAD", "1") != "0"
+        self.group_tiles = int(os.environ.get("DML_GROUP_TILES", "48"))     # 256 x 256 output tiles per grouped launch
+        self._wg_pending = []
         self.build()
         self.bytes = sum(t.numel() * t.element_size() for t in self.keep if isinstance(t, torch.Tensor))
 
@@ -458,6 +461,15 @@ class Plan:
                         N=Nw, ldy=dy.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, splitk=0,
                         Cm=Cm, ws=self.wgrad_ws.data_ptr(), ws_elems=self.wgrad_ws.numel())
         self.keep.append(dsc)
+        if tmp is None and self.group_wgrad and self.lib.dml_conv_wgrad_group_eligible(C.byref(dsc)):
+            # joins the next grouped launch (dml_conv_wgrad_group): the weight gradients of a few consecutive layers
+            # share one round of workgroups, so each needs a handful of split-K slabs instead of ~28
+            Ktot = kh * kw * x.C
+            base = (Nw // 256) * ((Ktot + 255) // 256)
+            self._wg_pending.append((dsc, conv, base))
+            if sum(b for _, _, b in self._wg_pending) >= self.group_tiles or len(self._wg_pending) >= 12:
+                self.flush_wgrad()
+            return
         self.call(self.bwd, self.lib.dml_conv_wgrad, C.byref(dsc))
         if tmp is not None:
             self.call(self.bwd, self.lib.dml_unpad_wgrad, tmp.data_ptr(), gptr, conv.out_channels, kh * kw, Cm, Cm)
@@ -466,6 +478,21 @@ class Plan:
         for i in range(first, len(self.bwd)):
             self.side[i] = (i == first)
         self.mark_grad(conv.weight)
+
+    def flush_wgrad(self):
+        """emit the pending weight-gradient jobs as one grouped launch on the side stream"""
+        pend, self._wg_pending = self._wg_pending, []
+        if not pend:
+            return
+        arr = (C.c_void_p * len(pend))(*[C.addressof(d) for d, _, _ in pend])
+        self.keep.append(arr)
+        i = len(self.bwd)
+        args = self.call(self.bwd, self.lib.dml_conv_wgrad_group, C.addressof(arr), len(pend), self.wgrad_ws.data_ptr(),
+                         self.wgrad_ws.numel())
+        args.meta = [d for d, _, _ in pend]                 # bench.py: FLOPs / bytes of the launch
+        self.side[i] = True
+        for _, conv, _ in pend:
+            self.param_last_op[self.e.store._index(conv.weight)] = i
 
     def mark_grad(self, p):
         self.param_last_op[self.e.store._index(p)] = len(self.bwd) - 1
@@ -680,6 +707,7 @@ class Plan:
         for hi in reversed(range(len(self.heads))):
             start = len(self.bwd)
             self._head_bwd(self.heads[hi], low, out)
+            self.flush_wgrad()                          # a head's segment may be skipped as a whole: keep its jobs inside
             self.head_bwd_range[hi] = (start, len(self.bwd))
         # bottlenecks in reverse (this whole segment, and the head ops that only feed it, are skipped when no backbone
         # parameter requires a gradient: the reference's incremental recipe trains one new head on a fixed trunk,
@@ -704,6 +732,7 @@ class Plan:
         self.call(self.bwd, lib.dml_maxpool3x3s2_bwd, self.grad_of(p0).ptr, amax.data_ptr(), dz0.ptr, B, z0.H, z0.W,
                   64, self.dt)
         self.unit_bwd(stem, dz0, need_dgrad=False)
+        self.flush_wgrad()
         self.backbone_bwd_range = (backbone_start, len(self.bwd))
 
     def _head_fwd(self, head: nn.Module, low: Act, out: Act):
@@ -852,13 +881,19 @@ class Plan:
         else:
             self.unit_bwd(upool, dzp)                                    # -> d pooled
         feeders = self.to_backbone_ops                 # backward ops whose only product is d(out) / d(low)
+        # The image-pooling branch contributes dv / HW to every pixel of d(out): far below half an ulp of the other four
+        # branches' sum in bf16.  It goes in FIRST (while the buffer is still untouched), so that the data gradients
+        # accumulate onto it in fp32 before each rounding and the term survives on average; a later head's segment finds
+        # the buffer initialised and adds.
+        first = not out.root.grad_init
+        self.call(self.bwd, lib.dml_avgpool_bwd_set if first else lib.dml_avgpool_bwd_add, self.grad_of(pooled).ptr,
+                  self.grad_of(out).ptr, B, out.H * out.W, out.C, self.grad_of(out).ld, self.dt)
+        out.root.grad_init = True
+        feeders.append(len(self.bwd) - 1)
         for i in range(4):
             self.unit_bwd(branches[i], dcat1.slice(256 * i, 256))       # -> d out (accumulating)
             feeders.append(len(self.bwd) - 1)           # unit_bwd ends with the data gradient
-        self.call(self.bwd, lib.dml_avgpool_bwd_add, self.grad_of(pooled).ptr, self.grad_of(out).ptr, B,
-                  out.H * out.W, out.C, self.grad_of(out).ld, self.dt)
-        feeders.append(len(self.bwd) - 1)
-        self.last_dgrad.pop(self.grad_of(out).ptr, None)      # not a data gradient: layer4's last BN keeps its own reduce
+        self.last_dgrad.pop(self.grad_of(out).ptr, None)      # several writers: layer4's last BN keeps its own reduce
         # low-level projection -> d low (layer1 output)
         self.unit_bwd(up_low, dcat2.slice(0, 48))
         feeders.append(len(self.bwd) - 1)

@@ -200,7 +200,10 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
         conv, bn = u.conv, u.bn
         cin = conv.in_channels
         x = _nchw(_act(u.x), u.x.B, u.x.H, u.x.W)[:, :cin]
-        wq = conv.weight.detach().float().cpu().to(torch.bfloat16).float().contiguous().requires_grad_(True)
+        wq = conv.weight.detach().float().cpu()
+        if u.dtype == torch.bfloat16:                  # (the ASPP image-pooling unit lives in fp32 storage: fp32 weights)
+            wq = wq.to(torch.bfloat16).float()
+        wq = wq.contiguous().requires_grad_(True)
         xr = x.clone().requires_grad_(consumers[id(u.x.root)] == 1 and u.x is u.x.root and u.x.root.grad is not None)
         y_ref = F.conv2d(xr, wq, None, conv.stride, conv.padding, conv.dilation)
         y = _nchw(_act(u.y), u.y.B, u.y.H, u.y.W)

@@ -794,3 +794,54 @@ def test_head_backward_fused_vs_plain_torch(lib, geom, dname):
     # shapes it does not cover are refused, not mis-computed
     assert lib.dml_head_bwd_fused(f_d.data_ptr(), lab_d.data_ptr(), sums.data_ptr(), gout.data_ptr(), pr_d.data_ptr(),
                                   de.data_ptr(), B, h, w, 16, 16, Hh + 1, Ww, 255, 0.01, float(B), dt, st()) == -3
+
+
+def test_conv_wgrad_group_matches_the_per_layer_launches(lib):
+    """dml_conv_wgrad_group: the weight gradients of several layers in one launch (a few split-K slabs each instead of
+    ~28) -- a bottleneck's three convolutions with different map sizes, the dropped-pad-channel case and a stride-2 job,
+    against autograd on the CPU; an ineligible job makes the call fail, not fall back."""
+    from dmlnet._lib import WgradDesc
+    cases = [("g1x1a", 2, 16, 16, 256, 1024, 1, 1, 1, 0), ("g3x3", 2, 16, 16, 256, 256, 3, 1, 1, 0),
+             ("g1x1b", 2, 16, 16, 1024, 256, 1, 1, 1, 0), ("g320", 1, 40, 44, 320, 256, 3, 1, 1, 304),
+             ("gs2", 2, 40, 36, 128, 256, 3, 2, 1, 0), ("gd6", 3, 12, 16, 512, 256, 3, 1, 6, 0)]
+    keep, descs, refs, outs = [], [], [], []
+    for name, B, Hh, Ww, Cin, Cout, k, stride, dil, Cm in cases:
+        x = qz(rnd("wgg.x" + name, (B, Cin, Hh, Ww)), torch.bfloat16)
+        w = qz(rnd("wgg.w" + name, (Cout, Cin, k, k), scale=0.05), torch.bfloat16).requires_grad_(True)
+        y, pad = conv_ref(x, w, k, stride, dil)
+        gy = qz(rnd("wgg.gy" + name, tuple(y.shape)), torch.bfloat16)
+        (y * gy).sum().backward()
+        xd, gyd = nhwc(x, torch.bfloat16), nhwc(gy, torch.bfloat16)
+        cm = Cm or Cin
+        dw = torch.full((Cout, k, k, cm), 1.0, device="cuda")
+        d = WgradDesc(x=xd.data_ptr(), dy=gyd.data_ptr(), dw=dw.data_ptr(), B=B, Hi=Hh, Wi=Ww, C=Cin, ldx=Cin, Ho=y.shape[2],
+                      Wo=y.shape[3], N=Cout, ldy=Cout, R=k, S=k, stride=stride, dil=dil, pad=pad, dtype=1, splitk=0, Cm=Cm,
+                      ws=None, ws_elems=0)
+        assert lib.dml_conv_wgrad_group_eligible(C.byref(d)) == 1, name
+        keep += [xd, gyd]
+        descs.append(d)
+        refs.append(w.grad[:, :cm])
+        outs.append(dw)
+    ws = torch.empty(48 << 20, device="cuda")
+    arr = (C.c_void_p * len(descs))(*[C.addressof(d) for d in descs])
+    chk(lib.dml_conv_wgrad_group(arr, len(descs), ws.data_ptr(), ws.numel(), st()))
+    torch.cuda.synchronize()
+    for (name, *_), dw, ref in zip(cases, outs, refs):
+        relclose(dw.cpu().permute(0, 3, 1, 2) - 1.0, ref, 2e-3, "grouped wgrad " + name)
+    # subsets and single jobs give the same result (other split choices)
+    for sub in ([0], [1, 2], [3, 4, 5]):
+        for i in sub:
+            outs[i].fill_(0.0)
+        arr2 = (C.c_void_p * len(sub))(*[C.addressof(descs[i]) for i in sub])
+        chk(lib.dml_conv_wgrad_group(arr2, len(sub), ws.data_ptr(), ws.numel(), st()))
+        torch.cuda.synchronize()
+        for i in sub:
+            relclose(outs[i].cpu().permute(0, 3, 1, 2), refs[i], 2e-3, "grouped wgrad subset %s" % cases[i][0])
+    # a 64-channel job is not eligible: refused
+    small = WgradDesc(x=keep[0].data_ptr(), dy=keep[1].data_ptr(), dw=outs[0].data_ptr(), B=2, Hi=16, Wi=16, C=256, ldx=256,
+                      Ho=16, Wo=16, N=64, ldy=1024, R=1, S=1, stride=1, dil=1, pad=0, dtype=1, splitk=0, Cm=0, ws=None, ws_elems=0)
+    assert lib.dml_conv_wgrad_group_eligible(C.byref(small)) == 0
+    arr3 = (C.c_void_p * 1)(C.addressof(small))
+    assert lib.dml_conv_wgrad_group(arr3, 1, ws.data_ptr(), ws.numel(), st()) == -3
+    # too small a workspace is an error, not an overrun
+    assert lib.dml_conv_wgrad_group(arr, len(descs), ws.data_ptr(), 1024, st()) == -1
