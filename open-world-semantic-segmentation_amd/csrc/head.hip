@@ -7,10 +7,24 @@
 // round trips), and the host numpy post-processing of test_embedding.py:339-350,428-445 and
 // anomaly/eval_ood_traditional.py:301-305.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
+constexpr bool DIST_NT_DEFAULT = false;      // tools/bench_dist_variants.py
 constexpr int MAXC = 32, MAXK = 33;   // embedding dim / prototype count supported by these kernels
+
+// 16-byte store of an output that nobody re-reads from cache (logits / features: 1.2 GB per step, far beyond L2):
+// NT = true marks it non-temporal
+template <bool NT> __device__ __forceinline__ void store4(float* p, const float4 v) {
+    if constexpr (NT) {
+        typedef float f32x4_nt __attribute__((ext_vector_type(4)));
+        f32x4_nt t = {v.x, v.y, v.z, v.w};
+        __builtin_nontemporal_store(t, reinterpret_cast<f32x4_nt*>(p));
+    } else {
+        *reinterpret_cast<float4*>(p) = v;
+    }
+}
 
 __device__ __forceinline__ void load_protos(float* sp, const float* __restrict__ protos, int n) {
     for (int i = threadIdx.x; i < n; i += blockDim.x) sp[i] = protos[i];
@@ -121,6 +135,7 @@ __global__ __launch_bounds__(256) void proto_dist_fwd_kernel(const float* __rest
 // ---- per-wave NHWC <-> "4 pixels per lane" transposition through a 16 KB LDS image (C = 16 floats per pixel).
 // Lane l owns pixel groups wave_first + l (4 pixels = 256 B = 16 chunks of 16 B).  Global accesses are issued so
 // that lane l touches chunk j*64 + l of the wave's contiguous 16 KB: 1 KB of consecutive bytes per instruction.
+template <bool NT = false>
 __device__ __forceinline__ void wave_store_nhwc16(float4* st, const float (&f)[16][4], float* __restrict__ dst,
                                                   int lane, int64_t wave_first, int64_t total) {
 #pragma unroll
@@ -134,7 +149,7 @@ __device__ __forceinline__ void wave_store_nhwc16(float4* st, const float (&f)[1
     for (int j = 0; j < 16; ++j) {
         const int q = j * 64 + lane, r = q >> 4;
         const float4 v = st[r * 16 + ((q & 15) ^ (r & 15))];
-        if (wave_first + r < total) *reinterpret_cast<float4*>(dst + (wave_first + r) * 64 + (q & 15) * 4) = v;
+        if (wave_first + r < total) store4<NT>(dst + (wave_first + r) * 64 + (q & 15) * 4, v);
     }
     __builtin_amdgcn_wave_barrier();
 }
@@ -159,6 +174,7 @@ __device__ __forceinline__ void wave_load_nhwc16(float4* st, float (&f)[16][4], 
 }
 
 // ---- fused upsample + head, K = C = 16: one pixel group per lane, features stored through the LDS transpose
+template <bool NT>
 __global__ __launch_bounds__(256) void upsample_dist_fwd_c16_kernel(const float* __restrict__ e,
                                                                     const float* __restrict__ protos,
                                                                     float* __restrict__ logits,
@@ -202,7 +218,7 @@ __global__ __launch_bounds__(256) void upsample_dist_fwd_c16_kernel(const float*
             f[c + 3][p] = ly0 * (lx0 * a.w + lx1 * bq.w) + ly1 * (lx0 * cq.w + lx1 * d.w);
         }
     }
-    if (feats != nullptr) wave_store_nhwc16(stage[wave], f, feats, lane, wave_first, total);
+    if (feats != nullptr) wave_store_nhwc16<NT>(stage[wave], f, feats, lane, wave_first, total);
     const int64_t pix = g * 4;
 #pragma unroll 4
     for (int k = 0; k < K; ++k) {
@@ -217,7 +233,123 @@ __global__ __launch_bounds__(256) void upsample_dist_fwd_c16_kernel(const float*
             }
         }
         if (logits != nullptr && active)
-            *reinterpret_cast<float4*>(logits + ((int64_t)b * K + k) * HW + pix) = make_float4(-d[0], -d[1], -d[2], -d[3]);
+            store4<NT>(logits + ((int64_t)b * K + k) * HW + pix, make_float4(-d[0], -d[1], -d[2], -d[3]));
+    }
+}
+
+// ---- the same for an exact x4 upsample (H = 4h, W = 4w: the DeepLabV3+ head, network/utils.py:88) with the low-resolution
+// operand staged in LDS.  A workgroup owns a band of up to four output rows that interpolate between the SAME two
+// low-resolution rows (rows 4j+2 .. 4j+5 lie between rows j and j+1) and 256 output columns: 2 x 66 low-resolution
+// pixels = 8.4 KB are fetched once, coalesced, instead of 64 gathered 16-byte loads per lane; each lane then blends the
+// two rows for its three source columns and forms its 4 pixels with three weights per pixel.  The NHWC copy goes out
+// through an 8 KB-per-wave transposition in two halves, so a workgroup needs 40 KB of LDS (4 per CU, the gathered
+// kernel's 64 KB allow 2).
+template <bool NT>
+__global__ __launch_bounds__(256) void upsample4_dist_fwd_c16_kernel(const float* __restrict__ e,
+                                                                     const float* __restrict__ protos,
+                                                                     float* __restrict__ logits,
+                                                                     float* __restrict__ feats, int B, int h, int w) {
+    constexpr int C = 16, K = 16, COLS = 66;
+    __shared__ __attribute__((aligned(16))) float4 low[2][COLS][4];       // [row][column][16-byte chunk, swizzled]
+    __shared__ __attribute__((aligned(16))) float4 stage[4][512];         // per wave: 64 lanes x 2 pixels x 64 B
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int H = 4 * h, W = 4 * w;
+    const int segs = (W + 255) / 256;
+    int bid = blockIdx.x;
+    const int seg = bid % segs;
+    bid /= segs;
+    const int jb = bid % (h + 1) - 1, b = bid / (h + 1);                  // band -1 .. h-1
+    const int r0 = max(jb, 0), r1 = min(jb + 1, h - 1);
+    const int Q0 = seg * 64;                                              // first low-resolution column of the segment
+    for (int idx = tid; idx < 2 * COLS * 4; idx += 256) {
+        const int row = idx / (COLS * 4), rem = idx - row * (COLS * 4);
+        const int ci = rem >> 2, c4 = rem & 3;
+        const int col = min(max(Q0 - 1 + ci, 0), w - 1);
+        const float4 v = *reinterpret_cast<const float4*>(e + (((int64_t)b * h + (row ? r1 : r0)) * w + col) * C + c4 * 4);
+        low[row][ci][c4 ^ (ci & 3)] = v;
+    }
+    __syncthreads();
+    const int Y = 4 * jb + 2 + wave;
+    if (Y < 0 || Y >= H) return;                                          // (whole waves: no barrier below)
+    float sY = 0.25f * ((float)Y + 0.5f) - 0.5f;
+    sY = sY < 0.f ? 0.f : sY;
+    const int y0 = min((int)sY, h - 1);
+    const float ly1 = sY - (float)y0, ly0 = 1.f - ly1;
+    // y0 is r0 except on the last band's clamp, y1 = y0 + 1 clamped is r1 -- or both rows coincide
+    const int ra = (y0 == r0) ? 0 : 1, rb = (min(y0 + 1, h - 1) == r1) ? 1 : 0;
+    const int q = Q0 + lane;                                              // this lane's low-resolution column
+    const bool active = q < w;
+    // rows blended for the three source columns q-1, q, q+1 (LDS columns lane, lane+1, lane+2)
+    float T[3][C];
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3) {
+        const int ci = lane + s3;
+#pragma unroll
+        for (int c4 = 0; c4 < 4; ++c4) {
+            const float4 a = low[ra][ci][c4 ^ (ci & 3)], bq = low[rb][ci][c4 ^ (ci & 3)];
+            T[s3][c4 * 4] = ly0 * a.x + ly1 * bq.x;
+            T[s3][c4 * 4 + 1] = ly0 * a.y + ly1 * bq.y;
+            T[s3][c4 * 4 + 2] = ly0 * a.z + ly1 * bq.z;
+            T[s3][c4 * 4 + 3] = ly0 * a.w + ly1 * bq.w;
+        }
+    }
+    float f[C][4];
+#pragma unroll
+    for (int p = 0; p < 4; ++p) {
+        const int X = 4 * q + p;
+        float sX = 0.25f * ((float)X + 0.5f) - 0.5f;
+        sX = sX < 0.f ? 0.f : sX;
+        const int x0 = min((int)sX, w - 1), x1 = x0 + (x0 < w - 1 ? 1 : 0);
+        const float l1 = sX - (float)x0, l0 = 1.f - l1;
+        const float wl = (x0 == q - 1 ? l0 : 0.f) + (x1 == q - 1 ? l1 : 0.f);
+        const float wc = (x0 == q ? l0 : 0.f) + (x1 == q ? l1 : 0.f);
+        const float wr = (x0 == q + 1 ? l0 : 0.f) + (x1 == q + 1 ? l1 : 0.f);
+#pragma unroll
+        for (int c = 0; c < C; ++c) f[c][p] = wl * T[0][c] + wc * T[1][c] + wr * T[2][c];
+    }
+    const int64_t HW = (int64_t)H * W;
+    const int64_t row_first = (((int64_t)b * H + Y) * W) / 4;             // first pixel group of this output row
+    const int64_t wave_first = row_first + Q0, row_end = row_first + w;
+    if (feats != nullptr) {
+        // two halves (pixels 0-1, 2-3): lane l owns 128 B = 8 chunks per half; store instruction j covers chunks
+        // j*64 + lane of the wave's 8 KB, i.e. 128 contiguous bytes per 8 lanes
+        float4* st = stage[wave];
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+#pragma unroll
+            for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    const int p = half * 2 + pp;
+                    st[lane * 8 + ((pp * 4 + c4) ^ (lane & 7))] =
+                        make_float4(f[c4 * 4][p], f[c4 * 4 + 1][p], f[c4 * 4 + 2][p], f[c4 * 4 + 3][p]);
+                }
+            __builtin_amdgcn_wave_barrier();
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int qq = j * 64 + lane, r = qq >> 3;
+                const float4 v = st[r * 8 + ((qq & 7) ^ (r & 7))];
+                if (wave_first + r < row_end)
+                    store4<NT>(feats + (wave_first + r) * 64 + half * 32 + (qq & 7) * 4, v);
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (logits == nullptr || !active) return;
+    const int64_t pix = (int64_t)Y * W + 4 * q;
+#pragma unroll 4
+    for (int k = 0; k < K; ++k) {
+        float d[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            const float m = protos[k * C + c];
+#pragma unroll
+            for (int p = 0; p < 4; ++p) {
+                const float t = f[c][p] - m;
+                d[p] += t * t;
+            }
+        }
+        store4<NT>(logits + ((int64_t)b * K + k) * HW + pix, make_float4(-d[0], -d[1], -d[2], -d[3]));
     }
 }
 
@@ -277,6 +409,7 @@ __global__ __launch_bounds__(256) void proto_dist_bwd_c16_kernel(const float* __
 // transposed through a per-wave 16 KB LDS image (XOR-swizzled 16-byte chunks) so that every store instruction
 // writes 1 KB of consecutive addresses instead of 64 scattered 16-byte pieces.  Prototypes are read with a
 // wave-uniform index (scalar loads), no LDS, no block barrier.
+template <bool NT>
 __global__ __launch_bounds__(256) void proto_dist_fwd_c16_kernel(const float* __restrict__ x,
                                                                  const float* __restrict__ protos,
                                                                  float* __restrict__ logits,
@@ -322,7 +455,7 @@ __global__ __launch_bounds__(256) void proto_dist_fwd_c16_kernel(const float* __
                 const int64_t gb = grp / groups_per_img;
                 const int64_t gpix = (grp - gb * groups_per_img) * 4;
                 float* dst = feats + (gb * HW + gpix) * C + (q & 15) * 4;
-                *reinterpret_cast<float4*>(dst) = v;
+                store4<NT>(dst, v);
             }
         }
     }
@@ -347,7 +480,7 @@ __global__ __launch_bounds__(256) void proto_dist_fwd_c16_kernel(const float* __
             if (d[p] > best[p]) { best[p] = d[p]; bi[p] = k; }
         }
         if (logits != nullptr && active)
-            *reinterpret_cast<float4*>(logits + (b * K + k) * HW + pix) = make_float4(d[0], d[1], d[2], d[3]);
+            store4<NT>(logits + (b * K + k) * HW + pix, make_float4(d[0], d[1], d[2], d[3]));
     }
     if (active) {
         if (argmax != nullptr)
@@ -926,8 +1059,13 @@ extern "C" int dml_proto_dist_fwd(const float* x_nchw, const float* protos, floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (HW % 4 == 0 && C == 16 && K == 16) {
         const int64_t groups = (int64_t)B * HW / 4;
-        hipLaunchKernelGGL(proto_dist_fwd_c16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, x_nchw,
-                           protos, logits, feats, argmax, dissum, B, HW);
+        static const bool nt = getenv("DML_DIST_NT") ? atoi(getenv("DML_DIST_NT")) != 0 : DIST_NT_DEFAULT;
+        if (nt)
+            hipLaunchKernelGGL(proto_dist_fwd_c16_kernel<true>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                               x_nchw, protos, logits, feats, argmax, dissum, B, HW);
+        else
+            hipLaunchKernelGGL(proto_dist_fwd_c16_kernel<false>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
+                               x_nchw, protos, logits, feats, argmax, dissum, B, HW);
     } else if (HW % 4 == 0) {
         const int grid = grid_for((int64_t)B * HW / 4, 256, 256 * 16);
         if (C <= 16) hipLaunchKernelGGL((proto_dist_fwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, x_nchw, protos, logits, feats,
@@ -952,10 +1090,26 @@ extern "C" int dml_upsample_dist_fwd(const float* e, const float* protos, float*
     if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (W % 4 == 0 && C == 16 && K == 16 && argmax == nullptr && dissum == nullptr) {
+    static const bool staged = getenv("DML_UPS_STAGED") ? atoi(getenv("DML_UPS_STAGED")) != 0 : true;
+    if (staged && H == 4 * h && W == 4 * w && C == 16 && K == 16 && argmax == nullptr && dissum == nullptr) {
+        static const bool nt4 = getenv("DML_DIST_NT") ? atoi(getenv("DML_DIST_NT")) != 0 : DIST_NT_DEFAULT;
+        const int64_t blocks = (int64_t)B * (h + 1) * ((W + 255) / 256);
+        if (blocks >= (1ll << 31)) return DML_EINVAL;
+        if (nt4)
+            hipLaunchKernelGGL(upsample4_dist_fwd_c16_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, e, protos, logits,
+                               feats, B, h, w);
+        else
+            hipLaunchKernelGGL(upsample4_dist_fwd_c16_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, e, protos, logits,
+                               feats, B, h, w);
+    } else if (W % 4 == 0 && C == 16 && K == 16 && argmax == nullptr && dissum == nullptr) {
         const int64_t groups = (int64_t)B * H * (W / 4);
-        hipLaunchKernelGGL(upsample_dist_fwd_c16_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, e,
-                           protos, logits, feats, B, h, w, H, W, sy, sx);
+        static const bool nt = getenv("DML_DIST_NT") ? atoi(getenv("DML_DIST_NT")) != 0 : DIST_NT_DEFAULT;
+        if (nt)
+            hipLaunchKernelGGL(upsample_dist_fwd_c16_kernel<true>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, e,
+                               protos, logits, feats, B, h, w, H, W, sy, sx);
+        else
+            hipLaunchKernelGGL(upsample_dist_fwd_c16_kernel<false>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, e,
+                               protos, logits, feats, B, h, w, H, W, sy, sx);
     } else if (W % 4 == 0) {
         const int grid = grid_for((int64_t)B * H * (W / 4), 256, 256 * 16);
         if (C <= 16) hipLaunchKernelGGL((upsample_dist_fwd_kernel<4, 16>), dim3(grid), dim3(256), 0, st, e, protos, logits, feats,

@@ -845,3 +845,32 @@ def test_conv_wgrad_group_matches_the_per_layer_launches(lib):
     assert lib.dml_conv_wgrad_group(arr3, 1, ws.data_ptr(), ws.numel(), st()) == -3
     # too small a workspace is an error, not an overrun
     assert lib.dml_conv_wgrad_group(arr, len(descs), ws.data_ptr(), 1024, st()) == -1
+
+
+@pytest.mark.parametrize("geom", [(2, 6, 5), (1, 1, 1), (2, 9, 70), (1, 3, 129), (1, 192, 192)])
+def test_upsample_dist_exact_x4_staged_and_gathered(lib, geom, monkeypatch):
+    """dml_upsample_dist_fwd at an exact x4 ratio runs the LDS-staged kernel (bands of four rows between two
+    low-resolution rows, 256-column segments): single-pixel maps, segments that end inside a row, several segments, the
+    benchmark's 192 -> 768 -- against F.interpolate + the distance formula on the CPU."""
+    B, h, w = geom
+    K = 16
+    Hh, Ww = 4 * h, 4 * w
+    e = rnd("ud4.e%d_%d" % (h, w), (B, K, h, w), 2.0)
+    up = F.interpolate(e, size=(Hh, Ww), mode="bilinear", align_corners=False)
+    feats = up.permute(0, 2, 3, 1).contiguous()
+    protos = 3.0 * torch.eye(K) + 0.1 * rnd("ud4.p", (K, K))
+    logits = -((feats.unsqueeze(3) - protos) ** 2).sum(-1).permute(0, 3, 1, 2)
+    ed = e.permute(0, 2, 3, 1).contiguous().cuda()
+    pr = protos.cuda()
+    lg = torch.full((B, K, Hh, Ww), float("nan"), device="cuda")
+    ft = torch.full((B, Hh, Ww, K), float("nan"), device="cuda")
+    chk(lib.dml_upsample_dist_fwd(ed.data_ptr(), pr.data_ptr(), lg.data_ptr(), ft.data_ptr(), None, None, B, h, w, K, K,
+                                  Hh, Ww, st()))
+    torch.cuda.synchronize()
+    relclose(ft.cpu(), feats, 1e-6, "staged x4 features")
+    relclose(lg.cpu(), logits, 1e-5, "staged x4 logits")
+    # outputs may be requested one at a time
+    lg2 = torch.full_like(lg, float("nan"))
+    chk(lib.dml_upsample_dist_fwd(ed.data_ptr(), pr.data_ptr(), lg2.data_ptr(), None, None, None, B, h, w, K, K, Hh, Ww, st()))
+    torch.cuda.synchronize()
+    assert torch.equal(lg2, lg)
