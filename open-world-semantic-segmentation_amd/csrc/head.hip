@@ -11,7 +11,9 @@
 
 namespace {
 
-constexpr bool DIST_NT_DEFAULT = false;      // tools/bench_dist_variants.py
+// non-temporal stores of logits / features: standalone head 0.378 -> 0.358 ms, staged x4 kernel 0.237 -> 0.219 ms
+// (tools/bench_dist_variants.py, 768 x 768 x 16)
+constexpr bool DIST_NT_DEFAULT = true;
 constexpr int MAXC = 32, MAXK = 33;   // embedding dim / prototype count supported by these kernels
 
 // 16-byte store of an output that nobody re-reads from cache (logits / features: 1.2 GB per step, far beyond L2):
@@ -173,6 +175,33 @@ __device__ __forceinline__ void wave_load_nhwc16(float4* st, float (&f)[16][4], 
     __builtin_amdgcn_wave_barrier();
 }
 
+// The same store in two halves (pixels 0-1, then 2-3) through an 8 KB-per-wave image: a 256-thread workgroup then needs
+// 32 KB of LDS instead of 64 KB.  Store instruction j of a half covers chunks j*64 + lane of the wave's 8 KB: 128
+// contiguous bytes per 8 lanes.  `bound`: first pixel group that must not be written.
+template <bool NT>
+__device__ __forceinline__ void wave_store_nhwc16_halves(float4* st, const float (&f)[16][4], float* __restrict__ dst,
+                                                         int lane, int64_t wave_first, int64_t bound) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+#pragma unroll
+        for (int pp = 0; pp < 2; ++pp)
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) {
+                const int p = half * 2 + pp;
+                st[lane * 8 + ((pp * 4 + c4) ^ (lane & 7))] =
+                    make_float4(f[c4 * 4][p], f[c4 * 4 + 1][p], f[c4 * 4 + 2][p], f[c4 * 4 + 3][p]);
+            }
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int qq = j * 64 + lane, r = qq >> 3;
+            const float4 v = st[r * 8 + ((qq & 7) ^ (r & 7))];
+            if (wave_first + r < bound) store4<NT>(dst + (wave_first + r) * 64 + half * 32 + (qq & 7) * 4, v);
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
 // ---- fused upsample + head, K = C = 16: one pixel group per lane, features stored through the LDS transpose
 template <bool NT>
 __global__ __launch_bounds__(256) void upsample_dist_fwd_c16_kernel(const float* __restrict__ e,
@@ -310,31 +339,7 @@ __global__ __launch_bounds__(256) void upsample4_dist_fwd_c16_kernel(const float
     const int64_t HW = (int64_t)H * W;
     const int64_t row_first = (((int64_t)b * H + Y) * W) / 4;             // first pixel group of this output row
     const int64_t wave_first = row_first + Q0, row_end = row_first + w;
-    if (feats != nullptr) {
-        // two halves (pixels 0-1, 2-3): lane l owns 128 B = 8 chunks per half; store instruction j covers chunks
-        // j*64 + lane of the wave's 8 KB, i.e. 128 contiguous bytes per 8 lanes
-        float4* st = stage[wave];
-#pragma unroll
-        for (int half = 0; half < 2; ++half) {
-#pragma unroll
-            for (int pp = 0; pp < 2; ++pp)
-#pragma unroll
-                for (int c4 = 0; c4 < 4; ++c4) {
-                    const int p = half * 2 + pp;
-                    st[lane * 8 + ((pp * 4 + c4) ^ (lane & 7))] =
-                        make_float4(f[c4 * 4][p], f[c4 * 4 + 1][p], f[c4 * 4 + 2][p], f[c4 * 4 + 3][p]);
-                }
-            __builtin_amdgcn_wave_barrier();
-#pragma unroll
-            for (int j = 0; j < 8; ++j) {
-                const int qq = j * 64 + lane, r = qq >> 3;
-                const float4 v = st[r * 8 + ((qq & 7) ^ (r & 7))];
-                if (wave_first + r < row_end)
-                    store4<NT>(feats + (wave_first + r) * 64 + half * 32 + (qq & 7) * 4, v);
-            }
-            __builtin_amdgcn_wave_barrier();
-        }
-    }
+    if (feats != nullptr) wave_store_nhwc16_halves<NT>(stage[wave], f, feats, lane, wave_first, row_end);
     if (logits == nullptr || !active) return;
     const int64_t pix = (int64_t)Y * W + 4 * q;
 #pragma unroll 4
@@ -417,7 +422,7 @@ __global__ __launch_bounds__(256) void proto_dist_fwd_c16_kernel(const float* __
                                                                  uint8_t* __restrict__ argmax,
                                                                  float* __restrict__ dissum, int B, int64_t HW) {
     constexpr int C = 16, K = 16;
-    __shared__ __attribute__((aligned(16))) float4 stage[4][1024];      // per wave: 256 px x 64 B
+    __shared__ __attribute__((aligned(16))) float4 stage[4][512];       // per wave: 64 lanes x 2 px x 64 B (two halves)
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int64_t groups_per_img = HW / 4;
     const int64_t total = (int64_t)B * groups_per_img;
@@ -433,32 +438,8 @@ __global__ __launch_bounds__(256) void proto_dist_fwd_c16_kernel(const float* __
         const float4 t = *reinterpret_cast<const float4*>(x + (b * C + c) * HW + pix);
         f[c][0] = t.x; f[c][1] = t.y; f[c][2] = t.z; f[c][3] = t.w;
     }
-    if (feats != nullptr) {
-        float4* st = stage[wave];
-#pragma unroll
-        for (int p = 0; p < 4; ++p)
-#pragma unroll
-            for (int c4 = 0; c4 < 4; ++c4) {
-                const int chunk = p * 4 + c4;                             // 16-byte chunk inside the lane's 256 B
-                st[lane * 16 + (chunk ^ (lane & 15))] =
-                    make_float4(f[c4 * 4][p], f[c4 * 4 + 1][p], f[c4 * 4 + 2][p], f[c4 * 4 + 3][p]);
-            }
-        __builtin_amdgcn_wave_barrier();
-        // a wave's 256 pixels are contiguous in NHWC only if they belong to one image: handle per 16-byte chunk
-#pragma unroll
-        for (int j = 0; j < 16; ++j) {
-            const int q = j * 64 + lane;                                  // chunk index in the wave's 16 KB image
-            const int r = q >> 4;                                         // source lane (row of 256 B)
-            const float4 v = st[r * 16 + ((q & 15) ^ (r & 15))];
-            const int64_t grp = wave_first + r;                           // pixel group that row came from
-            if (grp < total) {
-                const int64_t gb = grp / groups_per_img;
-                const int64_t gpix = (grp - gb * groups_per_img) * 4;
-                float* dst = feats + (gb * HW + gpix) * C + (q & 15) * 4;
-                store4<NT>(dst, v);
-            }
-        }
-    }
+    // NHWC features: pixel group g of the flattened (image, pixel / 4) order sits at feats + g * 64 floats
+    if (feats != nullptr) wave_store_nhwc16_halves<NT>(stage[wave], f, feats, lane, wave_first, total);
     float best[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sum[4] = {0.f, 0.f, 0.f, 0.f};
     int bi[4] = {0, 0, 0, 0};
 #pragma unroll 4
@@ -926,6 +907,11 @@ __global__ __launch_bounds__(256) void head_bwd_fused_c16_kernel(
             const int p_lo = (g == 0) ? 2 : 0, p_hi = (g == HB_GRPS - 1) ? 2 : 4;
             const float* frow = feats + (((int64_t)b * H + Y) * W + 4 * q) * C;
             const int64_t* lrow = labels + ((int64_t)b * H + Y) * W + 4 * q;
+            // the next pixel's features / label are requested before the current pixel's ~1000 VALU instructions
+            float4 nf[4];
+            int64_t nlab = lrow[p_lo];
+#pragma unroll
+            for (int c4 = 0; c4 < 4; ++c4) nf[c4] = *reinterpret_cast<const float4*>(frow + p_lo * C + c4 * 4);
 #pragma unroll 1
             for (int p = p_lo; p < p_hi; ++p) {
                 // keep the prototype loads (256 wave-uniform scalars) inside the iteration, 4 prototypes at a time:
@@ -933,11 +919,15 @@ __global__ __launch_bounds__(256) void head_bwd_fused_c16_kernel(
                 asm volatile("" ::: "memory");
                 float f[C];
 #pragma unroll
-                for (int c = 0; c < C; c += 4) {
-                    const float4 v = *reinterpret_cast<const float4*>(frow + p * C + c);
-                    f[c] = v.x; f[c + 1] = v.y; f[c + 2] = v.z; f[c + 3] = v.w;
+                for (int c4 = 0; c4 < 4; ++c4) {
+                    f[c4 * 4] = nf[c4].x; f[c4 * 4 + 1] = nf[c4].y; f[c4 * 4 + 2] = nf[c4].z; f[c4 * 4 + 3] = nf[c4].w;
                 }
-                const int64_t lab = lrow[p];
+                const int64_t lab = nlab;
+                if (p + 1 < p_hi) {
+                    nlab = lrow[p + 1];
+#pragma unroll
+                    for (int c4 = 0; c4 < 4; ++c4) nf[c4] = *reinterpret_cast<const float4*>(frow + (p + 1) * C + c4 * 4);
+                }
                 float lg[K];
                 float mx = -INFINITY;
 #pragma unroll 4
