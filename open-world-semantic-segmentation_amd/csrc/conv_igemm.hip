@@ -689,8 +689,8 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN, int MODE, int NST>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
+template <int BN, int MODE, int NST, int WPE = 3>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
                                                                   const uint32_t w_bytes) {
     typedef bf16_t T;
     constexpr int BM = 128, LA = NST - 1;
@@ -797,8 +797,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
 
     const int lr = lane & 15, lq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
-        if (LA > 2 && kt + 2 < KT) wait_vmcnt<(LA > 2 ? 2 : 1) * NI>();
-        else if (kt + 1 < KT) wait_vmcnt<NI>();
+        // tiles kt .. min(kt + LA - 1, KT - 1) are in flight; tile kt must have landed
+        if (LA > 2 && kt + 2 < KT) wait_vmcnt<(LA > 2 ? 2 : 0) * NI>();
+        else if (LA > 1 && kt + 1 < KT) wait_vmcnt<(LA > 1 ? 1 : 0) * NI>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
         if (kt + LA < KT) issue(kt + LA, (kt + LA) % NST);
@@ -1347,7 +1348,15 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // training grids are all larger)
             static const int narrow_below = getenv("DML_CONV_NARROW_BELOW") ? atoi(getenv("DML_CONV_NARROW_BELOW")) : 200;
             const bool narrow = a.nblk_m * ((a.N + 127) / 128) < narrow_below;
-            if (a.N > 64 && !narrow) {
+            // short K loops (1x1 convolutions over <= 256 channels: 2-8 K steps) are dominated by the latency of the first
+            // loads and of the epilogue's stores; a 2-stage ring (32 KB) and a 128-register budget put four workgroups on a
+            // CU instead of three to cover it (tools/bench_conv.py; DML_CONV_SMALLK=0 switches it off)
+            static const int smallk = getenv("DML_CONV_SMALLK") ? atoi(getenv("DML_CONV_SMALLK")) : 0;
+            if (a.N > 64 && !narrow && smallk > 0 && a.Ktot <= smallk) {
+                a.nblk_n = (a.N + 127) / 128;
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 2, 4>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
+                                   (uint32_t)xb, (uint32_t)wb);
+            } else if (a.N > 64 && !narrow) {
                 a.nblk_n = (a.N + 127) / 128;
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
                                    (uint32_t)xb, (uint32_t)wb);

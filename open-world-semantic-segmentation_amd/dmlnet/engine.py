@@ -1097,6 +1097,8 @@ class Engine:
 
     def side_stream(self, device):
         if device not in self._side:
+            # (stream priorities were tried: this runtime offers {normal, high} only, and neither a high-priority main
+            # stream nor a high-priority side stream changed the step time -- tools/ab_bench.sh)
             self._side[device] = torch.cuda.Stream(device=device)
         return self._side[device]
 
