@@ -81,6 +81,16 @@ typedef struct DmlConvDesc {
     const float* post_mean;
     const void* post_res;
     int32_t post_ldres, post_relu;
+    /* optional (bf16, LDS-DMA kernel): balance a launch whose tile count leaves the last round of workgroups mostly
+     * empty (576 tiles of 128 x 128 on 256 CUs x 3 slots: a quarter of the CUs carry three tiles, the rest two).  The
+     * tiles beyond the last multiple of the CU count are split along K into q workgroups each, so that every CU gets
+     * the same share; the parts park their fp32 accumulators in tail_ws ([tiles][q][128*128] floats) and the part that
+     * finishes last (agent-scope release / acquire around a counter in tail_counters, zero on entry, reset on exit) adds
+     * them in part order and runs the epilogue.  NULL = never split. */
+    float* tail_ws;
+    int64_t tail_ws_elems;
+    int32_t* tail_counters;
+    int32_t tail_counters_len, tail_reserved;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */

@@ -50,6 +50,12 @@ struct ConvArgs {
     const float* post_mean;
     const void* post_res;
     int post_ldres, post_relu;
+    // K-split of the remainder tiles (DmlConvDesc::tail_*): tiles >= tail_full are computed by tail_q workgroups each
+    float* tail_ws;
+    int* tail_cnt;
+    int tail_full, tail_q;
+    int64_t tail_ws_elems_;      // host side only: capacities of the two buffers
+    int tail_cnt_len_;
 };
 
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
@@ -705,7 +711,20 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave >> 1, wn = wave & 1;
-    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    // whole tiles first (XCD-aware order), then the K-split parts of the remainder tiles
+    int tile, kpart = 0, kparts = 1;
+    if (a.tail_q > 1) {
+        if ((int)blockIdx.x < a.tail_full) {
+            tile = xcd_remap(blockIdx.x, a.tail_full);
+        } else {
+            const int part = (int)blockIdx.x - a.tail_full;
+            tile = a.tail_full + part / a.tail_q;
+            kpart = part - (tile - a.tail_full) * a.tail_q;
+            kparts = a.tail_q;
+        }
+    } else {
+        tile = xcd_remap(blockIdx.x, gridDim.x);
+    }
     const int blk_m = tile / a.nblk_n, blk_n = tile - blk_m * a.nblk_n;
     const int m0 = blk_m * BM, n0 = blk_n * BN;
 
@@ -761,7 +780,15 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
         b_off[jj] = n < a.N ? (uint32_t)(((int64_t)n * a.Ktot + bchunk * 8) * 2) : OOB;
     }
 
+    const int KTall = a.Ktot / BK;
+    const int kbeg = (int)((int64_t)kpart * KTall / kparts), kend = (int)((int64_t)(kpart + 1) * KTall / kparts);
     int ir = 0, is = 0, ic0 = 0;       // filter tap / channel offset of the next tile to issue
+    if (kbeg > 0) {
+        const int per_tap = a.C / BK, tap = kbeg / per_tap;
+        ic0 = (kbeg - tap * per_tap) * BK;
+        ir = tap / a.S;
+        is = tap - ir * a.S;
+    }
     auto issue = [&](int kt, int stage) {
         T* sbase = smem + stage * STAGE;
         const uint32_t tapbit = 1u << (ir * a.S + is);
@@ -790,10 +817,10 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int KT = a.Ktot / BK;
+    const int KT = kend - kbeg;
 #pragma unroll
     for (int t = 0; t < LA; ++t)
-        if (t < KT) issue(t, t);
+        if (t < KT) issue(kbeg + t, t);
 
     const int lr = lane & 15, lq = lane >> 4;
     for (int kt = 0; kt < KT; ++kt) {
@@ -802,7 +829,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
         else if (LA > 1 && kt + 1 < KT) wait_vmcnt<(LA > 1 ? 1 : 0) * NI>();
         else wait_vmcnt<0>();
         __builtin_amdgcn_s_barrier();
-        if (kt + LA < KT) issue(kt + LA, (kt + LA) % NST);
+        if (kt + LA < KT) issue(kbeg + kt + LA, (kt + LA) % NST);
         const T* as = smem + (kt % NST) * STAGE + (wm * TM) * BK;
         const T* bs = smem + (kt % NST) * STAGE + BM * BK + (wn * TN) * BK;
         mfma_bf16x8 bf[NT], af[MT];
@@ -826,6 +853,48 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+    if (kparts > 1) {
+        // K-split remainder tile: park this part's fp32 accumulators (lane-linear: one 4 KB row per (i, j)), publish,
+        // and let the part that arrives last add all parts in part order -- deterministic -- and finish the tile.
+        // Hand-off per cdna_hip_programming.md (split-K seam): plain stores, drained, workgroup barrier, lane 0:
+        // agent-scope release + drained again + relaxed ticket; the last arriver: agent-scope acquire, barrier, plain loads.
+        const int rt = tile - a.tail_full;
+        float* slab = a.tail_ws + ((int64_t)rt * kparts + kpart) * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                *reinterpret_cast<f32x4*>(slab + ((i * MT + j) * NTHREADS + tid) * 4) = acc[i][j];
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        int* flag = reinterpret_cast<int*>(smem);            // the operand ring is free now
+        if (tid == 0) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            const int ticket = __hip_atomic_fetch_add(a.tail_cnt + rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (ticket == kparts - 1) {
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+                __hip_atomic_store(a.tail_cnt + rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
+            }
+            *flag = ticket;
+        }
+        __syncthreads();
+        if (*flag != kparts - 1) return;
+        const float* base = a.tail_ws + (int64_t)rt * kparts * (BM * BN);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int p = 0; p < kparts; ++p) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)p * (BM * BN) + ((i * MT + j) * NTHREADS + tid) * 4);
+                    acc[i][j] += v;
+                }
+        }
+    }
     conv_epilogue<T, NT, MT, MODE>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
 }
 
@@ -1352,7 +1421,31 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // loads and of the epilogue's stores; a 2-stage ring (32 KB) and a 128-register budget put four workgroups on a
             // CU instead of three to cover it (tools/bench_conv.py; DML_CONV_SMALLK=0 switches it off)
             static const int smallk = getenv("DML_CONV_SMALLK") ? atoi(getenv("DML_CONV_SMALLK")) : 0;
-            if (a.N > 64 && !narrow && smallk > 0 && a.Ktot <= smallk) {
+            // tiles of the partially filled last round, split along K (DmlConvDesc::tail_*): when the remainder is at most
+            // half a round of the CUs, q = CUs / remainder parts per tile give every CU the same share
+            a.tail_full = 0;
+            a.tail_q = 1;
+            static const bool tail_on = getenv("DML_CONV_TAIL") ? atoi(getenv("DML_CONV_TAIL")) != 0 : true;
+            if (tail_on && a.tail_ws != nullptr && a.N > 64 && !narrow) {
+                constexpr int CUS = 256;
+                const int ntiles = a.nblk_m * ((a.N + 127) / 128), full = ntiles / CUS * CUS, rem = ntiles - full;
+                if (full >= CUS && full <= 6 * CUS && rem > 0 && rem <= CUS / 2) {
+                    int q = CUS / rem;
+                    if (q > 8) q = 8;
+                    const int KTall = a.Ktot / BK;
+                    while (q > 1 && KTall / q < 6) --q;
+                    if (q > 1 && (int64_t)rem * q * 128 * 128 <= base.tail_ws_elems_ && rem <= base.tail_cnt_len_) {
+                        a.tail_full = full;
+                        a.tail_q = q;
+                    }
+                }
+            }
+            if (a.tail_q > 1) {
+                a.nblk_n = (a.N + 127) / 128;
+                const int ntiles = a.nblk_m * a.nblk_n;
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3>), dim3(a.tail_full + (ntiles - a.tail_full) * a.tail_q),
+                                   dim3(NTHREADS), 0, st, a, (uint32_t)xb, (uint32_t)wb);
+            } else if (a.N > 64 && !narrow && smallk > 0 && a.Ktot <= smallk) {
                 a.nblk_n = (a.N + 127) / 128;
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 2, 4>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
                                    (uint32_t)xb, (uint32_t)wb);
@@ -1412,6 +1505,12 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.bnr_ldy = 0; a.bnr_relu = 0;
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
+    a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
+    if (d->tail_ws && d->tail_counters && d->tail_ws_elems > 0 && d->tail_counters_len > 0) {
+        if (reinterpret_cast<uintptr_t>(d->tail_ws) & 15) return DML_EALIGN;
+        a.tail_ws = d->tail_ws; a.tail_cnt = d->tail_counters;
+        a.tail_ws_elems_ = d->tail_ws_elems; a.tail_cnt_len_ = d->tail_counters_len;
+    }
     if (d->post_scale) {
         if (d->mode != 0 || !d->post_shift || !d->post_mean || d->stats || d->bias || d->accum || d->y_f32) return DML_EINVAL;
         if (d->post_res && (d->post_ldres % vec || (reinterpret_cast<uintptr_t>(d->post_res) & 15))) return DML_EALIGN;
@@ -1461,6 +1560,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.bnr_ldy = 0; a.bnr_relu = 0;
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
+    a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -34,7 +34,10 @@ class ConvDesc(C.Structure):
                 ("bnr_ldy", C.c_int32), ("bnr_relu", C.c_int32),
                 # mode 0: inference epilogue BN(running stats) + residual + ReLU (see the header)
                 ("post_scale", c_p), ("post_shift", c_p), ("post_mean", c_p), ("post_res", c_p),
-                ("post_ldres", C.c_int32), ("post_relu", C.c_int32)]
+                ("post_ldres", C.c_int32), ("post_relu", C.c_int32),
+                # K-split of the tiles of a partially filled last round (see the header)
+                ("tail_ws", c_p), ("tail_ws_elems", C.c_int64), ("tail_counters", c_p),
+                ("tail_counters_len", C.c_int32), ("tail_reserved", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 22

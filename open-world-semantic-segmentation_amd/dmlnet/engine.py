@@ -325,6 +325,10 @@ class Plan:
         self.sp = self.scratch.data_ptr()
         # split-K partials of the weight gradients (one launch at a time uses it: all of them run on one stream)
         self.wgrad_ws = torch.empty(64 * (1 << 20) if training else 1, dtype=torch.float32, device=self.device)
+        # K-split of partially filled last rounds in the main-stream convolutions (DmlConvDesc.tail_*): one workspace and
+        # one counter array for the whole plan (the launches that use them are serialised on the caller's stream)
+        self.tail_ws = torch.empty(256 * 128 * 128 if training else 1, dtype=torch.float32, device=self.device)
+        self.tail_cnt = torch.zeros(128, dtype=torch.int32, device=self.device)
         self.group_wgrad = os.environ.get("DML_GROUP_WGRAD", "1") != "0"
         self.group_tiles = int(os.environ.get("DML_GROUP_TILES", "48"))     # 256 x 256 output tiles per grouped launch
         self._wg_pending = []
@@ -421,6 +425,9 @@ class Plan:
                        pre_shift=None, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
                        N=N or conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
                        y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
+        if self.training:
+            dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
+            dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
         if post is not None:            # inference epilogue: BN(running stats) + residual + ReLU (DmlConvDesc.post_*)
             scale, shift, mean, res, relu = post
             dsc.post_scale, dsc.post_shift, dsc.post_mean = scale.data_ptr(), shift.data_ptr(), mean.data_ptr()
@@ -438,6 +445,8 @@ class Plan:
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
                        accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
         x.root.grad_init = True
+        dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
+        dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
         self.keep.append(dsc)
         self.call(self.bwd, self.lib.dml_conv_igemm, C.byref(dsc))
         self.last_dgrad.pop(self.grad_of(x.root).ptr, None)

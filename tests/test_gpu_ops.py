@@ -874,3 +874,69 @@ def test_upsample_dist_exact_x4_staged_and_gathered(lib, geom, monkeypatch):
     chk(lib.dml_upsample_dist_fwd(ed.data_ptr(), pr.data_ptr(), lg2.data_ptr(), None, None, None, B, h, w, K, K, Hh, Ww, st()))
     torch.cuda.synchronize()
     assert torch.equal(lg2, lg)
+
+
+TAIL_CASES = [
+    # name, B, H, W, Cin, Cout, k, dil   -> tiles of 128 x 128, remainder beyond the last multiple of 256, parts
+    ("3x3_288tiles", 2, 96, 96, 256, 256, 3, 1),          # 288 tiles: 32 remainder tiles x 8 parts
+    ("1x1_k1024_320tiles", 2, 80, 128, 1024, 256, 1, 1),  # 320 tiles: 64 x 4
+    ("3x3_d2_576", 4, 96, 96, 128, 256, 3, 2),            # 576 tiles: 64 x 4, K = 1152
+    ("1x1_n512_360", 1, 96, 120, 256, 512, 1, 1),         # 90 x 4 = 360 tiles: 104 remainder x 2 parts, K loop of 8 steps
+]
+
+
+@pytest.mark.parametrize("case", TAIL_CASES, ids=[c[0] for c in TAIL_CASES])
+def test_conv_tail_split_k(lib, case):
+    """DmlConvDesc.tail_*: the tiles of a partially filled last round are computed by q workgroups each (split along K,
+    fp32 partials parked in the workspace, the last arriver adds them in part order and runs the epilogue).  Forward with
+    the fused BN statistics and the data gradient with accumulate, bf16, against F.conv2d on the same rounded operands;
+    twice in a row (the counters reset themselves) and bit-identical to the unsplit launch's statistics path."""
+    name, B, Hh, Ww, Cin, Cout, k, dil = case
+    dt, tdt = 1, torch.bfloat16
+    x = qz(rnd("tail.x" + name, (B, Cin, Hh, Ww)), tdt).requires_grad_(True)
+    w = qz(rnd("tail.w" + name, (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5), tdt).requires_grad_(True)
+    y_ref, pad = conv_ref(x, w, k, 1, dil)
+    gy = qz(rnd("tail.gy" + name, tuple(y_ref.shape)), tdt)
+    y_ref.backward(gy)
+    xd = nhwc(x.detach(), tdt)
+    wd = w.detach().permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
+    wtd = w.detach().permute(1, 2, 3, 0).contiguous().to("cuda", tdt)
+    M = B * Hh * Ww
+    ws = torch.full((256 * 128 * 128,), float("nan"), device="cuda")
+    cnt = torch.zeros(128, dtype=torch.int32, device="cuda")
+
+    def run(desc, out, use_tail):
+        desc.tail_ws, desc.tail_ws_elems = (ws.data_ptr(), ws.numel()) if use_tail else (None, 0)
+        desc.tail_counters, desc.tail_counters_len = (cnt.data_ptr(), cnt.numel()) if use_tail else (None, 0)
+        out.fill_(float("nan"))
+        chk(lib.dml_conv_igemm(C.byref(desc), st()))
+        torch.cuda.synchronize()
+        return out.clone()
+
+    yd = torch.empty((B, Hh, Ww, Cout), device="cuda", dtype=tdt)
+    stats = torch.zeros((M + 63) // 64 * Cout * 2, device="cuda")
+    d = make_desc(lib, xd, wd, yd, B, Hh, Ww, Cin, Hh, Ww, Cout, k, 1, dil, pad, dt, stats=stats)
+    y_plain = run(d, yd, False)
+    st_plain = stats.clone()
+    for rep in range(2):
+        stats.zero_()
+        y_tail = run(d, yd, True)
+        assert int(cnt.abs().sum()) == 0                               # counters back to zero
+        relclose(nchw(y_tail), y_ref.detach(), 1e-2, "tail fwd %s (run %d)" % (name, rep))
+        # same accumulation order per K part => at most one bf16 ulp from the unsplit result, statistics alike
+        relclose(y_tail.float(), y_plain.float(), 2.0 ** -7, "tail vs plain fwd " + name)
+        relclose(stats, st_plain, 1e-3, "tail statistics " + name)
+    assert not torch.isnan(ws[:128 * 128]).any()                       # the workspace was really used
+    # data gradient, accumulating into an initialised buffer
+    gyd = nhwc(gy, tdt)
+    dxd = torch.empty((B, Hh, Ww, Cin), device="cuda", dtype=tdt)
+    dd = make_desc(lib, gyd, wtd, dxd, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, dil, pad, dt, mode=1)
+    g_tail = run(dd, dxd, True)
+    relclose(nchw(g_tail), x.grad, 1e-2, "tail dgrad " + name)
+    dd.accum = 1
+    dd.tail_ws, dd.tail_ws_elems, dd.tail_counters, dd.tail_counters_len = ws.data_ptr(), ws.numel(), cnt.data_ptr(), cnt.numel()
+    dxd.copy_(g_tail)
+    chk(lib.dml_conv_igemm(C.byref(dd), st()))
+    torch.cuda.synchronize()
+    relclose(nchw(dxd), 2 * x.grad, 2e-2, "tail dgrad accum " + name)
+    assert int(cnt.abs().sum()) == 0
