@@ -856,31 +856,31 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
     if (kparts > 1) {
         // K-split remainder tile: park this part's fp32 accumulators (lane-linear: one 4 KB row per (i, j)), publish,
         // and let the part that arrives last add all parts in part order -- deterministic -- and finish the tile.
-        // Hand-off per cdna_hip_programming.md (split-K seam): plain stores, drained, workgroup barrier, lane 0:
-        // agent-scope release + drained again + relaxed ticket; the last arriver: agent-scope acquire, barrier, plain loads.
         const int rt = tile - a.tail_full;
-        float* slab = a.tail_ws + ((int64_t)rt * kparts + kpart) * (BM * BN);
+        // write-through (sc1) slab stores and sc1 loads instead of release / acquire fences: a release fence writes back
+        // every dirty line of this XCD's L2 -- the other workgroups' output tiles included (first version: -2.3 % on the
+        // whole step).  cdna_hip_programming.md, split-K seam: sc1 stores -> drained -> barrier -> relaxed ticket; the
+        // last arriver reads with sc1 loads.
+        typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+        const __amdgpu_buffer_rsrc_t rs_ws = __builtin_amdgcn_make_buffer_rsrc(
+            a.tail_ws + (int64_t)rt * kparts * (BM * BN), 0, kparts * BM * BN * 4, 0x00020000);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j)
-                *reinterpret_cast<f32x4*>(slab + ((i * MT + j) * NTHREADS + tid) * 4) = acc[i][j];
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs_ws,
+                                                       (kpart * BM * BN + ((i * MT + j) * NTHREADS + tid) * 4) * 4, 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);            // the operand ring is free now
         if (tid == 0) {
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             const int ticket = __hip_atomic_fetch_add(a.tail_cnt + rt, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            if (ticket == kparts - 1) {
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+            if (ticket == kparts - 1)
                 __hip_atomic_store(a.tail_cnt + rt, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next launch
-            }
             *flag = ticket;
         }
         __syncthreads();
         if (*flag != kparts - 1) return;
-        const float* base = a.tail_ws + (int64_t)rt * kparts * (BM * BN);
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -890,8 +890,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
-                    const f32x4 v = *reinterpret_cast<const f32x4*>(base + (int64_t)p * (BM * BN) + ((i * MT + j) * NTHREADS + tid) * 4);
-                    acc[i][j] += v;
+                    const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
+                        rs_ws, (p * BM * BN + ((i * MT + j) * NTHREADS + tid) * 4) * 4, 0, 16);
+                    acc[i][j] += __builtin_bit_cast(f32x4, v);
                 }
         }
     }

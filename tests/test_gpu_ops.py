@@ -881,7 +881,7 @@ TAIL_CASES = [
     ("3x3_288tiles", 2, 96, 96, 256, 256, 3, 1),          # 288 tiles: 32 remainder tiles x 8 parts
     ("1x1_k1024_320tiles", 2, 80, 128, 1024, 256, 1, 1),  # 320 tiles: 64 x 4
     ("3x3_d2_576", 4, 96, 96, 128, 256, 3, 2),            # 576 tiles: 64 x 4, K = 1152
-    ("1x1_n512_360", 1, 96, 120, 256, 512, 1, 1),         # 90 x 4 = 360 tiles: 104 remainder x 2 parts, K loop of 8 steps
+    ("1x1_n512_360", 1, 96, 120, 512, 512, 1, 1),         # 90 x 4 = 360 tiles: 104 remainder x 2 parts, 16 K steps
 ]
 
 
