@@ -926,7 +926,9 @@ def test_conv_tail_split_k(lib, case):
         # same accumulation order per K part => at most one bf16 ulp from the unsplit result, statistics alike
         relclose(y_tail.float(), y_plain.float(), 2.0 ** -7, "tail vs plain fwd " + name)
         relclose(stats, st_plain, 1e-3, "tail statistics " + name)
-    assert not torch.isnan(ws[:128 * 128]).any()                       # the workspace was really used
+    import os
+    if not os.environ.get("DML_CONV_V1") and os.environ.get("DML_CONV_TAIL", "1") != "0":
+        assert not torch.isnan(ws[:128 * 128]).any()                   # the LDS-DMA kernel really split the tail tiles
     # data gradient, accumulating into an initialised buffer
     gyd = nhwc(gy, tdt)
     dxd = torch.empty((B, Hh, Ww, Cin), device="cuda", dtype=tdt)
