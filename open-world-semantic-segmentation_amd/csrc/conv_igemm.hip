@@ -1102,6 +1102,151 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 weight gradient for N <= 64 output channels (layer1's 3x3 and 1x1 convolutions, the stem, the 48- and
+// 16-channel head convolutions): tile 64 (n) x 256 (kc), 4 waves side by side along kc (wave tile 64 x 64).  In the
+// 128 x 128 kernel half of every MFMA row block is padding for these layers and two of the four waves idle; here all
+// four compute.  Same LDS image (16-column sub-tiles read with ds_read_b64_tr_b16), same split-K / workspace scheme.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) void conv_wgrad_n64_kernel(const WgradArgs a) {
+    typedef bf16_t T;
+    constexpr int TN = 64, TK = 256, VEC = 8;
+    constexpr int SUB = 528;                       // elements per 16-column sub-tile (32 k rows x 16 + pad)
+    constexpr int YS = (TN / 16) * SUB, XS = (TK / 16) * SUB;
+    constexpr int NT = 4, MT = 4;
+
+    __shared__ __attribute__((aligned(16))) T smem[2 * (YS + XS)];
+    auto Ys = [&](int buf) -> T* { return smem + buf * (YS + XS); };
+    auto Xs = [&](int buf) -> T* { return smem + buf * (YS + XS) + YS; };
+
+    const int tid = threadIdx.x, lane = tid & 63, wk = tid >> 6;
+    const int ntile = a.nblk_k;                    // one n tile
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntile, blk_k = logical - split * ntile;
+    const int kc0 = blk_k * TK;
+
+    const T* __restrict__ X = static_cast<const T*>(a.x);
+    const T* __restrict__ DY = static_cast<const T*>(a.dy);
+
+    // dy: 32 rows x 8 vectors = one 16-byte load per thread; x: 32 rows x 32 vectors = four per thread
+    const int yv = tid & 7, yrow = tid >> 3;
+    const int yn = yv * VEC;
+    const bool yn_ok = yn < a.N;
+    const int xv = tid & 31, xrow0 = tid >> 5;      // rows xrow0 + 8 j
+    const int kc = kc0 + xv * VEC;
+    const bool kc_ok = kc < a.Ktot;
+    const uint32_t tap = fdiv((uint32_t)(kc_ok ? kc : 0), a.div_c);
+    const int xc = (kc_ok ? kc : 0) - (int)tap * a.C;
+    const int tr = (int)tap / a.S, ts = (int)tap - tr * a.S;
+    const int dyo = tr * a.dil - a.pad, dxo = ts * a.dil - a.pad;
+
+    const int tile_beg = split * a.slab_tiles;
+    const int tiles_total = (a.M + BK - 1) / BK;
+    const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
+    const bool lin1x1 = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
+
+    uint4 y_reg, x_reg[4];
+    auto load_tiles = [&](int t) {
+        {
+            const int m = t * BK + yrow;
+            y_reg = make_uint4(0, 0, 0, 0);
+            if (m < a.M && yn_ok) y_reg = *reinterpret_cast<const uint4*>(DY + (int64_t)m * a.ldy + yn);
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int m = t * BK + xrow0 + j * 8;
+            uint4 xv4 = make_uint4(0, 0, 0, 0);
+            if (m < a.M && kc_ok) {
+                if (lin1x1) {
+                    xv4 = *reinterpret_cast<const uint4*>(X + (int64_t)m * a.ldx + xc);
+                } else {
+                    const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+                    const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+                    const uint32_t yo = fdiv(rem, a.div_wo);
+                    const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+                    const int ys = (int)yo * a.stride + dyo, xs = (int)xo * a.stride + dxo;
+                    if ((unsigned)ys < (unsigned)a.Hi && (unsigned)xs < (unsigned)a.Wi)
+                        xv4 = *reinterpret_cast<const uint4*>(X + ((int64_t)((int)b * a.Hi + ys) * a.Wi + xs) * a.ldx + xc);
+                }
+            }
+            x_reg[j] = xv4;
+        }
+    };
+    // sub-tile image [col/16][k'][16], k rows stored with bits 2/3 swapped (conflict-free for the transpose reads and
+    // for these 16-byte writes) -- as in conv_wgrad_kernel
+    auto row_pos = [](int row) { return (row & 0x13) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 3); };
+    auto store_tiles = [&](int buf) {
+        *reinterpret_cast<uint4*>(Ys(buf) + (yv >> 1) * SUB + row_pos(yrow) * 16 + (yv & 1) * 8) = y_reg;
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            *reinterpret_cast<uint4*>(Xs(buf) + (xv >> 1) * SUB + row_pos(xrow0 + j * 8) * 16 + (xv & 1) * 8) = x_reg[j];
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    if (tile_beg < tile_end) {
+        load_tiles(tile_beg);
+        store_tiles(0);
+    }
+    __syncthreads();
+
+    const int lr = lane & 15, lq = lane >> 4;
+    const int p_lo = ((lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4)) * 16 + (lr & 3) * 4;
+    const int p_hi = p_lo + 8 * 16;
+    int cur = 0;
+    for (int t = tile_beg; t < tile_end; ++t) {
+        const bool has_next = t + 1 < tile_end;
+        if (has_next) load_tiles(t + 1);
+        const T* ys = Ys(cur);
+        const T* xs = Xs(cur) + wk * 4 * SUB;
+        mfma_bf16x8 af[NT], bfr[MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            const bf16x4 lo = lds_tr16_b64(ys + i * SUB + p_lo);
+            const bf16x4 hi = lds_tr16_b64(ys + i * SUB + p_hi);
+            bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            af[i] = __builtin_bit_cast(mfma_bf16x8, v);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            const bf16x4 lo = lds_tr16_b64(xs + j * SUB + p_lo);
+            const bf16x4 hi = lds_tr16_b64(xs + j * SUB + p_hi);
+            bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+            bfr[j] = __builtin_bit_cast(mfma_bf16x8, v);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+        if (has_next) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    // acc[i][j][q] = dw[n = i*16 + lq*4 + q][kc = kc0 + wk*64 + j*16 + lr]
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = i * 16 + lq * 4 + q;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int k = kc0 + wk * 64 + j * 16 + lr;
+                if (k < a.Ktot) {
+                    if (a.ws != nullptr)
+                        a.ws[((int64_t)split * a.N + n) * a.Ktot + k] = acc[i][j][q];
+                    else
+                        atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q]);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 weight gradient, large tile: 256 (n) x 256 (kc) per 512-thread workgroup, 8 waves as 2 (n) x 4 (kc), wave
 // tile 128 x 64 = 32 MFMAs per 32-pixel K step.  Why: the 128 x 128 kernel moves 16 KB through the CU's vector
 // memory pipeline (64 B/clk) and 48 KB through LDS per 64 MFMAs -- both as busy as the matrix cores, so none of
@@ -1672,11 +1817,29 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         return 0;
     }
     a.ws = use_ws ? d->ws : nullptr;
+    // N <= 64 (bf16): 64 x 256 tiles instead of half-empty 128 x 128 ones
+    static const bool n64_on = getenv("DML_WGRAD_N64") ? atoi(getenv("DML_WGRAD_N64")) != 0 : true;
+    const bool n64 = n64_on && d->dtype == DML_BF16 && a.N <= 64;
+    if (n64) {
+        a.nblk_n = 1;
+        a.nblk_k = (a.Ktot + 255) / 256;
+        if (d->splitk <= 0) {
+            const int base = a.nblk_k;
+            splitk = use_ws ? (512 + base - 1) / base : (1024 + base - 1) / base;
+            if (use_ws && tiles / 48 > splitk) splitk = tiles / 48;
+            const int cap = (tiles + 7) / 8;
+            if (splitk > cap) splitk = cap;
+            if (splitk < 1) splitk = 1;
+            if (use_ws && (int64_t)splitk * plane > d->ws_elems) splitk = (int)(d->ws_elems / plane);
+        }
+    }
     if (splitk > tiles) splitk = tiles > 0 ? tiles : 1;
     a.slab_tiles = (tiles + splitk - 1) / splitk;
     splitk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
     dim3 grid(a.nblk_n * a.nblk_k * splitk);
-    if (d->dtype == DML_BF16)
+    if (n64)
+        hipLaunchKernelGGL(conv_wgrad_n64_kernel, grid, dim3(NTHREADS), 0, st, a);
+    else if (d->dtype == DML_BF16)
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);
     else
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
