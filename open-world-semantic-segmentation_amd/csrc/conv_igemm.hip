@@ -1819,7 +1819,9 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     a.ws = use_ws ? d->ws : nullptr;
     // N <= 64 (bf16): 64 x 256 tiles instead of half-empty 128 x 128 ones
     static const bool n64_on = getenv("DML_WGRAD_N64") ? atoi(getenv("DML_WGRAD_N64")) != 0 : true;
-    const bool n64 = n64_on && d->dtype == DML_BF16 && a.N <= 64;
+    // (measured, tools/bench_conv.py wgrad at 192 x 192: 3x3 64 -> 64 164 -> 160 us; the 1x1 layers are bound by the
+    // operand loads, not by the idle MFMA rows, and LOSE 20 % with the wider x tile -- they stay on the 128 x 128 kernel)
+    const bool n64 = n64_on && d->dtype == DML_BF16 && a.N <= 64 && a.R * a.S > 1;
     if (n64) {
         a.nblk_n = 1;
         a.nblk_k = (a.Ktot + 255) / 256;
