@@ -695,14 +695,18 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
 typedef __attribute__((address_space(3))) void* lds_ptr_t;
 template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
 
-template <int BN, int MODE, int NST, int WPE = 3>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
+// BM = 128: 4 waves (2 x 2), three workgroups per CU.  BM = 256: 8 waves (4 x 2) on the same 64 x 64 wave tile -- the
+// weight tile is shared by twice the rows, so a K step moves 24 KB into LDS for 2.1 MFLOP (85 FLOP/B against 64) -- two
+// workgroups per CU (72 KB of LDS each, 128-register budget).
+template <int BN, int MODE, int NST, int WPE = 3, int BM = 128>
+__global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(WPE))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
                                                                   const uint32_t w_bytes) {
     typedef bf16_t T;
-    constexpr int BM = 128, LA = NST - 1;
+    constexpr int LA = NST - 1, NTH = BM * 2, WAVES = BM / 32;
     constexpr int STAGE = (BM + BN) * BK;          // elements per ring stage
     constexpr int TM = 64, TN = BN / 2, MT = 4, NT = TN / 16;
-    constexpr int A_I = 2, B_I = BN / 64;           // DMA instructions per wave per tile (1 KiB = 16 rows each)
+    constexpr int A_I = 2, B_I = BN / 16 / WAVES;   // DMA instructions per wave per tile (1 KiB = 16 rows each)
+    static_assert(B_I >= 1, "tile too narrow for this many waves");
     constexpr int NI = A_I + B_I;
     constexpr uint32_t OOB = 0x80000000u;
 
@@ -869,7 +873,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4_t, acc[i][j]), rs_ws,
-                                                       (kpart * BM * BN + ((i * MT + j) * NTHREADS + tid) * 4) * 4, 0, 16);
+                                                       (kpart * BM * BN + ((i * MT + j) * NTH + tid) * 4) * 4, 0, 16);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();
         int* flag = reinterpret_cast<int*>(smem);            // the operand ring is free now
@@ -891,7 +895,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(WPE)))
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const u32x4_t v = __builtin_amdgcn_raw_buffer_load_b128(
-                        rs_ws, (p * BM * BN + ((i * MT + j) * NTHREADS + tid) * 4) * 4, 0, 16);
+                        rs_ws, (p * BM * BN + ((i * MT + j) * NTH + tid) * 4) * 4, 0, 16);
                     acc[i][j] += __builtin_bit_cast(f32x4, v);
                 }
         }
@@ -1585,6 +1589,31 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                         a.tail_q = q;
                     }
                 }
+            }
+            static const int bm256 = getenv("DML_CONV_BM256") ? atoi(getenv("DML_CONV_BM256")) : 0;
+            if (bm256 && a.N >= 128 && !narrow && a.N % 128 == 0) {
+                // 256-row tiles: whole tiles on the first multiple of 256 workgroups, the remainder split along K
+                constexpr int CUS = 256;
+                a.nblk_m = (a.M + 255) / 256;
+                a.nblk_n = a.N / 128;
+                const int ntiles = a.nblk_m * a.nblk_n, full = ntiles / CUS * CUS, rem = ntiles - full;
+                a.tail_full = 0;
+                a.tail_q = 1;
+                if (base.tail_ws != nullptr && full >= CUS && rem > 0 && rem <= CUS / 2) {
+                    int q = CUS / rem;
+                    if (q > 8) q = 8;
+                    const int KTall = a.Ktot / BK;
+                    while (q > 1 && KTall / q < 6) --q;
+                    if (q > 1 && (int64_t)rem * q * 256 * 128 <= base.tail_ws_elems_ && rem <= base.tail_cnt_len_) {
+                        a.tail_full = full;
+                        a.tail_q = q;
+                    }
+                }
+                const int grid = a.tail_q > 1 ? a.tail_full + (ntiles - a.tail_full) * a.tail_q : ntiles;
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3, 4, 256>), dim3(grid), dim3(512), 0, st, a, (uint32_t)xb,
+                                   (uint32_t)wb);
+                DML_LAUNCH_CHECK();
+                return 0;
             }
             if (a.tail_q > 1) {
                 a.nblk_n = (a.N + 127) / 128;
