@@ -178,3 +178,71 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert h["traffic"] is None or h["traffic"] > 0.99 * 192 * 16 * 768 * 768
     assert len(h["step_path"]) >= 2 and all(e["ms"] > 0 and e["bytes_per_px"] > 0 for e in h["step_path"])
     assert d["host_enqueue_ms_per_step"] > 0
+
+
+def test_native_plan_packing_and_dispatch_without_a_gpu():
+    """dml_plan_run / DmlPlanOp on the host side only: entry-point ids, argument packing (pointers, negative ints,
+    floats, doubles, by-reference descriptors, indirect int32), write-through of per-step argument patches, and the
+    failed-op report -- using calls that the entry points reject during argument validation, i.e. before any HIP call."""
+    import ctypes as C
+    import struct
+    from dmlnet import _lib, engine as E
+    lib = _lib.load()
+    assert lib.dml_plan_fn_id(b"dml_fill_f32") >= 0 and lib.dml_plan_fn_id(b"dml_no_such_entry") == -1
+    for name in ("dml_conv_igemm", "dml_conv_wgrad_group", "dml_bn_bwd_apply", "dml_head_bwd_fused", "dml_sgd_step"):
+        fid = lib.dml_plan_fn_id(name.encode())
+        assert fid >= 0 and lib.dml_plan_fn_nargs(fid) == len(getattr(lib, name).argtypes) - 1, name
+    # word packing
+    assert E._pack_word(None, C.c_void_p) == (0, False)
+    assert E._pack_word(-3, C.c_int) == (0xFFFFFFFFFFFFFFFD, False)
+    assert E._pack_word(1.5, C.c_float) == (struct.unpack("<I", struct.pack("<f", 1.5))[0], False)
+    assert E._pack_word(-2.25, C.c_double) == (struct.unpack("<Q", struct.pack("<d", -2.25))[0], False)
+    boxed = C.c_int(7)
+    w, ind = E._pack_word(boxed, C.c_int)
+    assert ind and w == C.addressof(boxed)
+    d = _lib.ConvDesc()
+    assert E._pack_word(C.byref(d), C.c_void_p) == (C.addressof(d), False)
+    # a launch list of three ops that all fail validation before launching anything: the first one must be reported
+    ops = []
+    a0 = E.BoundArgs([None, 16, 1.0])                     # dml_fill_f32(NULL, ...) -> DML_EINVAL
+    ops.append((lib.dml_fill_f32, a0))
+    a1 = E.BoundArgs([None, None, 0, 1, 1])               # dml_convert_dtype(NULL, ...) -> DML_EINVAL
+    ops.append((lib.dml_convert_dtype, a1))
+    nat = E.NativeList(lib, ops)
+    assert nat.arr[0].nargs == 3 and nat.arr[0].args[1] == 16 and nat.arr[1].nargs == 5
+    failed = C.c_int(-1)
+    assert lib.dml_plan_run(nat.arr, 0, 2, None, None, None, 0, C.byref(failed)) == -1 and failed.value == 0
+    assert lib.dml_plan_run(nat.arr, 1, 2, None, None, None, 0, C.byref(failed)) == -1 and failed.value == 1
+    assert lib.dml_plan_run(nat.arr, 1, 1, None, None, None, 0, C.byref(failed)) == 0          # empty range
+    a0[1] = -5                                            # per-step patch: written through to the packed copy
+    assert nat.arr[0].args[1] == 0xFFFFFFFFFFFFFFFB and a0[1] == -5
+    a0[2] = 0.25
+    assert nat.arr[0].args[2] == struct.unpack("<I", struct.pack("<f", 0.25))[0]
+    # a Python step in the list stays outside the native array
+    ops.append((lambda stream: 0, E.BoundArgs()))
+    nat2 = E.NativeList(lib, ops)
+    assert nat2.python_ops == {2} and nat2.arr[2].fn == -1
+    # malformed op -> rejected with its index
+    nat.arr[1].nargs = 4
+    assert lib.dml_plan_run(nat.arr, 1, 2, None, None, None, 0, C.byref(failed)) == -1 and failed.value == 1
+
+
+def test_grouped_weight_gradient_eligibility_is_host_logic():
+    """dml_conv_wgrad_group_eligible decides on the host which layers the plan may put into a grouped launch."""
+    import ctypes as C
+    from dmlnet import _lib
+    lib = _lib.load()
+
+    def desc(**kw):
+        base = dict(x=0x1000, dy=0x2000, dw=0x3000, B=16, Hi=48, Wi=48, C=256, ldx=256, Ho=48, Wo=48, N=256, ldy=256, R=3, S=3,
+                    stride=1, dil=1, pad=1, dtype=1, splitk=0, Cm=0, ws=None, ws_elems=0)
+        base.update(kw)
+        return _lib.WgradDesc(**base)
+
+    assert lib.dml_conv_wgrad_group_eligible(C.byref(desc())) == 1                                  # layer3 3x3
+    assert lib.dml_conv_wgrad_group_eligible(C.byref(desc(C=1024, ldx=1024, R=1, S=1, pad=0))) == 1   # 1x1 1024 -> 256
+    assert lib.dml_conv_wgrad_group_eligible(C.byref(desc(dtype=0))) == 0                           # fp32 plans
+    assert lib.dml_conv_wgrad_group_eligible(C.byref(desc(N=128, ldy=128))) == 0                    # not a whole 256-channel tile
+    assert lib.dml_conv_wgrad_group_eligible(C.byref(desc(C=64, ldx=64, R=1, S=1, pad=0, N=256))) == 0   # one output tile only
+    assert lib.dml_conv_wgrad_group_eligible(C.byref(desc(x=None))) == 0
+    assert lib.dml_conv_wgrad_group(None, 1, None, 0, None) == -1
