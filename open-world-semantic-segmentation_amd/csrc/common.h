@@ -2,6 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <cstdlib>
+
+#ifndef DML_GRID_CAP_DEFAULT
+#define DML_GRID_CAP_DEFAULT 0
+#endif
 #include "../../include/dmlnet_hip.h"
 
 #define DML_LAUNCH_CHECK()                        \
@@ -107,7 +112,11 @@ __device__ __forceinline__ double wave_sum_d(double v) {
     return v;
 }
 
+// Workgroups for a grid-stride streaming kernel.  Caps of 2048 and above are "enough to fill the chip" choices, not
+// buffer sizes; DML_GRID_CAP overrides them (tools: short-lived workgroups stream faster than persistent ones, see bn.hip).
 static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
+    static const int cap_override = getenv("DML_GRID_CAP") ? atoi(getenv("DML_GRID_CAP")) : DML_GRID_CAP_DEFAULT;
+    if (cap_override > 0 && max_blocks >= 2048) max_blocks = cap_override;
     int64_t g = (work_items + block - 1) / block;
     if (g < 1) g = 1;
     if (g > max_blocks) g = max_blocks;

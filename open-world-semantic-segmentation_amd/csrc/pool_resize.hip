@@ -268,6 +268,139 @@ __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const TI* __restrict_
     }
 }
 
+// ---- bf16 -> bf16 fast paths, 16-byte vectors (8 channels) per thread instead of scalar 2-byte accesses
+__global__ __launch_bounds__(256) void bilinear_fwd_bf16v_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ y, int B,
+                                                                 int h, int w, int H, int W, int C, int ldx, int ldy,
+                                                                 float sy, float sx) {
+    const int CV = C / 8;
+    const int64_t total = (int64_t)B * H * W * CV;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int X = (int)(p % W); p /= W;
+    const int Y = (int)(p % H);
+    const int b = (int)(p / H);
+    const Lerp ly = src_index(Y, sy, h), lx = src_index(X, sx, w);
+    const bf16_t* base = x + (int64_t)b * h * w * ldx + cv * 8;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    Vec16<bf16_t>::load(base + ((int64_t)ly.i0 * w + lx.i0) * ldx, v00);
+    Vec16<bf16_t>::load(base + ((int64_t)ly.i0 * w + lx.i1) * ldx, v01);
+    Vec16<bf16_t>::load(base + ((int64_t)ly.i1 * w + lx.i0) * ldx, v10);
+    Vec16<bf16_t>::load(base + ((int64_t)ly.i1 * w + lx.i1) * ldx, v11);
+#pragma unroll
+    for (int q = 0; q < 8; ++q) o[q] = ly.l0 * (lx.l0 * v00[q] + lx.l1 * v01[q]) + ly.l1 * (lx.l0 * v10[q] + lx.l1 * v11[q]);
+    Vec16<bf16_t>::store(y + (((int64_t)b * H + Y) * W + X) * ldy + cv * 8, o);
+}
+
+__global__ __launch_bounds__(256) void bilinear_bwd_bf16v_kernel(const bf16_t* __restrict__ dy, bf16_t* __restrict__ dx, int B,
+                                                                 int h, int w, int H, int W, int C, int lddy, int lddx,
+                                                                 float sy, float sx) {
+    const int CV = C / 8;
+    const int64_t total = (int64_t)B * h * w * CV;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int xs = (int)(p % w); p /= w;
+    const int ys = (int)(p % h);
+    const int b = (int)(p / h);
+    const int Y0 = max(0, (int)floorf(((float)ys - 0.5f) / sy - 0.5f) - 1);
+    const int Y1 = min(H - 1, (int)ceilf(((float)ys + 1.5f) / sy - 0.5f) + 1);
+    const int X0 = max(0, (int)floorf(((float)xs - 0.5f) / sx - 0.5f) - 1);
+    const int X1 = min(W - 1, (int)ceilf(((float)xs + 1.5f) / sx - 0.5f) + 1);
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int Y = Y0; Y <= Y1; ++Y) {
+        const Lerp ly = src_index(Y, sy, h);
+        const float wy = (ly.i0 == ys ? ly.l0 : 0.f) + (ly.i1 == ys ? ly.l1 : 0.f);
+        if (wy == 0.f) continue;
+        for (int X = X0; X <= X1; ++X) {
+            const Lerp lx = src_index(X, sx, w);
+            const float wx = (lx.i0 == xs ? lx.l0 : 0.f) + (lx.i1 == xs ? lx.l1 : 0.f);
+            if (wx == 0.f) continue;
+            float g[8];
+            Vec16<bf16_t>::load(dy + (((int64_t)b * H + Y) * W + X) * lddy + cv * 8, g);
+            const float ww = wy * wx;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc[q] += ww * g[q];
+        }
+    }
+    Vec16<bf16_t>::store(dx + (((int64_t)b * h + ys) * w + xs) * lddx + cv * 8, acc);
+}
+
+// max-pool backward, one thread per 2 x 2 block of the input: the four positions share their four candidate windows
+// (pooled outputs (a, b) .. (a + 1, b + 1)), so dy / argmax are fetched once per block instead of once per position
+template <typename T>
+__global__ __launch_bounds__(256) void maxpool_bwd_blk_kernel(const T* __restrict__ dy, const uint8_t* __restrict__ argmax,
+                                                              T* __restrict__ dx, int B, int H, int W, int C, int Ho, int Wo) {
+    constexpr int V = Vec16<T>::N;
+    const int CV = C / V, Hb = (H + 1) / 2, Wb = (W + 1) / 2;
+    const int64_t total = (int64_t)B * Hb * Wb * CV;
+    const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= total) return;
+    const int cv = (int)(i % CV);
+    int64_t p = i / CV;
+    const int bx = (int)(p % Wb); p /= Wb;
+    const int by = (int)(p % Hb);
+    const int b = (int)(p / Hb);
+    float acc[2][2][V];
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int q = 0; q < V; ++q) acc[u][t][q] = 0.f;
+    // window (yo, xo) covers input rows 2 yo - 1 .. 2 yo + 1: of this block's rows 2 by, 2 by + 1 the window yo = by takes
+    // both (r = 1, 2) and yo = by + 1 takes row 2 by + 1 (r = 0); the same along x
+#pragma unroll
+    for (int dyo = 0; dyo < 2; ++dyo) {
+        const int yo = by + dyo;
+        if (yo >= Ho) continue;
+#pragma unroll
+        for (int dxo = 0; dxo < 2; ++dxo) {
+            const int xo = bx + dxo;
+            if (xo >= Wo) continue;
+            const int64_t o = (((int64_t)b * Ho + yo) * Wo + xo) * C + cv * V;
+            float g[V];
+            Vec16<T>::load(dy + o, g);
+            uint8_t am[V];
+            if (V == 8) {
+                const uint2 t = *reinterpret_cast<const uint2*>(argmax + o);
+                const uint32_t wv[2] = {t.x, t.y};
+#pragma unroll
+                for (int q = 0; q < 8; ++q) am[q] = (uint8_t)(wv[q >> 2] >> ((q & 3) * 8));
+            } else {
+                const uint32_t t = *reinterpret_cast<const uint32_t*>(argmax + o);
+#pragma unroll
+                for (int q = 0; q < 4; ++q) am[q] = (uint8_t)(t >> (q * 8));
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = 2 * by + u - (2 * yo - 1);           // tap row of input row 2 by + u in this window
+                if (r < 0 || r > 2) continue;
+#pragma unroll
+                for (int t = 0; t < 2; ++t) {
+                    const int sc = 2 * bx + t - (2 * xo - 1);
+                    if (sc < 0 || sc > 2) continue;
+#pragma unroll
+                    for (int q = 0; q < V; ++q) acc[u][t][q] += (am[q] == r * 3 + sc) ? g[q] : 0.f;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+        const int yi = 2 * by + u;
+        if (yi >= H) continue;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const int xi = 2 * bx + t;
+            if (xi >= W) continue;
+            Vec16<T>::store(dx + (((int64_t)b * H + yi) * W + xi) * C + cv * V, acc[u][t]);
+        }
+    }
+}
+
 inline bool vec_ok(int dtype, int a) { return a % (dtype == DML_BF16 ? 8 : 4) == 0; }
 
 }  // namespace
@@ -296,13 +429,15 @@ extern "C" int dml_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void*
     if (!vec_ok(dtype, C)) return DML_EALIGN;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int V = dtype == DML_BF16 ? 8 : 4;
-    const int grid = grid_for((int64_t)B * H * W * (C / V), 256);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    const int64_t items = (int64_t)B * ((H + 1) / 2) * ((W + 1) / 2) * (C / V);
+    if (items >= (1ll << 31) * 256) return DML_EINVAL;
+    const dim3 grid((unsigned)((items + 255) / 256));
     if (dtype == DML_BF16)
-        hipLaunchKernelGGL(maxpool_bwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, argmax,
+        hipLaunchKernelGGL(maxpool_bwd_blk_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dy, argmax,
                            (bf16_t*)dx, B, H, W, C, Ho, Wo);
     else
-        hipLaunchKernelGGL(maxpool_bwd_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, argmax,
+        hipLaunchKernelGGL(maxpool_bwd_blk_kernel<float>, grid, dim3(256), 0, st, (const float*)dy, argmax,
                            (float*)dx, B, H, W, C, Ho, Wo);
     DML_LAUNCH_CHECK();
     return 0;
@@ -371,6 +506,19 @@ static int launch_bilinear(const void* src, void* dst, int B, int h, int w, int 
     const int grid = grid_for(items, 256, 256 * 16);
     hipStream_t st = static_cast<hipStream_t>(stream);
     const bool fi = in_f32 || dtype == DML_F32, fo = out_f32 || dtype == DML_F32;
+    if (!fi && !fo && C % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0 &&
+        (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+        const int64_t it8 = BWD ? (int64_t)B * h * w * (C / 8) : (int64_t)B * H * W * (C / 8);
+        const dim3 g8((unsigned)((it8 + 255) / 256));
+        if (BWD)
+            hipLaunchKernelGGL(bilinear_bwd_bf16v_kernel, g8, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, h, w, H, W, C,
+                               ld_src, ld_dst, sy, sx);
+        else
+            hipLaunchKernelGGL(bilinear_fwd_bf16v_kernel, g8, dim3(256), 0, st, (const bf16_t*)src, (bf16_t*)dst, B, h, w, H, W, C,
+                               ld_src, ld_dst, sy, sx);
+        DML_LAUNCH_CHECK();
+        return 0;
+    }
 #define GO(TI, TO)                                                                                           \
     do {                                                                                                     \
         if (BWD)                                                                                             \

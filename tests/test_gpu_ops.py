@@ -548,9 +548,10 @@ def test_bn_eval_coeffs(lib):
 
 
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
-def test_maxpool(lib, dname):
+@pytest.mark.parametrize("geom", [(2, 13, 10, 16), (1, 12, 16, 64), (2, 7, 9, 8), (1, 1, 1, 8), (1, 2, 5, 8)])
+def test_maxpool(lib, dname, geom):
     dt, tdt, tol = DT[dname]
-    B, Hh, Ww, Cc = 2, 13, 10, 16
+    B, Hh, Ww, Cc = geom
     x = qz(rnd("mp.x", (B, Cc, Hh, Ww)), tdt).requires_grad_(True)
     y = F.max_pool2d(x, 3, 2, 1)
     gy = qz(rnd("mp.g", tuple(y.shape)), tdt)
