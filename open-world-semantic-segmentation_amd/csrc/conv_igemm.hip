@@ -1590,8 +1590,12 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                     }
                 }
             }
-            static const int bm256 = getenv("DML_CONV_BM256") ? atoi(getenv("DML_CONV_BM256")) : 0;
-            if (bm256 && a.N >= 128 && !narrow && a.N % 128 == 0) {
+            // 256-row tiles pay only on very large maps with a long K loop (the decoder's 3x3 at 192 x 192: 1003 -> 922 us);
+            // everywhere else three workgroups of four waves hide latency better than two of eight (whole step -2.7 % with
+            // 256-row tiles on every layer).  DML_CONV_BM256: 0 = never, 1 = rule below (default), 2 = every eligible layer
+            static const int bm256 = getenv("DML_CONV_BM256") ? atoi(getenv("DML_CONV_BM256")) : 1;
+            const bool big_map = a.M >= (1 << 18) && a.Ktot >= 1024;
+            if ((bm256 == 2 || (bm256 == 1 && big_map)) && a.N >= 128 && !narrow && a.N % 128 == 0) {
                 // 256-row tiles: whole tiles on the first multiple of 256 workgroups, the remainder split along K
                 constexpr int CUS = 256;
                 a.nblk_m = (a.M + 255) / 256;
