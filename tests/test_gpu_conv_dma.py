@@ -22,6 +22,18 @@ def test_conv_ops_through_the_register_staged_kernel():
     assert "passed" in r.stdout
 
 
+def test_every_unit_locally_exact_through_the_256_row_tiles():
+    """The 256-row tile variant of the LDS-DMA kernel runs by itself only on very large maps (the decoder's 3x3 at 16 x
+    192 x 192); DML_CONV_BM256=2 forces it on every eligible layer of a bf16 train step -- fused statistics, fused
+    BN-backward sums, accumulate, the K-split tail -- and every unit must still be exact to one bf16 ulp."""
+    env = dict(os.environ, DML_CONV_BM256="2")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_bf16_parity.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "locally_exact", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       cwd=H.ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "2 passed" in r.stdout
+
+
 def test_sync_batchnorm_two_ranks_match_one_process():
     """set_sync_batchnorm(True): two ranks (gloo, sharing this GPU) with half a batch each reproduce the single-process
     whole-batch logits, loss, running statistics and reduced gradients (tools/check_syncbn.py)."""
