@@ -1590,12 +1590,15 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                     }
                 }
             }
-            // 256-row tiles pay only on very large maps with a long K loop (the decoder's 3x3 at 192 x 192: 1003 -> 922 us);
-            // everywhere else three workgroups of four waves hide latency better than two of eight (whole step -2.7 % with
-            // 256-row tiles on every layer).  DML_CONV_BM256: 0 = never, 1 = rule below (default), 2 = every eligible layer
+            // 256-row tiles pay where the K loop is long (3x3 convolutions over >= 256 channels: layer3 / layer4 / ASPP /
+            // decoder), with the K-split tail balancing their few tiles: ASPP 3x3 389 -> 343 us (1014 TFLOP/s), layer4 3x3
+            // 202 -> 176 us, layer3 3x3 66.5 -> 63.8 us, decoder 3x3 1003 -> 922 us.  On the short-K 1x1 layers three
+            // workgroups of four waves hide latency better than two of eight (whole step -1.8 % with 256-row tiles
+            // everywhere).  DML_CONV_BM256: 0 = never, 1 = this rule (default), 2 = every eligible layer,
+            // >= 64 = the K threshold of the rule
             static const int bm256 = getenv("DML_CONV_BM256") ? atoi(getenv("DML_CONV_BM256")) : 1;
-            const bool big_map = a.M >= (1 << 18) && a.Ktot >= 1024;
-            if ((bm256 == 2 || (bm256 == 1 && big_map)) && a.N >= 128 && !narrow && a.N % 128 == 0) {
+            const bool long_k = a.Ktot >= (bm256 >= 64 ? bm256 : 2304);
+            if ((bm256 == 2 || (bm256 != 0 && long_k)) && a.N >= 128 && !narrow && a.N % 128 == 0) {
                 // 256-row tiles: whole tiles on the first multiple of 256 workgroups, the remainder split along K
                 constexpr int CUS = 256;
                 a.nblk_m = (a.M + 255) / 256;

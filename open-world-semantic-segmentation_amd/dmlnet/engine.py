@@ -327,7 +327,7 @@ class Plan:
         self.wgrad_ws = torch.empty(64 * (1 << 20) if training else 1, dtype=torch.float32, device=self.device)
         # K-split of partially filled last rounds in the main-stream convolutions (DmlConvDesc.tail_*): one workspace and
         # one counter array for the whole plan (the launches that use them are serialised on the caller's stream)
-        self.tail_ws = torch.empty(256 * 128 * 128 if training else 1, dtype=torch.float32, device=self.device)
+        self.tail_ws = torch.empty(512 * 128 * 128 if training else 1, dtype=torch.float32, device=self.device)
         self.tail_cnt = torch.zeros(128, dtype=torch.int32, device=self.device)
         self.group_wgrad = os.environ.get("DML_GROUP_WGRAD", "1") != "0"
         # 256 x 256 output tiles per grouped launch.  17 = one layer3 bottleneck (4 + 9 + 4): its three weight gradients

@@ -42,7 +42,7 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
             line += "fwd%s %.1fus %.0fTF | " % ("+st" if use_stats else "", t * 1e6, fl / t / 1e12)
             if use_stats:                                # the same with the K-split of the last round's tiles allowed
-                tws = torch.empty(256 * 128 * 128, device="cuda"); tcnt = torch.zeros(128, dtype=torch.int32, device="cuda")
+                tws = torch.empty(512 * 128 * 128, device="cuda"); tcnt = torch.zeros(128, dtype=torch.int32, device="cuda")
                 d.tail_ws, d.tail_ws_elems, d.tail_counters, d.tail_counters_len = tws.data_ptr(), tws.numel(), tcnt.data_ptr(), 128
                 t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
                 line += "fwd+st+tail %.1fus %.0fTF | " % (t * 1e6, fl / t / 1e12)
