@@ -883,6 +883,7 @@ TAIL_CASES = [
     ("1x1_k1024_320tiles", 2, 80, 128, 1024, 256, 1, 1),  # 320 tiles: 64 x 4
     ("3x3_d2_576", 4, 96, 96, 128, 256, 3, 2),            # 576 tiles: 64 x 4, K = 1152
     ("1x1_n512_360", 1, 96, 120, 512, 512, 1, 1),         # 90 x 4 = 360 tiles: 104 remainder x 2 parts, 16 K steps
+    ("3x3_256rows_288", 4, 96, 96, 256, 256, 3, 1),       # K = 2304: 256-row tiles, 144 x 2 = 288 tiles: 32 x 8 parts
 ]
 
 
@@ -903,7 +904,7 @@ def test_conv_tail_split_k(lib, case):
     wd = w.detach().permute(0, 2, 3, 1).contiguous().to("cuda", tdt)
     wtd = w.detach().permute(1, 2, 3, 0).contiguous().to("cuda", tdt)
     M = B * Hh * Ww
-    ws = torch.full((256 * 128 * 128,), float("nan"), device="cuda")
+    ws = torch.full((512 * 128 * 128,), float("nan"), device="cuda")
     cnt = torch.zeros(128, dtype=torch.int32, device="cuda")
 
     def run(desc, out, use_tail):
@@ -928,8 +929,13 @@ def test_conv_tail_split_k(lib, case):
         relclose(y_tail.float(), y_plain.float(), 2.0 ** -7, "tail vs plain fwd " + name)
         relclose(stats, st_plain, 1e-3, "tail statistics " + name)
     import os
-    if not os.environ.get("DML_CONV_V1") and os.environ.get("DML_CONV_TAIL", "1") != "0":
-        assert not torch.isnan(ws[:128 * 128]).any()                   # the LDS-DMA kernel really split the tail tiles
+    # did the launch split?  256-row tiles when K >= 2304 (default rule), 128-row ones otherwise
+    bm = 256 if (k * k * Cin >= 2304 and os.environ.get("DML_CONV_BM256", "1") == "1") or os.environ.get("DML_CONV_BM256") == "2" else 128
+    tiles = (M + bm - 1) // bm * (Cout // 128)
+    full, rem = tiles // 256 * 256, tiles % 256
+    expect = full >= 256 and 0 < rem <= 128 and not os.environ.get("DML_CONV_V1") and os.environ.get("DML_CONV_TAIL", "1") != "0"
+    if os.environ.get("DML_CONV_BM256", "1") in ("0", "1", "2"):
+        assert bool(torch.isnan(ws[:128 * 128]).any()) != expect, (tiles, full, rem)     # the workspace was used iff it split
     # data gradient, accumulating into an initialised buffer
     gyd = nhwc(gy, tdt)
     dxd = torch.empty((B, Hh, Ww, Cin), device="cuda", dtype=tdt)
