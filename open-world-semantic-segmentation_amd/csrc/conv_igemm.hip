@@ -1590,14 +1590,18 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                     }
                 }
             }
-            // 256-row tiles pay where the K loop is long (3x3 convolutions over >= 256 channels: layer3 / layer4 / ASPP /
-            // decoder), with the K-split tail balancing their few tiles: ASPP 3x3 389 -> 343 us (1014 TFLOP/s), layer4 3x3
-            // 202 -> 176 us, layer3 3x3 66.5 -> 63.8 us, decoder 3x3 1003 -> 922 us.  On the short-K 1x1 layers three
+            // 256-row tiles pay where the K loop is long (3x3 convolutions over >= 256 channels: layer4 / ASPP / decoder),
+            // with the K-split tail balancing their few tiles: in isolation ASPP 3x3 389 -> 343 us (1014 TFLOP/s), layer4
+            // 3x3 202 -> 176 us, decoder 3x3 1003 -> 922 us.  On the short-K 1x1 layers three
             // workgroups of four waves hide latency better than two of eight (whole step -1.8 % with 256-row tiles
             // everywhere).  DML_CONV_BM256: 0 = never, 1 = this rule (default), 2 = every eligible layer,
             // >= 64 = the K threshold of the rule
+            // In the plan (serial profile, r02 v3 -> v5): ASPP forward 1.14 -> 0.98 ms, ASPP data gradients 1.12 -> 1.01,
+            // decoder forward 0.95 -> 0.86, layer4 3x3 -0.05; but layer3's 3x3 (K = 2304, only 288 tiles of 256 rows) LOSES
+            // 0.24 ms over its 44 launches -- one 72-step tile per CU at two waves per SIMD -- hence the tile-count clause.
             static const int bm256 = getenv("DML_CONV_BM256") ? atoi(getenv("DML_CONV_BM256")) : 1;
-            const bool long_k = a.Ktot >= (bm256 >= 64 ? bm256 : 2304);
+            const int tiles256 = ((a.M + 255) / 256) * (a.N / 128);
+            const bool long_k = bm256 >= 64 ? a.Ktot >= bm256 : (a.Ktot >= 4608 || (a.Ktot >= 2304 && tiles256 >= 512));
             if ((bm256 == 2 || (bm256 != 0 && long_k)) && a.N >= 128 && !narrow && a.N % 128 == 0) {
                 // 256-row tiles: whole tiles on the first multiple of 256 workgroups, the remainder split along K
                 constexpr int CUS = 256;

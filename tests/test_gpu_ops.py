@@ -883,7 +883,7 @@ TAIL_CASES = [
     ("1x1_k1024_320tiles", 2, 80, 128, 1024, 256, 1, 1),  # 320 tiles: 64 x 4
     ("3x3_d2_576", 4, 96, 96, 128, 256, 3, 2),            # 576 tiles: 64 x 4, K = 1152
     ("1x1_n512_360", 1, 96, 120, 512, 512, 1, 1),         # 90 x 4 = 360 tiles: 104 remainder x 2 parts, 16 K steps
-    ("3x3_256rows_288", 4, 96, 96, 256, 256, 3, 1),       # K = 2304: 256-row tiles, 144 x 2 = 288 tiles: 32 x 8 parts
+    ("3x3_256rows_288", 4, 96, 96, 512, 256, 3, 1),       # K = 4608: 256-row tiles, 144 x 2 = 288 tiles: 32 x 8 parts
 ]
 
 
@@ -930,7 +930,9 @@ def test_conv_tail_split_k(lib, case):
         relclose(stats, st_plain, 1e-3, "tail statistics " + name)
     import os
     # did the launch split?  256-row tiles when K >= 2304 (default rule), 128-row ones otherwise
-    bm = 256 if (k * k * Cin >= 2304 and os.environ.get("DML_CONV_BM256", "1") == "1") or os.environ.get("DML_CONV_BM256") == "2" else 128
+    Kt = k * k * Cin
+    rule = Kt >= 4608 or (Kt >= 2304 and (M + 255) // 256 * (Cout // 128) >= 512)
+    bm = 256 if (rule and os.environ.get("DML_CONV_BM256", "1") == "1") or os.environ.get("DML_CONV_BM256") == "2" else 128
     tiles = (M + bm - 1) // bm * (Cout // 128)
     full, rem = tiles // 256 * 256, tiles % 256
     expect = full >= 256 and 0 < rem <= 128 and not os.environ.get("DML_CONV_V1") and os.environ.get("DML_CONV_TAIL", "1") != "0"
