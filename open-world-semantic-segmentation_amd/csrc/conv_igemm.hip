@@ -58,6 +58,8 @@ struct ConvArgs {
     int tail_cnt_len_;
 };
 
+int g_persist_kt = -1;      // largest K-step count the persistent kernel takes (launch_conv); -1: read DML_CONV_PERSIST
+
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
@@ -904,6 +906,198 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(WPE))) v
 }
 
 // ------------------------------------------------------------------------------------------------
+// Persistent form of the LDS-DMA ring for SHORT K loops (1x1 convolutions over <= 512 channels, the 64-channel 3x3):
+// there a tile is 2-18 K steps, and the first loads' latency plus the epilogue (its loads, and the stores the wave must
+// see acknowledged before s_endpgm frees its LDS and registers) is 40-78 % of a tile's lifetime
+// (profiles/r01_conv_phase_cycles.txt: 3.5k + 6.2k cycles beside a 13.3k-cycle loop at K = 256; 5.3k + 7.2k beside 3.5k
+// at K = 64).  A workgroup here walks a list of tiles: the ring does not drain at a tile boundary -- the first two
+// stages of the NEXT tile are issued during the last two K steps of the current one, so its K loop starts on landed
+// data, the epilogue's stores are never waited for (only the kernel's end is), and the next tile's address setup runs
+// under loads in flight.  Same tile, ring, fragment reads, MFMA order and epilogue as conv_igemm_dma_kernel<BN, MODE, 3>:
+// results are bit-identical.
+// vmcnt bookkeeping: the counter is in-order over loads AND stores on gfx9; at the first K step after an epilogue the
+// operations younger than the stage being waited for are the next stage's NI loads plus the epilogue's stores, so
+// vmcnt(NI) still implies "landed" (it over-waits for all but the last NI of the stores, never under-waits).
+// ------------------------------------------------------------------------------------------------
+template <int BN, int MODE>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_dma_persist_kernel(
+    const ConvArgs a_karg, const uint32_t x_bytes, const uint32_t w_bytes, const int ntiles) {
+    typedef bf16_t T;
+    // the descriptor is read through an opaque pointer: its ~60 words are then scalar loads from the kernel-argument
+    // segment where they are used (tile setup, epilogue) instead of living in SGPRs across the whole tile loop (which
+    // spilled 59-71 of them to VGPR lanes)
+    typedef const __attribute__((address_space(4))) uint32_t* KArgPtr;
+    KArgPtr ap = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
+    static_assert(sizeof(ConvArgs) % 4 == 0, "descriptor is copied by words");
+    auto load_args = [&](ConvArgs& dst) {
+        asm volatile("" : "+s"(ap));           // loads below cannot be hoisted above this point
+        uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
+#pragma unroll
+        for (int i = 0; i < (int)(sizeof(ConvArgs) / 4); ++i) d[i] = ap[i];
+    };
+    ConvArgs a;
+    load_args(a);
+    constexpr int NST = 3, BM = 128, WAVES = 4;
+    constexpr int STAGE = (BM + BN) * BK;
+    constexpr int TM = 64, TN = BN / 2, MT = 4, NT = TN / 16;
+    constexpr int A_I = 2, B_I = BN / 16 / WAVES;
+    constexpr int NI = A_I + B_I;
+    constexpr uint32_t OOB = 0x80000000u;
+
+    __shared__ __attribute__((aligned(1024))) T smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // this workgroup's tiles: the XCD's contiguous share of the tile list (xcd_remap's split), strided by the
+    // workgroups of that XCD, so that the tiles in flight on an XCD at any time are neighbours (shared rows / weights)
+    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
+    const int tq = ntiles >> 3, tr = ntiles & 7;
+    const int tbase = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
+    const int tcnt = tq + (xcd < tr ? 1 : 0);
+    int ti = blockIdx.x >> 3;
+    if (ti >= tcnt) return;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)w_bytes, 0x00020000);
+
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
+    const int sh2 = (MODE == 1 && a.stride == 2) ? 1 : 0;
+
+    struct TileAddr {
+        int a_base[A_I];
+        uint32_t a_mask[A_I];
+        uint32_t b_off[B_I];
+        int ir, is, ic0, kt;      // filter tap / channel offset / K step of the next stage to issue
+        int m0, n0;
+    };
+    auto setup = [&](TileAddr& t, const int tile) {
+        const int blk_m = tile / a.nblk_n, blk_n = tile - blk_m * a.nblk_n;
+        t.m0 = blk_m * BM;
+        t.n0 = blk_n * BN;
+        t.ir = 0; t.is = 0; t.ic0 = 0; t.kt = 0;
+#pragma unroll
+        for (int jj = 0; jj < A_I; ++jj) {
+            const int m = t.m0 + (wave * A_I + jj) * 16 + prow;
+            t.a_base[jj] = 0;
+            t.a_mask[jj] = 0;
+            if (m < a.M) {
+                const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+                const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+                const uint32_t yo = fdiv(rem, a.div_wo);
+                const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+                const int iy = MODE == 0 ? (int)yo * a.stride - a.pad : (int)yo + a.pad;
+                const int ix = MODE == 0 ? (int)xo * a.stride - a.pad : (int)xo + a.pad;
+                const int by = MODE == 0 ? iy : (iy >> sh2), bx = MODE == 0 ? ix : (ix >> sh2);
+                t.a_base[jj] = ((((int)b * a.Hi + by) * a.Wi + bx) * a.ldx + lchunk * 8) * 2;
+                uint32_t mk = 0;
+                for (int r = 0, tp = 0; r < a.R; ++r)
+                    for (int q = 0; q < a.S; ++q, ++tp) {
+                        bool ok;
+                        if (MODE == 0) {
+                            const int ys = iy + r * a.dil, xs = ix + q * a.dil;
+                            ok = ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+                        } else {
+                            const int ty = iy - r * a.dil, tx = ix - q * a.dil;
+                            ok = (sh2 == 0 || (((ty | tx) & 1) == 0)) && ty >= 0 && tx >= 0 && ((ty >> sh2) < a.Hi) &&
+                                 ((tx >> sh2) < a.Wi);
+                        }
+                        mk |= ok ? (1u << tp) : 0u;
+                    }
+                t.a_mask[jj] = mk;
+            }
+        }
+#pragma unroll
+        for (int jj = 0; jj < B_I; ++jj) {
+            const int row = (wave * B_I + jj) * 16 + prow, n = t.n0 + row;
+            const int bchunk = swz_chunk<T>(b_rho<NT>(row), lane & 3);
+            t.b_off[jj] = n < a.N ? (uint32_t)(((int64_t)n * a.Ktot + bchunk * 8) * 2) : OOB;
+        }
+    };
+    auto issue = [&](TileAddr& t, const int stage) {
+        T* sbase = smem + stage * STAGE;
+        const uint32_t tapbit = 1u << (t.ir * a.S + t.is);
+        const int soff = (MODE == 0 ? ((t.ir * a.dil) * a.Wi + t.is * a.dil) * a.ldx
+                                    : -((((t.ir * a.dil) >> sh2) * a.Wi + ((t.is * a.dil) >> sh2)) * a.ldx)) * 2 + t.ic0 * 2;
+#pragma unroll
+        for (int jj = 0; jj < A_I; ++jj) {
+            const uint32_t voff = (t.a_mask[jj] & tapbit) ? (uint32_t)(t.a_base[jj] + soff) : OOB;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + (wave * A_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
+        }
+#pragma unroll
+        for (int jj = 0; jj < B_I; ++jj) {
+            const uint32_t voff = t.b_off[jj] + (uint32_t)(t.kt * BK * 2);
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * BK + (wave * B_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
+        }
+        ++t.kt;
+        t.ic0 += BK;
+        if (t.ic0 >= a.C) {
+            t.ic0 = 0;
+            if (++t.is == a.S) { t.is = 0; ++t.ir; }
+        }
+    };
+
+    const int KT = a.Ktot / BK;                 // >= 2 (host side)
+    const int lr = lane & 15, lq = lane >> 4;
+    TileAddr cur, nxt;
+    setup(cur, tbase + ti);
+    issue(cur, 0);
+    issue(cur, 1);
+    int rd = 0, wr = 2;                         // ring stage read by the next K step / written by the next issue
+
+    for (;;) {
+        load_args(a);
+        const int tn = ti + per;
+        const bool has_next = tn < tcnt;
+        if (has_next) setup(nxt, tbase + tn);
+
+        f32x4 acc[NT][MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        for (int kt = 0; kt < KT; ++kt) {
+            // in flight: this step's stage and, unless the list ends here, the one after it
+            if (kt + 1 < KT || has_next) wait_vmcnt<NI>();
+            else wait_vmcnt<0>();
+            __builtin_amdgcn_s_barrier();
+            if (kt + 2 < KT) issue(cur, wr);
+            else if (has_next) issue(nxt, wr);
+            const T* as = smem + rd * STAGE + (wm * TM) * BK;
+            const T* bs = smem + rd * STAGE + BM * BK + (wn * TN) * BK;
+            wr = wr == NST - 1 ? 0 : wr + 1;
+            rd = rd == NST - 1 ? 0 : rd + 1;
+            mfma_bf16x8 bf[NT], af[MT];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + b_row<NT>(i, lr) * BK + swz_chunk<T>(lr, lq) * 8);
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int row = j * 16 + lr;
+                af[j] = *reinterpret_cast<const mfma_bf16x8*>(as + row * BK + swz_chunk<T>(row, lq) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+        load_args(a);                           // the epilogue's fields: not live across the K loop
+        conv_epilogue<T, NT, MT, MODE>(acc, a, cur.m0 + wm * TM, cur.n0 + wn * TN, lr, lq);
+        if (!has_next) break;
+        cur = nxt;
+        ti = tn;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // weight-gradient kernel: dw[n][kc] += sum_m dy[m][n] * x[src(m, tap(kc))][c(kc)]
 // tile 128 (n) x 128 (kc), K loop over 32-pixel slabs, split over the pixel dimension.
 // Both operands are "K-major" in memory (pixel rows, channel contiguous): the bf16 fragments are
@@ -1626,6 +1820,32 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                 DML_LAUNCH_CHECK();
                 return 0;
             }
+            // short K loops over more than a round of tiles: persistent workgroups (conv_igemm_dma_persist_kernel), as many
+            // as share the tile list evenly.  DML_CONV_PERSIST: 0 = off (default), otherwise the largest K-step count it
+            // applies to.  Measured (tools/bench_1x1.py, profiles/r02_persist_variant.txt): bit-identical and NOT faster --
+            // 1x1 K = 256 -> 1024 forward 58.1 -> 56.3 us, its data gradient with the BN-backward sums 85.7 -> 99.7 us, 3x3
+            // K = 576 91 -> 104 us: with three workgroups per CU the hardware already runs one tile's epilogue under the
+            // other two's K loops, and a static tile list loses the dispatcher's load balancing.
+            const int persist_kt = g_persist_kt < 0 ? (g_persist_kt = getenv("DML_CONV_PERSIST") ? atoi(getenv("DML_CONV_PERSIST")) : 0)
+                                                    : g_persist_kt;
+            if (persist_kt > 0 && a.tail_q == 1 && !narrow && a.Ktot / BK >= 2 && a.Ktot / BK <= persist_kt) {
+                constexpr int SLOTS = 768;                      // three workgroups per CU
+                const bool wide = a.N > 64;
+                a.nblk_n = wide ? (a.N + 127) / 128 : (a.N + 63) / 64;
+                const int ntiles = a.nblk_m * a.nblk_n;
+                if (ntiles > SLOTS) {
+                    const int rounds = (ntiles + SLOTS - 1) / SLOTS;
+                    const int grid = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
+                    if (wide)
+                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<128, MODE>), dim3(grid), dim3(NTHREADS), 0, st, a,
+                                           (uint32_t)xb, (uint32_t)wb, ntiles);
+                    else
+                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<64, MODE>), dim3(grid), dim3(NTHREADS), 0, st, a,
+                                           (uint32_t)xb, (uint32_t)wb, ntiles);
+                    DML_LAUNCH_CHECK();
+                    return 0;
+                }
+            }
             if (a.tail_q > 1) {
                 a.nblk_n = (a.N + 127) / 128;
                 const int ntiles = a.nblk_m * a.nblk_n;
@@ -1731,6 +1951,13 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
 }
 
 // tuning aid (not part of the ABI header): the bf16 128x128 forward kernel with parts removed
+// tests / tuning: switch the persistent short-K kernel in-process (returns the previous setting)
+extern "C" int dml_debug_conv_persist(int max_k_steps) {
+    const int prev = g_persist_kt;
+    g_persist_kt = max_k_steps;
+    return prev;
+}
+
 extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream) {
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.y = d->y; a.bias = nullptr; a.stats = d->stats;

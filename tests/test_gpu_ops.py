@@ -951,3 +951,72 @@ def test_conv_tail_split_k(lib, case):
     torch.cuda.synchronize()
     relclose(nchw(dxd), 2 * x.grad, 2e-2, "tail dgrad accum " + name)
     assert int(cnt.abs().sum()) == 0
+
+
+PERSIST_CASES = [
+    # name, mode, B, H, W, C (K side), N (output side), k, stride (of the forward conv), bnr, accum
+    ("fwd_1x1_k256_n1024", 0, 16, 48, 48, 256, 1024, 1, 1, 0, 0),          # layer3 conv3: 2304 tiles, 8 K steps
+    ("fwd_1x1_k64_n256", 0, 2, 192, 192, 64, 256, 1, 1, 0, 0),            # layer1 conv3: 2 K steps, 2 rounds of 576
+    ("fwd_3x3_k576_n64_ragged", 0, 4, 191, 190, 64, 64, 3, 1, 0, 0),      # 64-wide tiles, ragged last tile, 18 K steps
+    ("fwd_1x1_n320", 0, 8, 96, 96, 128, 320, 1, 1, 0, 0),                 # partial third column of tiles
+    ("dgrad_1x1_bnr_accum", 1, 16, 48, 48, 256, 1024, 1, 1, 1, 1),        # layer3 conv1 data gradient + bn3 sums
+    ("dgrad_1x1_bnr", 1, 8, 96, 96, 128, 512, 1, 1, 1, 0),
+    ("dgrad_1x1_stride2", 1, 16, 48, 48, 512, 256, 1, 2, 0, 0),           # downsample conv: writes 96 x 96
+    ("dgrad_3x3_k576_n64", 1, 4, 192, 192, 64, 64, 3, 1, 1, 0),
+]
+
+
+@pytest.mark.parametrize("case", PERSIST_CASES, ids=[c[0] for c in PERSIST_CASES])
+def test_conv_persistent_short_k_is_bit_identical(lib, case):
+    """conv_igemm_dma_persist_kernel (workgroups that walk a tile list, ring kept full across tile boundaries) against
+    the one-tile-per-workgroup kernel on the same launch: outputs, BN statistics partials and BN-backward partials must
+    be bit-identical (same tile, same MFMA order, same epilogue); the one-tile kernel is what the other tests check
+    against torch."""
+    name, mode, B, Hh, Ww, Cc, N, k, stride, bnr, accum = case
+    lib.dml_debug_conv_persist.restype = C.c_int
+    lib.dml_debug_conv_persist.argtypes = [C.c_int]
+    g = torch.Generator(device="cuda").manual_seed(5)
+    pad = k // 2
+    if mode == 0:
+        Hi, Wi, Ho, Wo = Hh, Ww, Hh, Ww
+    else:                          # data gradient: "input" is dy on the forward output grid, output on the input grid
+        Hi, Wi, Ho, Wo = Hh, Ww, Hh * stride, Ww * stride
+    x = (torch.randn(B, Hi, Wi, Cc, device="cuda", generator=g)).to(torch.bfloat16)
+    w = (torch.randn(N, k, k, Cc, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    M = B * Ho * Wo
+    y0 = (torch.randn(B, Ho, Wo, N, device="cuda", generator=g) * 0.3).to(torch.bfloat16)
+    G = (M + 63) // 64
+    ybn = (torch.randn(M, N, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    bits = torch.randint(0, 256, (M * N // 8,), device="cuda", dtype=torch.uint8, generator=g)
+    mean, invstd = torch.randn(N, device="cuda", generator=g) * 0.2, torch.rand(N, device="cuda", generator=g) + 0.5
+
+    def run(persist):
+        prev = lib.dml_debug_conv_persist(24 if persist else 0)
+        try:
+            y = y0.clone()
+            stats = torch.full((G * N * 2,), 3.0, device="cuda")
+            part = torch.full((G * N * 2,), 7.0, device="cuda")
+            d = make_desc(lib, x, w, y, B, Hi, Wi, Cc, Ho, Wo, N, k, stride, 1, pad, 1, mode=mode,
+                          stats=stats if mode == 0 else None, accum=accum)
+            if bnr:
+                d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+                d.bnr_partials, d.bnr_ldy, d.bnr_relu = part.data_ptr(), N, 1
+            for _ in range(2 if not accum else 1):           # a second launch over a warm cache changes the interleaving
+                chk(lib.dml_conv_igemm(C.byref(d), st()))
+            torch.cuda.synchronize()
+            return y, stats, part
+        finally:
+            lib.dml_debug_conv_persist(prev)
+
+    y1, s1, p1 = run(True)
+    y2, s2, p2 = run(False)
+    assert torch.isfinite(y1.float()).all()
+    assert (y1.float() - y0.float()).abs().max().item() > 0.1, "nothing was written"
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)), "%s: outputs differ at %d elements" % (
+        name, (y1.view(torch.int16) != y2.view(torch.int16)).sum().item())
+    assert torch.equal(s1.view(torch.int32), s2.view(torch.int32)), name + ": BN statistics partials differ"
+    assert torch.equal(p1.view(torch.int32), p2.view(torch.int32)), name + ": BN-backward partials differ"
+    if mode == 0:
+        assert (s1 != 3.0).any()
+    if bnr:
+        assert (p1 != 7.0).any()
