@@ -560,7 +560,8 @@ def main():
         args.gpus = world
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
-    backend = dist.get_backend() if world > 1 else None
+    dp = dist.is_available() and dist.is_initialized()      # world > 1, or a single forced rank (DML_FORCE_DIST=1)
+    backend = dist.get_backend() if dp else None
 
     res = train_pass(args, args.dtype, device, rank, world, steps=args.steps, warmup=args.warmup,
                      profile=(world == 1 and not args.no_profile), dump_conv=args.dump_conv)
@@ -574,7 +575,7 @@ def main():
                                       "head, DML loss (DCE+VL), SGD; %dx%d crops, %d images/GPU, 16 prototypes, "
                                       "random-init weights" % (args.size, args.size, args.batch),
                           "global_batch": args.batch * world, "parallelism": "dp%d" % world,
-                          "rccl_ranks": dist.get_world_size() if world > 1 else 1, "backend": backend,
+                          "rccl_ranks": dist.get_world_size() if dp else 1, "backend": backend,
                           "final_loss": res["final_loss"]},
                "host_enqueue_ms_per_step": res["host_ms"]}
         if "roofline" in res:
@@ -606,7 +607,7 @@ def main():
             out["input_pipeline"]["cpu_baseline"] = cpu_input_pipeline(args.size)
     if rank == 0:
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if dp:
         dist.barrier()
         dist.destroy_process_group()
 
@@ -619,6 +620,7 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
     import utils
     from dmlnet.optim import FusedSGD
 
+    dp = dist.is_available() and dist.is_initialized()
     torch.manual_seed(1)
     model = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
     model.to(device)
@@ -630,9 +632,9 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
                     {"params": model.classifier.parameters(), "lr": lr}],
                    lr=lr, momentum=0.9, weight_decay=1e-4).bind(model)       # main_embedding.py:385-388
     sched = utils.PolyLR(opt, 30000, power=0.9)
-    crit = utils.DMLLoss(alpha=0.01, ignore_index=255, sync=True if world > 1 else None,
+    crit = utils.DMLLoss(alpha=0.01, ignore_index=255, sync=True if dp else None,
                          fused_backward=True)      # the loss is the only consumer of the logits (main_embedding.py:466-470)
-    if world > 1:
+    if dp:
         model._engine.store.bind(device)
         model._engine.reducer = parallel.GradReducer(model._engine.store, bucket_mb=32.0, average=False)
     img, lab = synth_batch(args.batch, args.size, rank, device)
@@ -649,18 +651,18 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
     for _ in range(warmup):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(steps):
         loss = step()
     torch.cuda.synchronize()
-    if world > 1:
+    if dp:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dp:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())

@@ -38,6 +38,9 @@ class GradReducer:
     def __init__(self, store, bucket_mb: float = 32.0, group=None, average: bool = True):
         self.store, self.group, self.average = store, group, average
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        # DML_FORCE_DIST=1: run the collectives with a single rank too -- the only way to execute the RCCL path (communicator
+        # setup, comm-stream ordering, the nccl backend's in-place all-reduce on slices of the flat buffer) on a 1-GPU box
+        self.active = self.world > 1 or (dist.is_initialized() and os.environ.get("DML_FORCE_DIST") == "1")
         sizes = [p.numel() for p in store.params]
         self.buckets = make_buckets(store.offsets, sizes, store.total, int(bucket_mb * (1 << 20) / 4))
         self._sched = {}
@@ -46,7 +49,7 @@ class GradReducer:
     # --- synchronous path (CPU/gloo tests, or no overlap wanted)
     def reduce_all(self, flat_g: Optional[torch.Tensor] = None):
         flat_g = self.store.flat_g if flat_g is None else flat_g
-        if self.world == 1:
+        if not self.active:
             return
         for lo, hi, _ in self.buckets:
             seg = flat_g[lo:hi]
@@ -67,7 +70,7 @@ class GradReducer:
         return self._sched[key]
 
     def run_backward(self, plan, stream):
-        if self.world == 1:
+        if not self.active:
             plan.run_backward()
             return
         dev = self.store.flat_g.device
@@ -99,7 +102,7 @@ def init_from_env(backend: Optional[str] = None):
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1 and not dist.is_initialized():
+    if (world > 1 or os.environ.get("DML_FORCE_DIST") == "1") and not dist.is_initialized():
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:

@@ -71,6 +71,34 @@ def test_data_parallel_reducer_two_ranks():
     assert "parameters identical across ranks after 3 steps: True" in r.stdout and "uneven shards" in r.stdout
 
 
+def test_rccl_backend_runs_the_reducer_with_one_forced_rank():
+    """The nccl (= RCCL) backend on real hardware: this pool has one GPU per box, so the only way to execute the RCCL code
+    path -- communicator setup, the in-place all-reduce on slices of the flat gradient buffer from the comm stream, the
+    loss-sum all-reduce on the device, barrier / max-over-ranks timing -- is a single rank with DML_FORCE_DIST=1.  The
+    step must then equal the plain single-GPU step (sum over one rank = identity) and report backend nccl."""
+    import json
+    # fp32: the second step's loss depends on the first step's reduced gradients; in bf16 at this size (BatchNorm over 2 x 8 x 8
+    # samples in layer3 / layer4) rounding-level differences between two runs grow to ~1 % of the loss within three steps
+    # (measured: 4.757 vs 4.722), which would hide a wrong reduction behind the tolerance
+    args = [sys.executable, os.path.join(H.ROOT, "bench.py"), "--size", "128", "--batch", "2", "--steps", "1", "--warmup", "1",
+            "--dtype", "f32", "--no-cpu-baseline", "--no-profile", "--no-fp32-companion"]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(_free_port()),
+               RANK="0", LOCAL_RANK="0", WORLD_SIZE="1")
+    out = {}
+    for forced in ("0", "1"):
+        e = dict(env, DML_FORCE_DIST=forced)
+        e.pop("DML_DIST_BACKEND", None)
+        r = subprocess.run(args, capture_output=True, text=True, cwd=H.ROOT, timeout=900, env=e)
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        assert len(lines) == 1, lines
+        out[forced] = json.loads(lines[0])
+    assert out["0"]["config"]["backend"] is None and out["1"]["config"]["backend"] == "nccl"
+    assert out["1"]["config"]["rccl_ranks"] == 1 and out["1"]["n_gpus"] == 1
+    a, b = out["0"]["config"]["final_loss"], out["1"]["config"]["final_loss"]
+    assert abs(a - b) <= 2e-3 * abs(a), (a, b)         # same seeds, same batch
+
+
 def test_bench_gpus_flag_launches_ranks_itself():
     """`python bench.py --gpus N` (no torchrun): N = 2 on this 1-GPU box must fail cleanly before any GPU work, and with
     DML_BENCH_ALLOW_SHARED_GPU=1 (test hook: ranks share device 0 over gloo) it must print ONE line with n_gpus 2."""
