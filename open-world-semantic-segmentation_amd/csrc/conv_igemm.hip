@@ -60,6 +60,12 @@ struct ConvArgs {
 
 int g_persist_kt = -1;      // largest K-step count the persistent kernel takes (launch_conv); -1: read DML_CONV_PERSIST
 
+int g_wgrad_depth = -1;     // K steps per barrier of the 256 x 256 weight-gradient kernel (1 | 2); -1: read DML_WGRAD_DEPTH
+inline int wgrad_depth() {
+    if (g_wgrad_depth < 0) g_wgrad_depth = getenv("DML_WGRAD_DEPTH") ? atoi(getenv("DML_WGRAD_DEPTH")) : 2;
+    return g_wgrad_depth;
+}
+
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
     const int q = nwg >> 3, r = nwg & 7, xcd = bid & 7, slot = bid >> 3;
@@ -1459,7 +1465,11 @@ constexpr int WB_THREADS = 512;
 constexpr int WB_SUB = 528;                 // elements per 16-column sub-tile (32 k rows x 16 + pad)
 constexpr int WB_OP = 16 * WB_SUB;          // one operand, one stage (256 columns)
 
+// DEPTH = 2: two K steps per barrier -- two register sets and 2 x 2 LDS buffers, so that a load has two K steps to land
+// (twice the bytes in flight per CU: 64 KB; the one-workgroup-per-CU kernel is bound by what its 512 threads keep
+// outstanding) and the barrier is paid once per 64 MFMAs of a wave.
 // `logical`: this workgroup's index among the job's nblk_n * nblk_k * splits workgroups (tiles of one pixel slab adjacent)
+template <int DEPTH>
 __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_t x_bytes, const uint32_t dy_bytes,
                                                const int logical, bf16_t* smem) {
     typedef bf16_t T;
@@ -1467,8 +1477,8 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
     constexpr int NT = 8, MT = 4;                 // wave tile: 8 n-tiles x 4 kc-tiles of 16
     constexpr uint32_t OOB = 0x80000000u;
 
-    auto Ys = [&](int buf) -> T* { return smem + buf * 2 * WB_OP; };
-    auto Xs = [&](int buf) -> T* { return smem + buf * 2 * WB_OP + WB_OP; };
+    auto Ys = [&](int buf, int h) -> T* { return smem + (buf * DEPTH + h) * 2 * WB_OP; };
+    auto Xs = [&](int buf, int h) -> T* { return smem + (buf * DEPTH + h) * 2 * WB_OP + WB_OP; };
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wn = wave >> 2, wk = wave & 3;
@@ -1514,9 +1524,9 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
     const uint32_t ystep = (uint32_t)(BK * a.ldy * 2), xstep = (uint32_t)(BK * a.ldx * 2);
 
     typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
-    uint4 y_reg[LD], x_reg[LD];
-    // loads the NEXT tile in sequence (call once per K step, in order)
-    auto load_next = [&]() {
+    uint4 y_reg[DEPTH][LD], x_reg[DEPTH][LD];
+    // loads the NEXT tile in sequence into register set h (call once per K step, in tile order)
+    auto load_next = [&](const int h) {
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
             const u32x4_t yv = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)yoff[j], 0, 0);
@@ -1540,11 +1550,11 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
                 }
             }
             const u32x4_t xv = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)vo, 0, 0);
-            y_reg[j] = make_uint4(yv.x, yv.y, yv.z, yv.w);
-            x_reg[j] = make_uint4(xv.x, xv.y, xv.z, xv.w);
+            y_reg[h][j] = make_uint4(yv.x, yv.y, yv.z, yv.w);
+            x_reg[h][j] = make_uint4(xv.x, xv.y, xv.z, xv.w);
         }
     };
-    auto store_tiles = [&](int buf) {
+    auto store_tiles = [&](int buf, const int h) {
 #pragma unroll
         for (int j = 0; j < LD; ++j) {
             const int row = prow + j * RPP;
@@ -1552,8 +1562,8 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
             // conflict-free for ds_read_b64_tr_b16 and for these 16-byte writes
             const int prow_ = (row & 0x13) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 3);
             const int off = (vcol >> 1) * WB_SUB + prow_ * 16 + (vcol & 1) * 8;
-            *reinterpret_cast<uint4*>(Ys(buf) + off) = y_reg[j];
-            *reinterpret_cast<uint4*>(Xs(buf) + off) = x_reg[j];
+            *reinterpret_cast<uint4*>(Ys(buf, h) + off) = y_reg[h][j];
+            *reinterpret_cast<uint4*>(Xs(buf, h) + off) = x_reg[h][j];
         }
     };
 
@@ -1563,11 +1573,15 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
 #pragma unroll
         for (int i = 0; i < NT; ++i) acc[j][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    if (tile_beg < tile_end) {
-        load_next();
-        store_tiles(0);
-        if (tile_beg + 1 < tile_end) load_next();
-    }
+#pragma unroll
+    for (int h = 0; h < DEPTH; ++h)
+        if (tile_beg + h < tile_end) load_next(h);
+#pragma unroll
+    for (int h = 0; h < DEPTH; ++h)
+        if (tile_beg + h < tile_end) store_tiles(0, h);
+#pragma unroll
+    for (int h = 0; h < DEPTH; ++h)
+        if (tile_beg + DEPTH + h < tile_end) load_next(h);
     __syncthreads();
 
     const int lr = lane & 15, lq = lane >> 4;
@@ -1575,9 +1589,12 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
     const int p_lo = ((lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4)) * 16 + (lr & 3) * 4;
     const int p_hi = p_lo + 8 * 16;
     int cur = 0;
-    for (int t = tile_beg; t < tile_end; ++t) {
-        const T* ys = Ys(cur) + wn * 8 * WB_SUB;
-        const T* xs = Xs(cur) + wk * 4 * WB_SUB;
+    for (int t = tile_beg; t < tile_end; t += DEPTH) {
+#pragma unroll
+      for (int h = 0; h < DEPTH; ++h) {
+        if (DEPTH > 1 && t + h >= tile_end) break;      // workgroup-uniform
+        const T* ys = Ys(cur, h) + wn * 8 * WB_SUB;
+        const T* xs = Xs(cur, h) + wk * 4 * WB_SUB;
         mfma_bf16x8 yf[NT], xf[MT];
 #pragma unroll
         for (int j = 0; j < MT; ++j) {
@@ -1593,15 +1610,16 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
             bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
             yf[i] = __builtin_bit_cast(mfma_bf16x8, v);
         }
-        if (t + 1 < tile_end) {
-            store_tiles(cur ^ 1);                 // tile t+1 (in registers since the previous step)
-            if (t + 2 < tile_end) load_next();    // tile t+2
+        if (t + h + DEPTH < tile_end) {
+            store_tiles(cur ^ 1, h);                            // tile t+h+DEPTH (in registers since the previous round)
+            if (t + h + 2 * DEPTH < tile_end) load_next(h);     // tile t+h+2*DEPTH
         }
 #pragma unroll
         for (int j = 0; j < MT; ++j)
 #pragma unroll
             for (int i = 0; i < NT; ++i)
                 acc[j][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xf[j], yf[i], acc[j][i], 0, 0, 0);
+      }
         __syncthreads();
         cur ^= 1;
     }
@@ -1630,10 +1648,11 @@ __device__ __forceinline__ void wgrad_big_body(const WgradArgs& a, const uint32_
     }
 }
 
+template <int DEPTH>
 __global__ __launch_bounds__(WB_THREADS) void conv_wgrad_big_kernel(const WgradArgs a, const uint32_t x_bytes,
                                                                     const uint32_t dy_bytes) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * WB_OP];
-    wgrad_big_body(a, x_bytes, dy_bytes, xcd_remap(blockIdx.x, gridDim.x), smem);
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * DEPTH * 2 * WB_OP];
+    wgrad_big_body<DEPTH>(a, x_bytes, dy_bytes, xcd_remap(blockIdx.x, gridDim.x), smem);
 }
 
 // Several weight gradients in ONE launch.  A single 48 x 48 layer has 4-9 output tiles of 256 x 256, so filling 256 CUs
@@ -1648,12 +1667,13 @@ struct WgradGroup {
     uint32_t xb[WG_MAX_JOBS], yb[WG_MAX_JOBS];
     WgradArgs job[WG_MAX_JOBS];
 };
+template <int DEPTH>
 __global__ __launch_bounds__(WB_THREADS) void conv_wgrad_group_kernel(const WgradGroup g) {
-    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * 2 * WB_OP];
+    __shared__ __attribute__((aligned(16))) bf16_t smem[2 * DEPTH * 2 * WB_OP];
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     int j = 0;
     while (j + 1 < g.njobs && logical >= g.start[j + 1]) ++j;
-    wgrad_big_body(g.job[j], g.xb[j], g.yb[j], logical - g.start[j], smem);
+    wgrad_big_body<DEPTH>(g.job[j], g.xb[j], g.yb[j], logical - g.start[j], smem);
 }
 
 // dw[n][rs][c < Cm] += sum_s ws[s][n][rs][c]   (fp32 atomics on the L2 are ~10x more expensive per byte than this)
@@ -1951,6 +1971,13 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
 }
 
 // tuning aid (not part of the ABI header): the bf16 128x128 forward kernel with parts removed
+// tests / tuning: K steps per barrier of the large weight-gradient kernel (returns the previous setting)
+extern "C" int dml_debug_wgrad_depth(int depth) {
+    const int prev = wgrad_depth();
+    g_wgrad_depth = depth == 1 ? 1 : 2;
+    return prev;
+}
+
 // tests / tuning: switch the persistent short-K kernel in-process (returns the previous setting)
 extern "C" int dml_debug_conv_persist(int max_k_steps) {
     const int prev = g_persist_kt;
@@ -2076,7 +2103,10 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         a.ws = d->ws;
         a.slab_tiles = (tiles + sk - 1) / sk;
         sk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
-        hipLaunchKernelGGL(conv_wgrad_big_kernel, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
+        if (wgrad_depth() == 2)
+            hipLaunchKernelGGL(conv_wgrad_big_kernel<2>, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
+        else
+            hipLaunchKernelGGL(conv_wgrad_big_kernel<1>, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), 1), dim3(256), 0, st, d->ws, d->dw, sk, nrs,
                            cm, d->C);
@@ -2193,7 +2223,10 @@ extern "C" int dml_conv_wgrad_group(const DmlWgradDesc* const* descs, int n, flo
         off += (int64_t)sk[j] * plane[j];
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    hipLaunchKernelGGL(conv_wgrad_group_kernel, dim3(g.start[n]), dim3(WB_THREADS), 0, st, g);
+    if (wgrad_depth() == 2)
+        hipLaunchKernelGGL(conv_wgrad_group_kernel<2>, dim3(g.start[n]), dim3(WB_THREADS), 0, st, g);
+    else
+        hipLaunchKernelGGL(conv_wgrad_group_kernel<1>, dim3(g.start[n]), dim3(WB_THREADS), 0, st, g);
     hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(grid_for(max_items, 256, 1024), n), dim3(256), 0, st, r);
     DML_LAUNCH_CHECK();
     return 0;
