@@ -21,66 +21,75 @@ __device__ __forceinline__ void merge(Moments& a, double nb, double meanb, doubl
 }
 
 // partials[g][n] = (sum, M2 about the group mean) over rows [64 g, 64 g + 64)
+// One pass (round 2; it was two dependent passes -- total sum for the mean, then M2 about it -- with two six-step LDS
+// trees: 7.7 us for a kernel that reads ~1 MB, 85 times per step): every thread folds its groups into three fp64 sums
+//   S = sum s_g,  Q = sum M2_g,  P = sum s_g^2 / n_g      ->      M2 = Q + P - S^2 / M
+// (the identity of the two-stage finalize of the large maps below; in fp64 the cancellation costs ~1e-16 mean^2 / var),
+// the 16 slices of a wave meet through DPP-free shuffles and the four waves through one LDS exchange.
 constexpr int FIN_CH = 4, FIN_SL = 64;
+__device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
+    const long long b = __double_as_longlong(v);
+    const int lo = __shfl_xor((int)(b & 0xffffffffll), mask), hi = __shfl_xor((int)(b >> 32), mask);
+    return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
+}
 template <int FIN_CH, int FIN_SL>      // channels x group-slices per 256-thread block
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ partials, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* scale, float* shift, float* save_mean, float* save_invstd, double* moments_out) {
-    __shared__ double sh[FIN_SL][FIN_CH];
+    static_assert(FIN_CH == 4 && FIN_SL == 64, "lane = 4 channels x 16 slices per wave");
+    __shared__ double sh[3][4][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
     const int64_t G = (M + DML_STAT_ROWS - 1) / DML_STAT_ROWS;
     const int last_rows = (int)(M - (G - 1) * DML_STAT_ROWS);
-    // pass 1: exact total sum -> global mean
-    double s = 0.0;
-    if (n < N)
-        #pragma unroll 8
-        for (int64_t g = sl; g < G; g += FIN_SL) s += (double)partials[(g * N + n) * 2];
-    sh[sl][ch] = s;
-    __syncthreads();
-    for (int k = FIN_SL / 2; k > 0; k >>= 1) {
-        if (sl < k) sh[sl][ch] += sh[sl + k][ch];
-        __syncthreads();
-    }
-    const double gmean = sh[0][ch] / (double)M;
-    __syncthreads();
-    // pass 2 (partials are L2-hot): M2 = sum_g [ M2_g + n_g (mean_g - mean)^2 ]  (Chan et al., no cancellation)
-    double q = 0.0;
+    double S = 0.0, Q = 0.0, P = 0.0;
     if (n < N)
         #pragma unroll 8
         for (int64_t g = sl; g < G; g += FIN_SL) {
             const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
             const double rows = g == G - 1 ? (double)last_rows : (double)DML_STAT_ROWS;
-            const double d = (double)p.x / rows - gmean;
-            q += (double)p.y + rows * d * d;
+            S += (double)p.x;
+            Q += (double)p.y;
+            P += (double)p.x * (double)p.x / rows;
         }
-    sh[sl][ch] = q;
-    __syncthreads();
-    for (int k = FIN_SL / 2; k > 0; k >>= 1) {
-        if (sl < k) sh[sl][ch] += sh[sl + k][ch];
-        __syncthreads();
+#pragma unroll
+    for (int m = FIN_CH; m < 64; m <<= 1) {          // the wave's 16 slices of this channel: lanes ch + 4 k
+        S += shfl_xor_f64(S, m);
+        Q += shfl_xor_f64(Q, m);
+        P += shfl_xor_f64(P, m);
     }
-    if (sl == 0 && n < N && moments_out != nullptr) {       // synchronised BN: this rank's (mean, M2), merged later
-        moments_out[2 * n] = gmean;
-        moments_out[2 * n + 1] = sh[0][ch];
+    const int wave = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) < FIN_CH) {
+        sh[0][wave][ch] = S;
+        sh[1][wave][ch] = Q;
+        sh[2][wave][ch] = P;
+    }
+    __syncthreads();
+    if (threadIdx.x >= FIN_CH || n >= N) return;
+    S = sh[0][0][ch] + sh[0][1][ch] + sh[0][2][ch] + sh[0][3][ch];
+    Q = sh[1][0][ch] + sh[1][1][ch] + sh[1][2][ch] + sh[1][3][ch];
+    P = sh[2][0][ch] + sh[2][1][ch] + sh[2][2][ch] + sh[2][3][ch];
+    const double cnt = (double)M, mean = S / cnt;
+    double m2 = Q + (P - S * mean);
+    if (m2 < 0.0) m2 = 0.0;
+    if (moments_out != nullptr) {       // synchronised BN: this rank's (mean, M2), merged later
+        moments_out[2 * n] = mean;
+        moments_out[2 * n + 1] = m2;
         return;
     }
-    if (sl == 0 && n < N) {
-        const double mean = gmean, m2 = sh[0][ch], cnt = (double)M;
-        const double var_b = m2 / cnt;
-        const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
-        const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
-        const float sc = g * invstd;
-        scale[n] = sc;
-        shift[n] = b;
-        save_mean[n] = (float)mean;
-        if (save_invstd) save_invstd[n] = invstd;
-        if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
-        if (running_var) {
-            const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
-            running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
-        }
+    const double var_b = m2 / cnt;
+    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+    const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
+    const float sc = g * invstd;
+    scale[n] = sc;
+    shift[n] = b;
+    save_mean[n] = (float)mean;
+    if (save_invstd) save_invstd[n] = invstd;
+    if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+    if (running_var) {
+        const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
+        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
     }
 }
 
@@ -298,18 +307,22 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 // many partial rows (the 64-row groups of a fused reduce on the 192 x 192 layers: 9216): chunks of R rows are summed
 // first, each chunk into ITS OWN first row (nobody else touches those columns of that row), and the finalize then
 // walks the chunk heads with row stride R -- the same two coalesced stages as the forward statistics
+// (32 VGPRs: see bn_bwd_finalize_kernel)
 __global__ __launch_bounds__(256) void bn_bwd_fold_kernel(float* partials, int G, int N, int R) {
     __shared__ double sh[2][4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
     const int g0 = blockIdx.y * R, g1 = min(G, g0 + R);
     double s0 = 0.0, s1 = 0.0;
-    if (n < N)
-        #pragma unroll 8
-        for (int g = g0 + rl; g < g1; g += 4) {
-            const float2 p = *reinterpret_cast<const float2*>(partials + ((int64_t)g * N + n) * 2);
+    if (n < N) {
+        const uint32_t step = 8u * (uint32_t)N;                                        // partials hold < 2^31 floats
+        uint32_t off = ((uint32_t)(g0 + rl) * (uint32_t)N + (uint32_t)n) * 2u;
+        #pragma unroll 4
+        for (int g = g0 + rl; g < g1; g += 4, off += step) {
+            const float2 p = *reinterpret_cast<const float2*>(partials + off);
             s0 += (double)p.x; s1 += (double)p.y;
         }
+    }
     sh[0][rl][c] = s0; sh[1][rl][c] = s1;
     __syncthreads();
     if (rl == 0 && n < N) {
@@ -319,25 +332,42 @@ __global__ __launch_bounds__(256) void bn_bwd_fold_kernel(float* partials, int G
     }
 }
 
+// At most 32 VGPRs, deliberately: this kernel sits on the backward's critical path while the weight-gradient kernel of the
+// side stream holds every CU with one 8-wave workgroup of 235 registers (2 x 240 of a SIMD's 512); a 4-wave block that
+// needs <= 32 registers per lane still fits beside it and starts at once, a larger one waits for a weight-gradient
+// workgroup to retire (measured: 6 us -> 33 us per launch, 112 launches per step).  (The compiler drops an
+// amdgpu_num_vgpr request below what eight waves per SIMD allow, so the loops are written to need few: 32-bit element
+// offsets from a scalar base, four loads in flight.)
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partials, int nblocks, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma, float* dbeta,
     float* coef, double* sums_out, int row_stride) {
-    __shared__ double sh[2][FIN_SL][FIN_CH];
+    __shared__ double sh[2][4][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
     double s0 = 0.0, s1 = 0.0;
-    if (n < N)
-        #pragma unroll 8
-        for (int g = sl; g < nblocks; g += FIN_SL) {
-            const float2 p = *reinterpret_cast<const float2*>(partials + ((int64_t)g * row_stride * N + n) * 2);
+    if (n < N) {
+        const uint32_t step = (uint32_t)(FIN_SL * row_stride) * (uint32_t)N * 2u;       // partials hold < 2^31 floats
+        uint32_t off = ((uint32_t)(sl * row_stride) * (uint32_t)N + (uint32_t)n) * 2u;
+        #pragma unroll 4
+        for (int g = sl; g < nblocks; g += FIN_SL, off += step) {
+            const float2 p = *reinterpret_cast<const float2*>(partials + off);
             s0 += p.x; s1 += p.y;
         }
-    sh[0][sl][ch] = s0; sh[1][sl][ch] = s1;
+    }
+#pragma unroll
+    for (int m = FIN_CH; m < 64; m <<= 1) {          // the wave's 16 slices of this channel (see bn_finalize_kernel)
+        s0 += shfl_xor_f64(s0, m);
+        s1 += shfl_xor_f64(s1, m);
+    }
+    if ((threadIdx.x & 63) < FIN_CH) {
+        sh[0][threadIdx.x >> 6][ch] = s0;
+        sh[1][threadIdx.x >> 6][ch] = s1;
+    }
     __syncthreads();
-    for (int s = FIN_SL / 2; s > 0; s >>= 1) {
-        if (sl < s) { sh[0][sl][ch] += sh[0][sl + s][ch]; sh[1][sl][ch] += sh[1][sl + s][ch]; }
-        __syncthreads();
+    if (sl == 0) {
+        sh[0][0][ch] = sh[0][0][ch] + sh[0][1][ch] + sh[0][2][ch] + sh[0][3][ch];
+        sh[1][0][ch] = sh[1][0][ch] + sh[1][1][ch] + sh[1][2][ch] + sh[1][3][ch];
     }
     if (sl == 0 && n < N && sums_out != nullptr) {          // synchronised BN: local sums out, parameter gradients local
         sums_out[2 * n] = sh[0][0][ch];
