@@ -126,7 +126,7 @@ def conv_bytes_of_plan(plan):
                 d = args[0]._obj
                 rd = d.B * d.Hi * d.Wi * d.C * es + d.N * d.R * d.S * d.C * es
                 wr = d.B * d.Ho * d.Wo * d.N * (4 if d.y_f32 else es)
-                total += rd + wr * (2 if d.accum else 1)
+                total += rd + wr * (2 if (d.accum or d.res_dz) else 1)      # accumulate / masked residual source: one more read
             elif fn is lib.dml_conv_wgrad or fn is lib.dml_conv_wgrad_group:
                 for d in ([args[0]._obj] if fn is lib.dml_conv_wgrad else args.meta):
                     total += d.B * d.Hi * d.Wi * d.C * es + d.B * d.Ho * d.Wo * d.N * es + 2 * 4 * d.N * d.R * d.S * d.C

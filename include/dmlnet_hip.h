@@ -91,6 +91,14 @@ typedef struct DmlConvDesc {
     int64_t tail_ws_elems;
     int32_t* tail_counters;
     int32_t tail_counters_len, tail_reserved;
+    /* mode 1 only, optional (bf16, same conditions as bnr_*; not with accum): y = conv + res_dz (.) [res_mask bit], i.e.
+     * the gradient that reaches a bottleneck's input through its identity branch -- the block output's gradient res_dz
+     * [M][N] (pitch res_ld) masked by the 1-bit ReLU mask of that output (dml_bn_apply's, one byte per 8 channels) --
+     * is added in the epilogue of conv1's data gradient (resnet.py:96-113 backward), so that the BN-backward apply of
+     * the block's bn3 need not write the masked copy (dres = NULL there) for this launch to read back. */
+    const void* res_dz;
+    const uint8_t* res_mask;
+    int32_t res_ld, res_reserved;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */

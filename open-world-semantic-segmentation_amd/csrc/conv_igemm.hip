@@ -56,6 +56,10 @@ struct ConvArgs {
     int tail_full, tail_q;
     int64_t tail_ws_elems_;      // host side only: capacities of the two buffers
     int tail_cnt_len_;
+    // data-gradient mode: masked residual gradient added in the epilogue (DmlConvDesc::res_*)
+    const void* res_dz;
+    const uint8_t* res_mask;
+    int res_ld;
 };
 
 int g_persist_kt = -1;      // largest K-step count the persistent kernel takes (launch_conv); -1: read DML_CONV_PERSIST
@@ -195,6 +199,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
             // stored -- exactly what dml_bn_bwd_reduce would compute from the stored tensor -- so the separate pass
             // over dz / y / mask disappears.
             const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
+            const bool resm = MODE == 1 && a.res_dz != nullptr;
             const bool post = MODE == 0 && a.post_scale != nullptr;
 #pragma unroll
             for (int g = 0; g < CL / 8; ++g) {
@@ -221,14 +226,20 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                 // all of the group's loads (accumulate operand, BN input, mask bytes) are issued before the first
                 // use: one memory round trip per group instead of one per row
                 uint4 told[MT], ty[MT];
-                uint32_t bits[MT];
+                uint32_t bits[MT], rbits[MT];
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     const int m = mw0 + j * 16 + lr;
                     told[j] = make_uint4(0, 0, 0, 0);
                     ty[j] = make_uint4(0, 0, 0, 0);
                     bits[j] = 0xffu;
+                    rbits[j] = 0xffu;
                     if (m < a.M) {
+                        if (resm) {
+                            told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.res_dz) +
+                                                                      (int64_t)m * a.res_ld + n8);
+                            rbits[j] = a.res_mask[(int64_t)m * (a.N >> 3) + (n8 >> 3)];
+                        }
                         if (post && a.post_res != nullptr)
                             told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.post_res) +
                                                                       (int64_t)m * a.post_ldres + n8);
@@ -257,8 +268,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         const uint32_t tt[4] = {told[j].x, told[j].y, told[j].z, told[j].w};      // zeros unless accumulating
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
-                            w[2 * e] += __uint_as_float(tt[e] << 16);
-                            w[2 * e + 1] += __uint_as_float(tt[e] & 0xffff0000u);
+                            if (resm) {          // masked residual gradient: a cleared ReLU bit drops the element
+                                w[2 * e] += (rbits[j] >> (2 * e)) & 1u ? __uint_as_float(tt[e] << 16) : 0.f;
+                                w[2 * e + 1] += (rbits[j] >> (2 * e + 1)) & 1u ? __uint_as_float(tt[e] & 0xffff0000u) : 0.f;
+                            } else {
+                                w[2 * e] += __uint_as_float(tt[e] << 16);
+                                w[2 * e + 1] += __uint_as_float(tt[e] & 0xffff0000u);
+                            }
                         }
                     }
                     if (post && a.post_relu) {
@@ -1932,6 +1948,15 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0;
+    if (d->res_dz) {
+        // masked residual gradient in the epilogue: the 16-byte-vector bf16 path of the data gradient only
+        if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || d->accum || !d->res_mask) return DML_EINVAL;
+        if (d->N % 8 || d->ldy % 8 || d->res_ld % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
+            (reinterpret_cast<uintptr_t>(d->res_dz) & 15) || d->N <= 32)
+            return DML_EALIGN;
+        a.res_dz = d->res_dz; a.res_mask = d->res_mask; a.res_ld = d->res_ld;
+    }
     if (d->tail_ws && d->tail_counters && d->tail_ws_elems > 0 && d->tail_counters_len > 0) {
         if (reinterpret_cast<uintptr_t>(d->tail_ws) & 15) return DML_EALIGN;
         a.tail_ws = d->tail_ws; a.tail_cnt = d->tail_counters;
@@ -2001,6 +2026,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);

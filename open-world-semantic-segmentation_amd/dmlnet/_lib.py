@@ -37,7 +37,8 @@ class ConvDesc(C.Structure):
                 ("post_ldres", C.c_int32), ("post_relu", C.c_int32),
                 # K-split of the tiles of a partially filled last round (see the header)
                 ("tail_ws", c_p), ("tail_ws_elems", C.c_int64), ("tail_counters", c_p),
-                ("tail_counters_len", C.c_int32), ("tail_reserved", C.c_int32)]
+                ("tail_counters_len", C.c_int32), ("tail_reserved", C.c_int32),
+                ("res_dz", C.c_void_p), ("res_mask", C.c_void_p), ("res_ld", C.c_int32), ("res_reserved", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 22

@@ -316,6 +316,9 @@ class Plan:
                          and dist.get_world_size(engine.sync_group) > 1)
         self.world = dist.get_world_size(engine.sync_group) if self.sync else 1
         self.last_dgrad = {}           # gradient buffer address -> ConvDesc of the data gradient that wrote it last
+        self.res_src = {}              # id(block input) -> (dz of the block output, its ReLU mask): identity-branch gradient
+        #                                that conv1's data gradient adds in its epilogue (DmlConvDesc.res_*)
+        self.fuse_res_grad = os.environ.get("DML_FUSE_RES_GRAD", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
         self.fork_branches = os.environ.get("DML_FORK_BRANCHES", "1") != "0"
         # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
@@ -447,6 +450,12 @@ class Plan:
                        pre_shift=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld, Ho=x.H, Wo=x.W, N=x.C,
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
                        accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
+        res = self.res_src.pop(id(x), None)
+        if res is not None:
+            # the identity branch's share of this gradient (block output gradient x ReLU mask) is added in the epilogue
+            assert not x.root.grad_init and x is x.root
+            rdz, rmask = res
+            dsc.res_dz, dsc.res_mask, dsc.res_ld = rdz.ptr, rmask.data_ptr(), rdz.ld
         x.root.grad_init = True
         dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
         dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
@@ -731,12 +740,21 @@ class Plan:
                 dres = self.grad_of(ud.z)
                 self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
                 ud.z.grad_init = True
+            elif (self.fuse_res_grad and self.dtype == torch.bfloat16 and not xb.root.grad_init and xb is xb.root
+                  and u3.relu and u3.mask is not None and u3.drop is None and xb.C % 8 == 0 and xb.C > 32
+                  and dz.ld == xb.C and self.conv_geom(u1.conv, xb)[:3] == (1, 1, 1)):
+                # The masked output gradient is this block's contribution to d(xb) through the identity branch.  Instead
+                # of having the BN-backward apply write that copy (75 MB per layer3 block) for conv1's data gradient to
+                # accumulate onto, conv1's data gradient reads dz and the mask itself (DmlConvDesc.res_*).
+                self.unit_bwd(u3, dz, dres=None)
+                self.res_src[id(xb)] = (dz, u3.mask)
             else:
                 dres = self.grad_of(xb)
                 self.unit_bwd(u3, dz, dres=dres, dres_accum=xb.root.grad_init)
                 xb.root.grad_init = True
             self.unit_bwd(u2, self.grad_of(u2.z))
             self.unit_bwd(u1, self.grad_of(u1.z))
+            assert not self.res_src, "conv1's data gradient did not take the identity-branch gradient"
             if ud is not None:
                 self.unit_bwd(ud, self.grad_of(ud.z))
         # max pool + stem

@@ -1062,3 +1062,44 @@ def test_wgrad_two_k_steps_per_barrier_is_bit_identical(lib, case):
     y = torch.nn.functional.conv2d(xr, w, padding=dil * (k // 2), dilation=dil)
     y.backward(dy.float().permute(0, 3, 1, 2))
     relclose(out[(2, 0)].permute(0, 3, 1, 2).cpu(), w.grad.cpu(), 2e-3, "wgrad depth 2 vs torch " + name)
+
+
+@pytest.mark.parametrize("bnr", [0, 1])
+def test_dgrad_adds_the_masked_residual_gradient_in_its_epilogue(lib, bnr):
+    """DmlConvDesc.res_*: y = conv^T(dy) + res_dz (.) [mask bit] must be bit-identical to the accumulate path on a
+    pre-masked copy (what the plans did before: dml_bn_bwd_apply wrote dz (.) mask, conv1's data gradient accumulated onto
+    it), with and without the fused BN-backward sums; ragged row count."""
+    B, Hh, Ww, Cin, Cout = 3, 21, 19, 256, 64                # data gradient of a 1x1 conv Cin -> Cout: writes [M][Cin]
+    M = B * Hh * Ww
+    g = torch.Generator(device="cuda").manual_seed(3)
+    dy = torch.randn(B, Hh, Ww, Cout, device="cuda", generator=g).to(torch.bfloat16)
+    wt = (torch.randn(Cin, 1, 1, Cout, device="cuda", generator=g) * 0.1).to(torch.bfloat16)
+    dz = torch.randn(M, Cin, device="cuda", generator=g).to(torch.bfloat16)
+    bits = torch.randint(0, 256, (M * Cin // 8,), device="cuda", dtype=torch.uint8, generator=g)
+    mk = ((bits.view(M, Cin // 8, 1) >> torch.arange(8, device="cuda").view(1, 1, 8)) & 1).reshape(M, Cin).bool()
+    masked = torch.where(mk, dz, torch.zeros_like(dz))
+    ybn = (torch.randn(M, Cin, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
+    bits2 = torch.randint(0, 256, (M * Cin // 8,), device="cuda", dtype=torch.uint8, generator=g)
+    mean, invstd = torch.randn(Cin, device="cuda", generator=g) * 0.2, torch.rand(Cin, device="cuda", generator=g) + 0.5
+    G = (M + 63) // 64
+    outs = []
+    for fused in (True, False):
+        y = torch.empty(M, Cin, device="cuda", dtype=torch.bfloat16) if fused else masked.clone()
+        part = torch.full((G * Cin * 2,), 7.0, device="cuda")
+        d = make_desc(lib, dy, wt, y, B, Hh, Ww, Cout, Hh, Ww, Cin, 1, 1, 1, 0, 1, mode=1, accum=0 if fused else 1)
+        if fused:
+            d.res_dz, d.res_mask, d.res_ld = dz.data_ptr(), bits.data_ptr(), Cin
+        if bnr:
+            d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits2.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+            d.bnr_partials, d.bnr_ldy, d.bnr_relu = part.data_ptr(), Cin, 1
+        chk(lib.dml_conv_igemm(C.byref(d), st()))
+        torch.cuda.synchronize()
+        outs.append((y, part))
+    (y1, p1), (y2, p2) = outs
+    assert (y2.float() - masked.float()).abs().max().item() > 0.1
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)), "%d elements differ" % (y1.view(torch.int16) != y2.view(torch.int16)).sum().item()
+    assert torch.equal(p1.view(torch.int32), p2.view(torch.int32))
+    # the combination with accum is refused
+    d = make_desc(lib, dy, wt, y1, B, Hh, Ww, Cout, Hh, Ww, Cin, 1, 1, 1, 0, 1, mode=1, accum=1)
+    d.res_dz, d.res_mask, d.res_ld = dz.data_ptr(), bits.data_ptr(), Cin
+    assert lib.dml_conv_igemm(C.byref(d), st()) != 0
