@@ -490,15 +490,17 @@ __global__ __launch_bounds__(256) void bn_finalize_folded_kernel(
     const float* __restrict__ partials, int64_t M, int N, int R, int NC, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* scale, float* shift, float* save_mean, float* save_invstd) {
-    // 32 channels x 8 chunk lanes per block: the NC (<= 128) chunk sums are read 8 at a time
-    __shared__ double sh[3][8][32];
-    const int c = threadIdx.x & 31, cl = threadIdx.x >> 5;
-    const int n = blockIdx.x * 32 + c;
+    // 8 channels x 32 chunk lanes per block (it was 32 x 8: two blocks for the 64-channel layers, every thread walking 16
+    // chunks one after the other -- 14 us): the NC (<= 128) chunk sums are read 32 at a time, N / 8 blocks
+    constexpr int FC = 8, FL = 32;
+    __shared__ double sh[3][FL][FC];
+    const int c = threadIdx.x % FC, cl = threadIdx.x / FC;
+    const int n = blockIdx.x * FC + c;
     const double* f = reinterpret_cast<const double*>(partials);
     double S = 0.0, Q = 0.0, P = 0.0;
     if (n < N)
-        #pragma unroll 8
-        for (int ck = cl; ck < NC; ck += 8) {
+        #pragma unroll 4
+        for (int ck = cl; ck < NC; ck += FL) {
             const int64_t g0 = (int64_t)ck * R;
             S += f[(g0 + 0) * N + n];
             Q += f[(g0 + 1) * N + n];
@@ -511,7 +513,7 @@ __global__ __launch_bounds__(256) void bn_finalize_folded_kernel(
     if (cl != 0 || n >= N) return;
     S = Q = P = 0.0;
 #pragma unroll
-    for (int k = 0; k < 8; ++k) {
+    for (int k = 0; k < FL; ++k) {
         S += sh[0][k][c];
         Q += sh[1][k][c];
         P += sh[2][k][c];
@@ -552,7 +554,7 @@ extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, const float* g
         const int last_rows = (int)(M - (G - 1) * DML_STAT_ROWS);
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((N + 63) / 64, NC), dim3(256), 0, st, partials, G, N, R, NC,
                            last_rows);
-        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((N + 31) / 32), dim3(256), 0, st, partials, M, N, R, NC,
+        hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((N + 7) / 8), dim3(256), 0, st, partials, M, N, R, NC,
                            gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     } else {
         hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, st, partials, M, N, gamma,
