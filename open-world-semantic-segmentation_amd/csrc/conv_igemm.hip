@@ -60,6 +60,8 @@ struct ConvArgs {
     const void* res_dz;
     const uint8_t* res_mask;
     int res_ld;
+    // bit 0: the epilogue's bf16 output stores carry the non-temporal hint, bit 1: its partial-statistics stores (launch_conv)
+    int nt_out;
 };
 
 int g_persist_kt = -1;      // largest K-step count the persistent kernel takes (launch_conv); -1: read DML_CONV_PERSIST
@@ -120,6 +122,26 @@ __device__ __forceinline__ float row16_sum(float v) {
     return v;
 }
 
+// 16-byte store, optionally with the non-temporal hint.  Why the hint: a conv output of 75-300 MB passes through 32 MB of
+// L2; with plain stores the lines stay dirty until capacity evicts them, the evictions stall the allocating stores, the
+// stalled stores block the CU's memory pipeline and the operand loads of the other workgroups queue behind them -- the
+// store time ADDS to the compute time instead of hiding under it (1x1 256 -> 1024 at 48 x 48: 53 us, 30 us without the
+// stores, 36 us with the stores aimed at an L2-resident region).  Non-temporal stores stream to memory: 36.4 us.
+typedef unsigned int u32x4_st __attribute__((ext_vector_type(4)));
+typedef float f32x4_st __attribute__((ext_vector_type(4)));
+// (inline asm: with __builtin_nontemporal_store in one arm of a run-time branch the optimiser merges the two stores to the
+// same address into one plain store and the hint is gone)
+__device__ __forceinline__ void st16(void* p, uint32_t a, uint32_t b, uint32_t c, uint32_t d, const bool nt) {
+    const u32x4_st v = {a, b, c, d};
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<u32x4_st*>(p) = v;
+}
+__device__ __forceinline__ void st16f(float* p, float a, float b, float c, float d, const bool nt) {
+    const f32x4_st v = {a, b, c, d};
+    if (nt) asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(p), "v"(v) : "memory");
+    else *reinterpret_cast<f32x4_st*>(p) = v;
+}
+
 // ------------------------------------------------------------------------------------------------
 // shared epilogue: BN partial statistics, bias, accumulate, fp32 / storage-dtype stores
 // acc[i][j][e] = out[m = mw0 + j*16 + (lane&15)][n = nw0 + frag_chan<NT>(i, lane>>4) + e]
@@ -165,9 +187,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                     const int n = ch(i * 4);
                     float* sp = sg + (int64_t)n * 2 - i * 8;
                     if (pair_ok && n + 3 < a.N) {
-                        float4* p4 = reinterpret_cast<float4*>(sp + i * 8);
-                        p4[0] = make_float4(s[0], m2[0], s[1], m2[1]);
-                        p4[1] = make_float4(s[2], m2[2], s[3], m2[3]);
+                        st16f(sp + i * 8, s[0], m2[0], s[1], m2[1], (a.nt_out & 2) != 0);
+                        st16f(sp + i * 8 + 4, s[2], m2[2], s[3], m2[3], (a.nt_out & 2) != 0);
                     } else {
 #pragma unroll
                         for (int q = 0; q < 4; ++q)
@@ -283,7 +304,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                     }
                     const uint32_t pk[4] = {pack_bf16x2(w[0], w[1]), pack_bf16x2(w[2], w[3]), pack_bf16x2(w[4], w[5]),
                                             pack_bf16x2(w[6], w[7])};
-                    *reinterpret_cast<uint4*>(yp) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    st16(yp, pk[0], pk[1], pk[2], pk[3], (a.nt_out & 1) != 0);
                     if (bnr) {
                         const uint32_t yy[4] = {ty[j].x, ty[j].y, ty[j].z, ty[j].w};
 #pragma unroll
@@ -304,9 +325,10 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         r2[e] = row16_sum(r2[e]);
                     }
                     if (lr == 0) {
-                        float4* pp = reinterpret_cast<float4*>(a.bnr_partials + ((int64_t)(mw0 / TM) * a.N + n8) * 2);
+                        float* pp = a.bnr_partials + ((int64_t)(mw0 / TM) * a.N + n8) * 2;
 #pragma unroll
-                        for (int e = 0; e < 4; ++e) pp[e] = make_float4(r1[2 * e], r2[2 * e], r1[2 * e + 1], r2[2 * e + 1]);
+                        for (int e = 0; e < 4; ++e)
+                            st16f(pp + 4 * e, r1[2 * e], r2[2 * e], r1[2 * e + 1], r2[2 * e + 1], (a.nt_out & 2) != 0);
                     }
                 }
             }
@@ -1780,6 +1802,16 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
     a.w_bytes = small ? (uint32_t)wb64 : 0u;
     const bool aligned = (a.C % BK) == 0 && a.R * a.S <= 32 && small;
     a.nblk_m = (a.M + 127) / 128;
+    // non-temporal epilogue stores for outputs that do not fit the L2 anyway (st16); smaller ones are better left there for
+    // their consumer (1x1 1024 -> 256 at 48 x 48, 19 MB: 45.3 us plain, 46.9 non-temporal).  DML_CONV_NT: 0 never, 1 this
+    // rule (default), 2 always
+    static const int nt_mode = getenv("DML_CONV_NT") ? atoi(getenv("DML_CONV_NT")) : 1;
+    // the partial statistics (64 B per wave instruction) follow only where they are many: beside non-temporal outputs,
+    // 19 MB of plain partial stores bring the stalls back (192 x 192, 64 -> 256: 158 us, 126 with both non-temporal; all
+    // plain 141), while 4.7 MB do better plain (48 x 48, 256 -> 1024: 41.1 against 45.4 us)
+    const bool nt_y = nt_mode == 2 || (nt_mode == 1 && (int64_t)a.M * a.N * (int64_t)sizeof(T) >= (32ll << 20));
+    const bool nt_p = nt_y && (int64_t)((a.M + 63) / 64) * a.N * 8 >= (8ll << 20);
+    a.nt_out = (nt_y ? 1 : 0) | (nt_p ? 2 : 0);
     if constexpr (sizeof(T) == 2) {
         // LDS-DMA kernel: bf16, K tiles inside one tap, tensors addressable with a 31-bit byte offset.  With a 3-stage
         // ring (48 KB of LDS) and the 168-register budget three workgroups fit a CU like the register-staged kernel, and
@@ -1948,7 +1980,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
-    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
     if (d->res_dz) {
         // masked residual gradient in the epilogue: the 16-byte-vector bf16 path of the data gradient only
         if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || d->accum || !d->res_mask) return DML_EINVAL;
@@ -2026,7 +2058,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
-    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);
