@@ -160,6 +160,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
             const int grp = mw0 / TM;
             float* sg = a.stats + (int64_t)grp * a.N * 2;
             const bool pair_ok = (a.N & 1) == 0;
+            // whole wave tile inside N: the partials leave in ONE store instruction -- lane (lq, lr = 2 i + h) writes the
+            // (sum, M2) pairs of channels 2h, 2h+1 of tile i, 32 lanes x 16 B covering the wave's 64 channels contiguously --
+            // instead of two 64-byte stores from four lanes per tile (8 instructions per wave: at ~1 us per 128 x 128 tile
+            // the statistics cost 13-34 us per launch on the large maps)
+            const bool gather = pair_ok && nw0 + NT * 16 <= a.N;
+            float S[NT][4], Q[NT][4];
 #pragma unroll
             for (int i = 0; i < NT; ++i) {
                 float s[4] = {0.f, 0.f, 0.f, 0.f};
@@ -183,7 +189,9 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                 }
 #pragma unroll
                 for (int q = 0; q < 4; ++q) m2[q] = row16_sum(m2[q]);
-                if (lr == 0) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) { S[i][q] = s[q]; Q[i][q] = m2[q]; }
+                if (lr == 0 && !gather) {
                     const int n = ch(i * 4);
                     float* sp = sg + (int64_t)n * 2 - i * 8;
                     if (pair_ok && n + 3 < a.N) {
@@ -198,6 +206,16 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                             }
                     }
                 }
+            }
+            if (gather && lr < 2 * NT) {
+                float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+                for (int i = 0; i < NT; ++i)
+#pragma unroll
+                    for (int h = 0; h < 2; ++h)
+                        if (lr == 2 * i + h) { v0 = S[i][2 * h]; v1 = Q[i][2 * h]; v2 = S[i][2 * h + 1]; v3 = Q[i][2 * h + 1]; }
+                const int n = nw0 + frag_chan<NT>(lr >> 1, lq) + (lr & 1) * 2;
+                st16f(sg + (int64_t)n * 2, v0, v1, v2, v3, (a.nt_out & 2) != 0);
             }
         }
     }
@@ -324,11 +342,13 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         r1[e] = row16_sum(r1[e]);
                         r2[e] = row16_sum(r2[e]);
                     }
-                    if (lr == 0) {
+                    if (lr < 4) {            // lane lr writes the pairs of channels 2 lr, 2 lr + 1: one instruction per group
                         float* pp = a.bnr_partials + ((int64_t)(mw0 / TM) * a.N + n8) * 2;
+                        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            st16f(pp + 4 * e, r1[2 * e], r2[2 * e], r1[2 * e + 1], r2[2 * e + 1], (a.nt_out & 2) != 0);
+                            if (lr == e) { v0 = r1[2 * e]; v1 = r2[2 * e]; v2 = r1[2 * e + 1]; v3 = r2[2 * e + 1]; }
+                        st16f(pp + 4 * lr, v0, v1, v2, v3, (a.nt_out & 2) != 0);
                     }
                 }
             }
