@@ -99,6 +99,13 @@ typedef struct DmlConvDesc {
     const void* res_dz;
     const uint8_t* res_mask;
     int32_t res_ld, res_reserved;
+    /* mode 1 only, optional (bf16, same conditions as bnr_*; not with accum / y_f32 / res_dz / bnr_*): y = bf16(conv + acc32).
+     * A gradient with several producers (autograd's fp32 sum at network/utils.py:360 -- the five ASPP branches reading
+     * `out` -- and at resnet.py:96-113 where a block input also feeds the downsample branch) is accumulated in an fp32
+     * staging tensor acc32 [M][N] (pitch acc32_ld floats) by the earlier producers (y_f32 = 1, accum = 0 / 1) and the
+     * LAST producer adds it to its accumulators and rounds the total once into the bf16 tensor y. */
+    const float* acc32;
+    int32_t acc32_ld, acc32_reserved;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
@@ -229,6 +236,11 @@ int dml_global_avgpool_fwd(const void* x, void* y, int B, int HW, int C, int ldx
 int dml_broadcast_hw(const void* v, void* z, int B, int HW, int C, int ldz, int dtype, void* stream);
 /* dv[b][c] = sum over HW of dz[b,:,:,c] */
 int dml_reduce_hw(const void* dz, void* dv, int B, int HW, int C, int lddz, int dtype, void* stream);
+/* out[b][c] = scale * sum over HW of x[b,:,:,c], x in `dtype`, out ALWAYS fp32.  The ASPP image-pooling branch
+ * (network/utils.py:318-329) runs a BatchNorm over only B samples per channel: its input (scale = 1/HW) and its output
+ * gradient (scale = 1) are B x C values whose sample-to-sample DIFFERENCES decide 1/sigma and the backward's
+ * cancellation, so the bf16 plans keep them unrounded. */
+int dml_reduce_hw_f32(const void* x, float* out, int B, int HW, int C, int ldx, int dtype, float scale, void* stream);
 /* dx[b,:,:,c] += dv[b][c] / HW */
 int dml_avgpool_bwd_add(const void* dv, void* dx, int B, int HW, int C, int lddx, int dtype, void* stream);
 /* dx[b,:,:,c] = dv[b][c] / HW.  In bf16 the plan lets this INITIALISE the gradient buffer and the data gradients of the

@@ -60,6 +60,9 @@ struct ConvArgs {
     const void* res_dz;
     const uint8_t* res_mask;
     int res_ld;
+    // data-gradient mode: fp32 sum of the earlier producers of this gradient, added before the one rounding (DmlConvDesc::acc32)
+    const float* acc32;
+    int acc32_ld;
     // bit 0: the epilogue's bf16 output stores carry the non-temporal hint, bit 1: its partial-statistics stores (launch_conv)
     int nt_out;
 };
@@ -239,6 +242,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
             // over dz / y / mask disappears.
             const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
             const bool resm = MODE == 1 && a.res_dz != nullptr;
+            constexpr bool a32 = MODE == 2;      // its own instantiation: the hot MODE 1 kernels keep their register budget
             const bool post = MODE == 0 && a.post_scale != nullptr;
 #pragma unroll
             for (int g = 0; g < CL / 8; ++g) {
@@ -264,7 +268,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                 }
                 // all of the group's loads (accumulate operand, BN input, mask bytes) are issued before the first
                 // use: one memory round trip per group instead of one per row
-                uint4 told[MT], ty[MT];
+                uint4 told[MT], ty[MT];      // (acc32: the row's eight floats, in told and ty -- never together with bnr)
                 uint32_t bits[MT], rbits[MT];
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
@@ -282,7 +286,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         if (post && a.post_res != nullptr)
                             told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.post_res) +
                                                                       (int64_t)m * a.post_ldres + n8);
-                        else if (a.accum)
+                        else if (a32) {
+                            // (32-bit element offset from the uniform base: the staging tensors stay below 2^32 bytes)
+                            const uint32_t ao = (uint32_t)m * (uint32_t)a.acc32_ld + (uint32_t)n8;
+                            told[j] = *reinterpret_cast<const uint4*>(a.acc32 + ao);
+                            ty[j] = *reinterpret_cast<const uint4*>(a.acc32 + ao + 4);
+                        } else if (a.accum)
                             told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.y) + (int64_t)m * a.ldy + n8);
                         if (bnr) {
                             ty[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.bnr_y) +
@@ -303,7 +312,12 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         for (int e = 0; e < 8; ++e) w[e] = (w[e] - rmu[e]) * r1[e] + r2[e];
                     }
                     bf16_t* yp = static_cast<bf16_t*>(a.y) + (int64_t)m * a.ldy + n8;
-                    {
+                    if (a32) {             // fp32 running sum of the earlier producers: this launch rounds the total once
+                        w[0] += __uint_as_float(told[j].x); w[1] += __uint_as_float(told[j].y);
+                        w[2] += __uint_as_float(told[j].z); w[3] += __uint_as_float(told[j].w);
+                        w[4] += __uint_as_float(ty[j].x); w[5] += __uint_as_float(ty[j].y);
+                        w[6] += __uint_as_float(ty[j].z); w[7] += __uint_as_float(ty[j].w);
+                    } else {
                         const uint32_t tt[4] = {told[j].x, told[j].y, told[j].z, told[j].w};      // zeros unless accumulating
 #pragma unroll
                         for (int e = 0; e < 4; ++e) {
@@ -466,7 +480,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w =
         __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)a.w_bytes, 0x00020000);
-    const int sh2 = (MODE == 1 && a.stride == 2) ? 1 : 0;
+    const int sh2 = (MODE != 0 && a.stride == 2) ? 1 : 0;
 
     int a_iy[A_LD], a_ix[A_LD], a_img[A_LD];       // generic path: pixel decomposition
     int a_base[A_LD];                               // fast path
@@ -808,7 +822,7 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(WPE))) v
     // per piece and lane: signed byte offset of the row's tap-(0,0) pixel (+ swizzled chunk) and one validity bit per
     // filter tap (image border, stride-2 parity of the data gradient) -- the per-K-step part is scalar (see
     // conv_igemm_kernel)
-    const int sh2 = (MODE == 1 && a.stride == 2) ? 1 : 0;
+    const int sh2 = (MODE != 0 && a.stride == 2) ? 1 : 0;
     int a_base[A_I];
     uint32_t a_mask[A_I];
 #pragma unroll
@@ -1028,7 +1042,7 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
 
     const int prow = lane >> 2;
     const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
-    const int sh2 = (MODE == 1 && a.stride == 2) ? 1 : 0;
+    const int sh2 = (MODE != 0 && a.stride == 2) ? 1 : 0;
 
     struct TileAddr {
         int a_base[A_I];
@@ -1916,7 +1930,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // other two's K loops, and a static tile list loses the dispatcher's load balancing.
             const int persist_kt = g_persist_kt < 0 ? (g_persist_kt = getenv("DML_CONV_PERSIST") ? atoi(getenv("DML_CONV_PERSIST")) : 0)
                                                     : g_persist_kt;
-            if (persist_kt > 0 && a.tail_q == 1 && !narrow && a.Ktot / BK >= 2 && a.Ktot / BK <= persist_kt) {
+            if (MODE != 2 && persist_kt > 0 && a.tail_q == 1 && !narrow && a.Ktot / BK >= 2 && a.Ktot / BK <= persist_kt) {
                 constexpr int SLOTS = 768;                      // three workgroups per CU
                 const bool wide = a.N > 64;
                 a.nblk_n = wide ? (a.N + 127) / 128 : (a.N + 63) / 64;
@@ -1924,11 +1938,12 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                 if (ntiles > SLOTS) {
                     const int rounds = (ntiles + SLOTS - 1) / SLOTS;
                     const int grid = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
+                    constexpr int PM = MODE == 2 ? 1 : MODE;      // (never taken with MODE 2: no such instantiation)
                     if (wide)
-                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<128, MODE>), dim3(grid), dim3(NTHREADS), 0, st, a,
+                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<128, PM>), dim3(grid), dim3(NTHREADS), 0, st, a,
                                            (uint32_t)xb, (uint32_t)wb, ntiles);
                     else
-                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<64, MODE>), dim3(grid), dim3(NTHREADS), 0, st, a,
+                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<64, PM>), dim3(grid), dim3(NTHREADS), 0, st, a,
                                            (uint32_t)xb, (uint32_t)wb, ntiles);
                     DML_LAUNCH_CHECK();
                     return 0;
@@ -1939,10 +1954,10 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                 const int ntiles = a.nblk_m * a.nblk_n;
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3>), dim3(a.tail_full + (ntiles - a.tail_full) * a.tail_q),
                                    dim3(NTHREADS), 0, st, a, (uint32_t)xb, (uint32_t)wb);
-            } else if (a.N > 64 && !narrow && smallk > 0 && a.Ktot <= smallk) {
+            } else if (MODE != 2 && a.N > 64 && !narrow && smallk > 0 && a.Ktot <= smallk) {
                 a.nblk_n = (a.N + 127) / 128;
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 2, 4>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
-                                   (uint32_t)xb, (uint32_t)wb);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, (MODE == 2 ? 1 : MODE), 2, 4>), dim3(a.nblk_m * a.nblk_n),
+                                   dim3(NTHREADS), 0, st, a, (uint32_t)xb, (uint32_t)wb);
             } else if (a.N > 64 && !narrow) {
                 a.nblk_n = (a.N + 127) / 128;
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a,
@@ -1956,28 +1971,32 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             return 0;
         }
     }
-    auto go = [&](auto bn_tag, auto al_tag) {
-        constexpr int BN = decltype(bn_tag)::value;
-        constexpr bool AL = decltype(al_tag)::value;
-        a.nblk_n = (a.N + BN - 1) / BN;
-        const int grid = a.nblk_m * a.nblk_n;
-        hipLaunchKernelGGL((conv_igemm_kernel<T, BN, AL, MODE>), dim3(grid), dim3(NTHREADS), 0, st, a);
-    };
-    using I128 = std::integral_constant<int, 128>;
-    using I64 = std::integral_constant<int, 64>;
-    using I32 = std::integral_constant<int, 32>;
-    const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
-    if (aligned) {
-        if (bn == 128) go(I128{}, std::true_type{});
-        else if (bn == 64) go(I64{}, std::true_type{});
-        else go(I32{}, std::true_type{});
+    if constexpr (MODE == 2) {
+        return DML_EUNSUPPORTED;      // acc32: LDS-DMA kernels only (bf16, C % 32 == 0, N > 32)
     } else {
-        if (bn == 128) go(I128{}, std::false_type{});
-        else if (bn == 64) go(I64{}, std::false_type{});
-        else go(I32{}, std::false_type{});
+        auto go = [&](auto bn_tag, auto al_tag) {
+            constexpr int BN = decltype(bn_tag)::value;
+            constexpr bool AL = decltype(al_tag)::value;
+            a.nblk_n = (a.N + BN - 1) / BN;
+            const int grid = a.nblk_m * a.nblk_n;
+            hipLaunchKernelGGL((conv_igemm_kernel<T, BN, AL, MODE>), dim3(grid), dim3(NTHREADS), 0, st, a);
+        };
+        using I128 = std::integral_constant<int, 128>;
+        using I64 = std::integral_constant<int, 64>;
+        using I32 = std::integral_constant<int, 32>;
+        const int bn = a.N > 64 ? 128 : (a.N > 32 ? 64 : 32);
+        if (aligned) {
+            if (bn == 128) go(I128{}, std::true_type{});
+            else if (bn == 64) go(I64{}, std::true_type{});
+            else go(I32{}, std::true_type{});
+        } else {
+            if (bn == 128) go(I128{}, std::false_type{});
+            else if (bn == 64) go(I64{}, std::false_type{});
+            else go(I32{}, std::false_type{});
+        }
+        DML_LAUNCH_CHECK();
+        return 0;
     }
-    DML_LAUNCH_CHECK();
-    return 0;
 }
 
 }  // namespace
@@ -2001,6 +2020,15 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
+    a.acc32 = nullptr; a.acc32_ld = 0;
+    if (d->acc32) {
+        // fp32 staging of a gradient with several producers: the 16-byte-vector bf16 path of the data gradient only
+        if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || d->accum || d->res_dz || d->bnr_partials) return DML_EINVAL;
+        if (d->N % 8 || d->ldy % 8 || d->acc32_ld % 4 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
+            (reinterpret_cast<uintptr_t>(d->acc32) & 15) || d->N <= 32)
+            return DML_EALIGN;
+        a.acc32 = d->acc32; a.acc32_ld = d->acc32_ld;
+    }
     if (d->res_dz) {
         // masked residual gradient in the epilogue: the 16-byte-vector bf16 path of the data gradient only
         if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || d->accum || !d->res_mask) return DML_EINVAL;
@@ -2042,6 +2070,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (a.acc32) return launch_conv<bf16_t, 2>(a, st);
     if (d->dtype == DML_BF16)
         return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
     return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
@@ -2078,7 +2107,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
-    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.acc32 = nullptr; a.acc32_ld = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -81,6 +81,7 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_global_avgpool_fwd),
     DML_ENTRY(dml_broadcast_hw),
     DML_ENTRY(dml_reduce_hw),
+    DML_ENTRY(dml_reduce_hw_f32),
     DML_ENTRY(dml_avgpool_bwd_add),
     DML_ENTRY(dml_avgpool_bwd_set),
     DML_ENTRY(dml_bilinear_fwd),

@@ -106,8 +106,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
 // out[b][c] = scale * sum_{p < HW} x[b][p][c];  block = 8 vector columns (128 B of a row) x 32 row lanes, four rows in
 // flight per lane: with 32 x 8 the launch had B * C / 256 workgroups (16 for the 256-channel gradient of the pooled
 // branch) and one load in flight per lane -- 145 us for 19 MB.
-template <typename T>
-__global__ __launch_bounds__(256) void reduce_hw_kernel(const T* __restrict__ x, T* __restrict__ out, int HW,
+template <typename T, typename TO = T>
+__global__ __launch_bounds__(256) void reduce_hw_kernel(const T* __restrict__ x, TO* __restrict__ out, int HW,
                                                         int C, int ldx, float scale) {
     constexpr int V = Vec16<T>::N;
     constexpr int COLS = 8, LANES = 32, U = 4;
@@ -147,7 +147,7 @@ __global__ __launch_bounds__(256) void reduce_hw_kernel(const T* __restrict__ x,
             float s = 0.f;
 #pragma unroll
             for (int r = 0; r < LANES; ++r) s += sh[r][threadIdx.x];
-            Elem<T>::st(out + (int64_t)b * C + cc, s * scale);
+            Elem<TO>::st(out + (int64_t)b * C + cc, s * scale);
         }
     }
 }
@@ -445,13 +445,16 @@ extern "C" int dml_maxpool3x3s2_bwd(const void* dy, const uint8_t* argmax, void*
 }
 
 static int launch_reduce_hw(const void* x, void* out, int B, int HW, int C, int ldx, int dtype, float scale,
-                            void* stream) {
+                            void* stream, bool out_f32 = false) {
     if (!x || !out || B <= 0 || HW <= 0) return DML_EINVAL;
     if (!vec_ok(dtype, C) || !vec_ok(dtype, ldx)) return DML_EALIGN;
     const int V = dtype == DML_BF16 ? 8 : 4;
     dim3 grid(B, (C / V + 7) / 8);
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (dtype == DML_BF16)
+    if (dtype == DML_BF16 && out_f32)
+        hipLaunchKernelGGL((reduce_hw_kernel<bf16_t, float>), grid, dim3(256), 0, st, (const bf16_t*)x, (float*)out, HW, C,
+                           ldx, scale);
+    else if (dtype == DML_BF16)
         hipLaunchKernelGGL(reduce_hw_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)x, (bf16_t*)out, HW, C,
                            ldx, scale);
     else
@@ -467,6 +470,10 @@ extern "C" int dml_global_avgpool_fwd(const void* x, void* y, int B, int HW, int
 }
 extern "C" int dml_reduce_hw(const void* dz, void* dv, int B, int HW, int C, int lddz, int dtype, void* stream) {
     return launch_reduce_hw(dz, dv, B, HW, C, lddz, dtype, 1.0f, stream);
+}
+extern "C" int dml_reduce_hw_f32(const void* x, float* out, int B, int HW, int C, int ldx, int dtype, float scale,
+                                 void* stream) {
+    return launch_reduce_hw(x, out, B, HW, C, ldx, dtype, scale, stream, true);
 }
 
 static int launch_broadcast(const void* v, void* z, int B, int HW, int C, int ldz, int dtype, float alpha,

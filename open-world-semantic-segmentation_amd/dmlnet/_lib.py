@@ -38,7 +38,9 @@ class ConvDesc(C.Structure):
                 # K-split of the tiles of a partially filled last round (see the header)
                 ("tail_ws", c_p), ("tail_ws_elems", C.c_int64), ("tail_counters", c_p),
                 ("tail_counters_len", C.c_int32), ("tail_reserved", C.c_int32),
-                ("res_dz", C.c_void_p), ("res_mask", C.c_void_p), ("res_ld", C.c_int32), ("res_reserved", C.c_int32)]
+                ("res_dz", C.c_void_p), ("res_mask", C.c_void_p), ("res_ld", C.c_int32), ("res_reserved", C.c_int32),
+                # fp32 staging of a gradient with several producers, rounded once by the last one (see the header)
+                ("acc32", C.c_void_p), ("acc32_ld", C.c_int32), ("acc32_reserved", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 22
@@ -103,6 +105,7 @@ _PROTOS = {
     "dml_global_avgpool_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_broadcast_hw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_reduce_hw": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_reduce_hw_f32": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_f, c_p]),
     "dml_avgpool_bwd_add": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_avgpool_bwd_set": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_bilinear_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),

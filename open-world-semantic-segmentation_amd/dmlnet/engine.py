@@ -261,13 +261,14 @@ class ParamStore:
 # ---------------------------------------------------------------------------------------------------
 class Act:
     """An NHWC activation (or gradient) living in a plan-owned buffer; may be a channel slice."""
-    __slots__ = ("t", "ptr", "B", "H", "W", "C", "ld", "f32", "es", "grad", "grad_init", "root")
+    __slots__ = ("t", "ptr", "B", "H", "W", "C", "ld", "f32", "es", "grad", "grad_init", "root", "g32")
 
     def __init__(self, t, ptr, B, H, W, C, ld, f32, es):
         self.t, self.ptr, self.B, self.H, self.W, self.C, self.ld, self.f32, self.es = t, ptr, B, H, W, C, ld, f32, es
         self.grad = None            # Act holding d(loss)/d(this)
         self.grad_init = False      # has any producer written the gradient yet?
         self.root = self            # concat buffer this is a slice of
+        self.g32 = None             # fp32 staging of the gradient while it still has producers to come (Plan.stage_grad32)
 
     @property
     def M(self):
@@ -320,6 +321,14 @@ class Plan:
         #                                that conv1's data gradient adds in its epilogue (DmlConvDesc.res_*)
         self.fuse_res_grad = os.environ.get("DML_FUSE_RES_GRAD", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
+        # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
+        # producer, as autograd does in the reference (resnet.py:112-113, network/utils.py:360).  Off by default: measured
+        # over 10 + 4 seeds (tests/tools/bf16_noise_seeds.py, profiles/r03_bf16_noise_seeds.txt) the per-tensor gradient
+        # noise is the same to three digits with a rounding after every producer (median 1 - cos 0.0788 vs 0.0789 at
+        # 4 x 256^2, 0.0995 vs 0.0995 at 2 x 768^2; emulation 0.077 / 0.097), while the fp32 staging tensors move 3 GB more
+        # per step (41.2 -> 42.0 ms).  The excess noise round 2 attributed to these roundings came from the bf16 rounding
+        # of the image-pooling branch's B x C tensors (_head_fwd).
+        self.stage32 = training and dtype == torch.bfloat16 and os.environ.get("DML_GRAD_STAGE32", "0") == "1"
         self.fork_branches = os.environ.get("DML_FORK_BRANCHES", "1") != "0"
         # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
         # of this network; backward: <= ~1100*N*2)
@@ -399,6 +408,16 @@ class Plan:
         g = root.grad.slice(c0, a.C)
         return g
 
+    def stage_grad32(self, a: Act):
+        """Declare d(loss)/d(a) a gradient with several producers (bf16 plans): the producers accumulate into an fp32
+        staging tensor and the last one (conv_dgrad(final=True), or a conversion) rounds the total once into the bf16
+        gradient the consumers read.  Rounding after every producer -- what a bf16 accumulate does -- costs about twice
+        the noise power: d(out) collects the pooled term and four ASPP data gradients, and the BatchNorm backward that
+        differences it amplifies whatever rounding noise it carries (profiles/r02_bf16_noise_by_depth.txt)."""
+        if not self.stage32 or a is not a.root or a.g32 is not None or a.C % 8 or a.C <= 32 or a.f32:
+            return
+        a.g32 = self.new(a.B, a.H, a.W, a.C, f32=True)
+
     def call(self, ops, fn, *args):
         lst = BoundArgs(args)
         ops.append((fn, lst))
@@ -442,18 +461,30 @@ class Plan:
         self.keep.append(dsc)
         self.call(self.fwd, self.lib.dml_conv_igemm, C.byref(dsc))
 
-    def conv_dgrad(self, dy: Act, conv: nn.Conv2d, wt, x: Act):
-        """d(loss)/dx (+)= conv^T(dy); x.grad is created on demand."""
+    def conv_dgrad(self, dy: Act, conv: nn.Conv2d, wt, x: Act, final=True):
+        """d(loss)/dx (+)= conv^T(dy); x.grad is created on demand.  `final`: no producer of this gradient comes after
+        this one (only looked at for staged gradients, stage_grad32)."""
         gx = self.grad_of(x)
         kh, kw, s, d, p, _, _ = self.conv_geom(conv, x)
         dsc = ConvDesc(x=dy.ptr, w=wt.data_ptr(), y=gx.ptr, bias=None, stats=None, pre_scale=None,
                        pre_shift=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld, Ho=x.H, Wo=x.W, N=x.C,
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
                        accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
+        g32 = x.g32 if x is x.root else None
+        convert = False
+        if g32 is not None and not (final and not x.root.grad_init):
+            if final and dy.C % 32 == 0 and kh * kw <= 32:
+                # last producer: conv + fp32 sum of the others, rounded once (DmlConvDesc.acc32, LDS-DMA kernels)
+                dsc.accum, dsc.acc32, dsc.acc32_ld = 0, g32.ptr, g32.ld
+            else:
+                dsc.y, dsc.ldy, dsc.y_f32 = g32.ptr, g32.ld, 1
+                convert = final
+        else:
+            g32 = None
         res = self.res_src.pop(id(x), None)
         if res is not None:
             # the identity branch's share of this gradient (block output gradient x ReLU mask) is added in the epilogue
-            assert not x.root.grad_init and x is x.root
+            assert not x.root.grad_init and x is x.root and g32 is None
             rdz, rmask = res
             dsc.res_dz, dsc.res_mask, dsc.res_ld = rdz.ptr, rmask.data_ptr(), rdz.ld
         x.root.grad_init = True
@@ -461,9 +492,17 @@ class Plan:
         dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
         self.keep.append(dsc)
         self.call(self.bwd, self.lib.dml_conv_igemm, C.byref(dsc))
+        if convert:
+            self.round_staged(x)
         self.last_dgrad.pop(self.grad_of(x.root).ptr, None)
-        if x is x.root:
+        if x is x.root and g32 is None:
             self.last_dgrad[gx.ptr] = dsc         # whole-tensor gradient: candidate for the fused BN-backward reduce
+
+    def round_staged(self, x: Act):
+        """fp32 staging tensor -> the bf16 gradient (a staged gradient whose last producer cannot do it itself)"""
+        g = self.grad_of(x)
+        assert x is x.root and g.ld == g.C and x.g32.ld == g.C
+        self.call(self.bwd, self.lib.dml_convert_dtype, x.g32.ptr, g.ptr, g.M * g.C, DML_F32, DML_BF16)
 
     def conv_wgrad(self, x: Act, dy: Act, conv: nn.Conv2d, Cp: int, pad_rows: int = 0):
         """pad_rows: dy carries `pad_rows` >= out_channels channels (zero beyond); the padded rows of the gradient
@@ -593,11 +632,11 @@ class Plan:
         self.units.append(u)
         return u
 
-    def unit_bwd(self, u: ConvUnit, dz: Act, dres: Optional[Act] = None, dres_accum=False, need_dgrad=True):
-        """Backward of `cbr`: BN (two passes) -> weight gradient -> data gradient into u.x.grad."""
+    def unit_bwd(self, u: ConvUnit, dz: Act, dres: Optional[Act] = None, dres_accum=False, need_dgrad=True, final=True):
+        """Backward of `cbr`: BN (two passes) -> weight gradient -> data gradient into u.x.grad (`final`: conv_dgrad)."""
         if u.dtype != self.dtype:
             with self.precision(u.dtype):
-                return self.unit_bwd(u, dz, dres, dres_accum, need_dgrad)
+                return self.unit_bwd(u, dz, dres, dres_accum, need_dgrad, final)
         lib, st = self.lib, self.e.store
         N, M = u.conv.out_channels, u.y.M
         bn = u.bn
@@ -654,7 +693,7 @@ class Plan:
             self.last_dgrad.pop(dres.ptr, None)   # written by the BN kernel, not by a data gradient
         self.conv_wgrad(u.x, dy, u.conv, u.Cp)
         if need_dgrad:
-            self.conv_dgrad(dy, u.conv, u.wt, u.x)
+            self.conv_dgrad(dy, u.conv, u.wt, u.x, final=final)
 
     # ---- the network -------------------------------------------------------------------------
     def build(self):
@@ -725,6 +764,13 @@ class Plan:
         # segments of the plan can be skipped when the loss does not reach them (Engine.backward).
         self.head_bwd_range = {}
         self.to_backbone_ops = []
+        # gradients with several producers: d(out) (pooled term + four ASPP data gradients per head), d(low) (decoder
+        # projection + layer2.0's conv1 and downsample), and the input of every other block with a downsample branch
+        self.stage_grad32(out)
+        self.stage_grad32(low)
+        for (xb, u1, u2, u3, ud) in blocks:
+            if ud is not None:
+                self.stage_grad32(xb)
         for hi in reversed(range(len(self.heads))):
             start = len(self.bwd)
             self._head_bwd(self.heads[hi], low, out)
@@ -734,6 +780,8 @@ class Plan:
         # parameter requires a gradient: the reference's incremental recipe trains one new head on a fixed trunk,
         # main_self_distillation.py:352-357)
         backbone_start = len(self.bwd)
+        if out.g32 is not None and len(self.heads) > 1:
+            self.round_staged(out)                      # several heads: which of them runs last is only known per step
         for (xb, u1, u2, u3, ud) in reversed(blocks):
             dz = self.grad_of(u3.z)
             if ud is not None:
@@ -753,7 +801,7 @@ class Plan:
                 self.unit_bwd(u3, dz, dres=dres, dres_accum=xb.root.grad_init)
                 xb.root.grad_init = True
             self.unit_bwd(u2, self.grad_of(u2.z))
-            self.unit_bwd(u1, self.grad_of(u1.z))
+            self.unit_bwd(u1, self.grad_of(u1.z), final=ud is None)
             assert not self.res_src, "conv1's data gradient did not take the identity-branch gradient"
             if ud is not None:
                 self.unit_bwd(ud, self.grad_of(ud.z))
@@ -785,25 +833,27 @@ class Plan:
             branches.append(self.cbr(out, aspp.convs[i][0], aspp.convs[i][1], out=cat1.slice(256 * i, 256)))
             marks.append(len(self.fwd))
         # image-pooling branch (network/utils.py:318-329): avg-pool -> 1x1 -> BN -> ReLU -> broadcast
-        pooled = self.new(B, 1, 1, out.C)
-        self.call(self.fwd, lib.dml_global_avgpool_fwd, out.ptr, pooled.ptr, B, out.H * out.W, out.C, out.ld, self.dt)
         if self.training and self.dtype == torch.bfloat16:
             # This BatchNorm sees B samples per channel.  When two of them are within bf16 resolution of each other the
             # rounded pre-normalisation values collapse, 1/sigma goes to 1/sqrt(eps) and the layer's backward -- whose two
             # correction terms cancel its output gradient almost exactly -- returns a spurious gradient hundreds of times
             # too large that the broadcast spreads over every pixel of d(out) (measured at 768 x 768, 2 images: layer4's
-            # bn3 gradients 20x their true norm).  The unit is B x 256 values: it runs in fp32 storage, with tiny
-            # conversions at its three bf16 boundaries.
+            # bn3 gradients 20x their true norm).  The unit is B x 256 values: it runs in fp32 storage, and so do its
+            # input (the pooled features) and its output gradient -- B x C numbers whose sample-to-sample DIFFERENCES
+            # decide 1/sigma and the cancellation (dml_reduce_hw_f32); only its output is rounded for the bf16 concat.
             with self.precision(torch.float32):
-                pooled32 = self.new(B, 1, 1, out.C)
-                self.call(self.fwd, lib.dml_convert_dtype, pooled.ptr, pooled32.ptr, B * out.C, DML_BF16, DML_F32)
-                upool = self.cbr(pooled32, aspp.convs[4][1], aspp.convs[4][2])
+                pooled = self.new(B, 1, 1, out.C)
+                self.call(self.fwd, lib.dml_reduce_hw_f32, out.ptr, pooled.ptr, B, out.H * out.W, out.C, out.ld, DML_BF16,
+                          1.0 / (out.H * out.W))
+                upool = self.cbr(pooled, aspp.convs[4][1], aspp.convs[4][2])
             zq = self.new(B, 1, 1, 256)
             self.call(self.fwd, lib.dml_convert_dtype, upool.z.ptr, zq.ptr, B * 256, DML_F32, DML_BF16)
-            pool_z, pooled_in = zq, pooled32
+            pool_z, pool_f32 = zq, True
         else:
+            pooled = self.new(B, 1, 1, out.C)
+            self.call(self.fwd, lib.dml_global_avgpool_fwd, out.ptr, pooled.ptr, B, out.H * out.W, out.C, out.ld, self.dt)
             upool = self.cbr(pooled, aspp.convs[4][1], aspp.convs[4][2])
-            pool_z, pooled_in = upool.z, pooled
+            pool_z, pool_f32 = upool.z, False
         self.call(self.fwd, lib.dml_broadcast_hw, pool_z.ptr, cat1.slice(1024, 256).ptr, B, out.H * out.W, 256,
                   cat1.ld, self.dt)
         marks.append(len(self.fwd))
@@ -847,7 +897,7 @@ class Plan:
         rec = HeadRec()
         rec.K, rec.Kp, rec.emb, rec.protos, rec.head_args = K, Kp, emb, protos, head_args
         rec.cat1, rec.cat2, rec.up_low, rec.branches, rec.pooled, rec.upool = cat1, cat2, up_low, branches, pooled, upool
-        rec.pooled_in = pooled_in
+        rec.pool_f32 = pool_f32
         rec.uproj, rec.ucls, rec.fin, rec.wt_fin = uproj, ucls, fin, wt_fin
         rec.head_bwd_args, rec.df, rec.feats_p = None, None, None
         return rec
@@ -897,35 +947,44 @@ class Plan:
         self.unit_bwd(uproj, dproj)                                      # -> d cat1
         dcat1 = self.grad_of(cat1)
         # pooling branch
-        dzp = self.new(B, 1, 1, 256)
-        self.call(self.bwd, lib.dml_reduce_hw, dcat1.slice(1024, 256).ptr, dzp.ptr, B, out.H * out.W, 256, dcat1.ld,
-                  self.dt)
-        if rec.pooled_in is not pooled:                                  # the unit lives in fp32 storage (_head_fwd)
+        staged = out.g32 is not None
+        if rec.pool_f32:                                                 # the unit lives in fp32 storage (_head_fwd)
             with self.precision(torch.float32):
-                dzp32 = self.new(B, 1, 1, 256)
-                self.call(self.bwd, lib.dml_convert_dtype, dzp.ptr, dzp32.ptr, B * 256, DML_BF16, DML_F32)
-                self.unit_bwd(upool, dzp32)                              # -> d pooled (fp32)
-                g32 = self.grad_of(rec.pooled_in)
-            self.call(self.bwd, lib.dml_convert_dtype, g32.ptr, self.grad_of(pooled).ptr, B * out.C, DML_F32, DML_BF16)
-            pooled.root.grad_init = True
+                dzp = self.new(B, 1, 1, 256)
+                self.call(self.bwd, lib.dml_reduce_hw_f32, dcat1.slice(1024, 256).ptr, dzp.ptr, B, out.H * out.W, 256,
+                          dcat1.ld, DML_BF16, 1.0)
+                self.unit_bwd(upool, dzp)                                # -> d pooled (fp32)
+                gp32 = self.grad_of(pooled)
+            if not staged:
+                gpq = self.new(B, 1, 1, out.C)
+                self.call(self.bwd, lib.dml_convert_dtype, gp32.ptr, gpq.ptr, B * out.C, DML_F32, DML_BF16)
         else:
+            assert not staged
+            dzp = self.new(B, 1, 1, 256)
+            self.call(self.bwd, lib.dml_reduce_hw, dcat1.slice(1024, 256).ptr, dzp.ptr, B, out.H * out.W, 256, dcat1.ld,
+                      self.dt)
             self.unit_bwd(upool, dzp)                                    # -> d pooled
+            gpq = self.grad_of(pooled)
         feeders = self.to_backbone_ops                 # backward ops whose only product is d(out) / d(low)
         # The image-pooling branch contributes dv / HW to every pixel of d(out): far below half an ulp of the other four
         # branches' sum in bf16.  It goes in FIRST (while the buffer is still untouched), so that the data gradients
-        # accumulate onto it in fp32 before each rounding and the term survives on average; a later head's segment finds
+        # accumulate onto it in fp32 before the rounding and the term survives on average; a later head's segment finds
         # the buffer initialised and adds.
         first = not out.root.grad_init
-        self.call(self.bwd, lib.dml_avgpool_bwd_set if first else lib.dml_avgpool_bwd_add, self.grad_of(pooled).ptr,
-                  self.grad_of(out).ptr, B, out.H * out.W, out.C, self.grad_of(out).ld, self.dt)
+        if staged:              # fp32 staging tensor (stage_grad32): the last ASPP data gradient rounds the sum once
+            self.call(self.bwd, lib.dml_avgpool_bwd_set if first else lib.dml_avgpool_bwd_add, gp32.ptr, out.g32.ptr, B,
+                      out.H * out.W, out.C, out.g32.ld, DML_F32)
+        else:
+            self.call(self.bwd, lib.dml_avgpool_bwd_set if first else lib.dml_avgpool_bwd_add, gpq.ptr,
+                      self.grad_of(out).ptr, B, out.H * out.W, out.C, self.grad_of(out).ld, self.dt)
         out.root.grad_init = True
         feeders.append(len(self.bwd) - 1)
         for i in range(4):
-            self.unit_bwd(branches[i], dcat1.slice(256 * i, 256))       # -> d out (accumulating)
+            self.unit_bwd(branches[i], dcat1.slice(256 * i, 256), final=(i == 3 and len(self.heads) == 1))   # -> d out
             feeders.append(len(self.bwd) - 1)           # unit_bwd ends with the data gradient
         self.last_dgrad.pop(self.grad_of(out).ptr, None)      # several writers: layer4's last BN keeps its own reduce
         # low-level projection -> d low (layer1 output)
-        self.unit_bwd(up_low, dcat2.slice(0, 48))
+        self.unit_bwd(up_low, dcat2.slice(0, 48), final=False)          # layer2.0's data gradients follow
         feeders.append(len(self.bwd) - 1)
 
     # ---- execution ---------------------------------------------------------------------------

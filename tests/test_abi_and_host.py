@@ -35,9 +35,10 @@ def test_struct_layout_matches_header():
     from dmlnet._lib import ConvDesc, WgradDesc
     # 7 ptr + 19 int32 (+4 pad) | bnr: 5 ptr + 2 int32 | post: 4 ptr + 2 int32 | tail: ptr, int64, ptr, 2 int32 |
     # res: 2 ptr + 2 int32
-    assert ctypes.sizeof(ConvDesc) == 7 * 8 + 19 * 4 + 4 + 5 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4
+    assert ctypes.sizeof(ConvDesc) == 7 * 8 + 19 * 4 + 4 + 5 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 2 * 4
     assert ConvDesc.tail_ws.offset == 224 and ConvDesc.tail_counters_len.offset == 248
     assert ConvDesc.res_dz.offset == 256 and ConvDesc.res_ld.offset == 272
+    assert ConvDesc.acc32.offset == 280 and ConvDesc.acc32_ld.offset == 288
     assert ConvDesc.bnr_y.offset == 136 and ConvDesc.bnr_ldy.offset == 176 and ConvDesc.post_scale.offset == 184
     from dmlnet._lib import BnEvalDesc
     assert ctypes.sizeof(BnEvalDesc) == 48

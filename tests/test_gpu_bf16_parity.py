@@ -89,66 +89,81 @@ def _vs_truth(grads, truth):
     return np.array(one_minus_cos), np.array(ratio)
 
 
-def _statistical_equivalence(shape, seed, tag):
+def _statistical_equivalence(shape, seeds, tag):
     """End to end, bf16 mode.  A deep BatchNorm network in train mode amplifies perturbations: on these inputs a 1e-3
     relative change of the IMAGE moves the bf16-storage oracle's own gradients by 1 - cos = 0.08 (4 x 256^2; tools:
     tests/tools/bf16_noise.py), so two correct bf16 implementations cannot agree element by element.  What a correct
     one must do is sit exactly as far from the fp32 truth as the emulated bf16 oracle does -- logits, loss and, for EVERY
     parameter tensor, direction (cosine) and magnitude (norm ratio) of the gradient.  A mis-scaled or mis-wired
-    gradient on any layer class shows as a norm ratio of 2 / 0.5 or a cosine near 0 on those tensors."""
+    gradient on any layer class shows as a norm ratio of 2 / 0.5 or a cosine near 0 on those tensors.
+
+    One draw of that comparison is itself a random variable: the per-tensor 1 - cos of BOTH implementations moves by
+    +-20 % from input to input (the ASPP image-pooling BatchNorm over B samples amplifies whatever reaches it), so the
+    ratio hip / emulation of a single seed scatters by +-0.14.  The gate therefore averages over several seeds (weights
+    and inputs); measured with tests/tools/bf16_noise_seeds.py (profiles/r03_bf16_noise_seeds.txt): median x1.05 +- 0.05
+    over 10 seeds at 4 x 256^2, x1.04 +- 0.07 over 4 seeds at 2 x 768^2.  Bars: 1.3x the emulation on median and p95
+    (round 2: 2.5x), 1.5x on the maximum over the 338 tensors (2x), norm-ratio spread 1.3x."""
     import utils
     torch.set_num_threads(min(64, torch.get_num_threads() or 8))
-    img = H.synth_tensor(seed, tag + ".img", shape)
-    lab = H.synth_labels(seed, tag + ".lab", (shape[0], shape[2], shape[3]), 16, 255, ignore_frac=0.05)
-    m = _build_hip(torch.bfloat16, seed)
-    lg, _, ft = m(img.cuda())
-    loss = utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft)
-    loss.backward()
-    torch.cuda.synchronize()
-    g_hip = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
-    t_lg, t_loss, g_true, o32 = _oracle_grads(seed, shape, tag, emulate=False)
-    e_lg, e_loss, g_emu, oemu = _oracle_grads(seed, shape, tag, emulate=True)
-    d_hip, d_emu = H.rel_err(lg, t_lg), H.rel_err(e_lg, t_lg)
-    l_hip, l_emu = abs(loss.item() - t_loss) / abs(t_loss), abs(e_loss - t_loss) / abs(t_loss)
-    c_hip, r_hip = _vs_truth(g_hip, g_true)
-    c_emu, r_emu = _vs_truth(g_emu, g_true)
-    names = list(g_true.keys())
-    print("%s vs fp32 oracle | logits: hip %.2e emu %.2e | loss: hip %.2e emu %.2e | 1-cos median/p95/max: hip %.2e %.2e "
-          "%.2e (%s) emu %.2e %.2e %.2e | norm ratio median [min,max]: hip %.3f [%.3f (%s), %.3f (%s)] emu %.3f [%.3f, %.3f]"
-          % (tag, d_hip, d_emu, l_hip, l_emu, np.median(c_hip), np.percentile(c_hip, 95), c_hip.max(),
-             names[int(np.argmax(c_hip))], np.median(c_emu), np.percentile(c_emu, 95), c_emu.max(), np.median(r_hip),
-             r_hip.min(), names[int(np.argmin(r_hip))], r_hip.max(), names[int(np.argmax(r_hip))], np.median(r_emu),
-             r_emu.min(), r_emu.max()))
-    assert torch.isfinite(lg).all()
-    assert d_hip <= 2.0 * d_emu + 1e-3, (d_hip, d_emu)
-    assert l_hip <= 3.0 * l_emu + 2e-3, (l_hip, l_emu)
-    # direction: the distribution over the 338 tensors must match the emulation's.  The emulation rounds a gradient that
-    # has several producers ONCE (autograd sums in fp32), the plan rounds after every producer (d(out): the pooled term +
-    # four ASPP data gradients; every residual connection: identity part, then conv1's data gradient).  That gradient is
-    # then differenced by a BatchNorm backward, and the extra roundings cost up to 2.3x in noise power (1 - cos) from
-    # layer4 down -- measured per tensor with tests/tools/debug_bf16_depth.py: head tensors 1.0-1.3x, layer4 ... stem
-    # 1.8-2.3x, flat along the depth, no tensor worse.  Bars: 2.5x the emulation's median / p95, 2x its maximum.
-    assert np.median(c_hip) <= 2.5 * np.median(c_emu) + 2e-3
-    assert np.percentile(c_hip, 95) <= 2.5 * np.percentile(c_emu, 95) + 5e-3
-    assert c_hip.max() <= 2.0 * c_emu.max() + 2e-2, names[int(np.argmax(c_hip))]
-    # magnitude: no tensor off by a factor, the bulk within the emulation's own spread
-    spread = max(abs(r_emu.max() - 1), abs(1 - r_emu.min()))
-    assert abs(np.median(r_hip) - 1) <= abs(np.median(r_emu) - 1) + 0.03
-    assert r_hip.max() <= 1 + 2.0 * spread + 0.05 and r_hip.min() >= 1 - 2.0 * spread - 0.05, (r_hip.min(), r_hip.max(), spread)
-    # running statistics come from the fp32 accumulators of bf16 convolutions on both sides
-    bufs, obufs = dict(m.named_buffers()), dict(oemu.named_buffers())
-    for k in ("backbone.bn1.running_var", "backbone.layer3.11.bn2.running_mean", "backbone.layer4.2.bn3.running_var",
-              "classifier.classifier.1.running_var"):
-        assert H.rel_err(bufs[k], obufs[k]) <= max(2.0 * H.rel_err(dict(o32.named_buffers())[k], obufs[k]), 1e-3), k
-    return m
+    stat = {"hip": [], "emu": []}
+    for seed in seeds:
+        img = H.synth_tensor(seed, tag + ".img", shape)
+        lab = H.synth_labels(seed, tag + ".lab", (shape[0], shape[2], shape[3]), 16, 255, ignore_frac=0.05)
+        m = _build_hip(torch.bfloat16, seed)
+        lg, _, ft = m(img.cuda())
+        loss = utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft)
+        loss.backward()
+        torch.cuda.synchronize()
+        g_hip = {k: p.grad.detach().double().cpu() for k, p in m.named_parameters()}
+        t_lg, t_loss, g_true, o32 = _oracle_grads(seed, shape, tag, emulate=False)
+        e_lg, e_loss, g_emu, oemu = _oracle_grads(seed, shape, tag, emulate=True)
+        d_hip, d_emu = H.rel_err(lg, t_lg), H.rel_err(e_lg, t_lg)
+        l_hip, l_emu = abs(loss.item() - t_loss) / abs(t_loss), abs(e_loss - t_loss) / abs(t_loss)
+        c_hip, r_hip = _vs_truth(g_hip, g_true)
+        c_emu, r_emu = _vs_truth(g_emu, g_true)
+        names = list(g_true.keys())
+        print("%s seed %d vs fp32 oracle | logits: hip %.2e emu %.2e | loss: hip %.2e emu %.2e | 1-cos median/p95/max: hip "
+              "%.2e %.2e %.2e (%s) emu %.2e %.2e %.2e | norm ratio median [min,max]: hip %.3f [%.3f (%s), %.3f (%s)] emu %.3f "
+              "[%.3f, %.3f]"
+              % (tag, seed, d_hip, d_emu, l_hip, l_emu, np.median(c_hip), np.percentile(c_hip, 95), c_hip.max(),
+                 names[int(np.argmax(c_hip))], np.median(c_emu), np.percentile(c_emu, 95), c_emu.max(), np.median(r_hip),
+                 r_hip.min(), names[int(np.argmin(r_hip))], r_hip.max(), names[int(np.argmax(r_hip))], np.median(r_emu),
+                 r_emu.min(), r_emu.max()))
+        assert torch.isfinite(lg).all()
+        stat["hip"].append((d_hip, l_hip, np.median(c_hip), np.percentile(c_hip, 95), c_hip.max(), np.median(r_hip),
+                            r_hip.max() - r_hip.min()))
+        stat["emu"].append((d_emu, l_emu, np.median(c_emu), np.percentile(c_emu, 95), c_emu.max(), np.median(r_emu),
+                            r_emu.max() - r_emu.min()))
+        # per seed: nothing mis-wired or mis-scaled (a wrong gradient is O(1) on these), running statistics equivalent
+        assert c_hip.max() <= 2.0 * c_emu.max() + 2e-2, names[int(np.argmax(c_hip))]
+        assert 0.6 <= r_hip.min() and r_hip.max() <= 1.5, (r_hip.min(), r_hip.max())
+        bufs, obufs = dict(m.named_buffers()), dict(oemu.named_buffers())
+        for k in ("backbone.bn1.running_var", "backbone.layer3.11.bn2.running_mean", "backbone.layer4.2.bn3.running_var",
+                  "classifier.classifier.1.running_var"):
+            assert H.rel_err(bufs[k], obufs[k]) <= max(2.0 * H.rel_err(dict(o32.named_buffers())[k], obufs[k]), 1e-3), k
+        del m
+        torch.cuda.empty_cache()
+    hip, emu = np.array(stat["hip"]).mean(0), np.array(stat["emu"]).mean(0)
+    print("%s mean over %d seeds | hip / emulation: logits %.2f loss %.2f | 1-cos median x%.3f p95 x%.3f max x%.3f | norm "
+          "median %.3f vs %.3f, spread %.3f vs %.3f" % (tag, len(seeds), hip[0] / emu[0], hip[1] / emu[1], hip[2] / emu[2],
+                                                          hip[3] / emu[3], hip[4] / emu[4], hip[5], emu[5], hip[6], emu[6]))
+    assert hip[0] <= 1.5 * emu[0] + 1e-3, (hip[0], emu[0])
+    assert hip[1] <= 3.0 * emu[1] + 2e-3, (hip[1], emu[1])
+    # direction: the distribution over the 338 tensors must be the emulation's
+    assert hip[2] <= 1.3 * emu[2] + 2e-3, (hip[2], emu[2])
+    assert hip[3] <= 1.3 * emu[3] + 5e-3, (hip[3], emu[3])
+    assert hip[4] <= 1.5 * emu[4] + 1e-2, (hip[4], emu[4])
+    # magnitude: the bulk as well centred as the emulation's, the spread over the tensors no wider than 1.3x
+    assert abs(hip[5] - 1) <= abs(emu[5] - 1) + 0.1, (hip[5], emu[5])
+    assert hip[6] <= 1.3 * emu[6] + 0.05, (hip[6], emu[6])
 
 
 def test_bf16_end_to_end_4x256_statistically_equivalent_to_emulated_oracle():
-    _statistical_equivalence((4, 3, 256, 256), 9, "bf16.256")
+    _statistical_equivalence((4, 3, 256, 256), (9, 10, 11, 12, 13), "bf16.256")
 
 
 def test_bf16_end_to_end_768_bs2_statistically_equivalent_to_emulated_oracle():
-    _statistical_equivalence((2, 3, 768, 768), 77, "bf16.768")
+    _statistical_equivalence((2, 3, 768, 768), (77, 78, 79), "bf16.768")
 
 
 def _act(a):
@@ -163,17 +178,24 @@ def _nchw(a2d, B, Hh, Ww):
     return a2d.view(B, Hh, Ww, -1).permute(0, 3, 1, 2).contiguous()
 
 
-@pytest.mark.parametrize("shape,seed", [((2, 3, 768, 768), 77), ((3, 3, 96, 160), 9)])
-def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
+@pytest.mark.parametrize("shape,seed,stage32", [((2, 3, 768, 768), 77, 0), ((3, 3, 96, 160), 9, 0), ((3, 3, 96, 160), 9, 1)])
+def test_bf16_plan_every_unit_is_locally_exact(shape, seed, stage32, monkeypatch):
     """The tight gate for the kernels bench.py times.  One bf16 train step; then for EVERY conv + BN (+ residual + ReLU)
     unit of the plan, from the plan's OWN stored tensors: the unit's outputs are recomputed with torch on the CPU in
     fp32 / fp64 and compared at bf16 resolution -- forward conv (conv_igemm_dma_kernel), batch statistics from the fp32
     accumulators, BN apply; backward BN (fused reduce in the data-gradient epilogue or stand-alone), gamma / beta
     gradients, weight gradient (conv_wgrad_big_kernel / conv_wgrad_kernel + split-K fold), data gradient.  Teacher
     forcing removes the chaos of the end-to-end comparison: every kernel is held to 1 bf16 ulp on its actual inputs at
-    the benchmark's map sizes."""
+    the benchmark's map sizes.
+
+    Gradients with SEVERAL producers (d(out): the pooled term + four ASPP data gradients; the input of a block with a
+    downsample branch: two data gradients, d(low) three; every other block input: conv1's data gradient + the masked
+    identity-branch gradient) are checked as sums: the stored gradient against the fp32 sum of all its consumers'
+    recomputed contributions -- one bf16 rounding where the plan rounds once (the fused identity add; fp32 staging,
+    `stage32` = DML_GRAD_STAGE32=1, DmlConvDesc.acc32), one per producer otherwise."""
     import torch.nn.functional as F
     import utils
+    monkeypatch.setenv("DML_GRAD_STAGE32", str(stage32))
     torch.set_num_threads(min(64, torch.get_num_threads() or 8))
     img = H.synth_tensor(seed, "unit.img", shape)
     lab = H.synth_labels(seed, "unit.lab", (shape[0], shape[2], shape[3]), 16, 255, ignore_frac=0.05)
@@ -200,6 +222,15 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
         return (got.double() - ref.double()).abs().max().item() / (ref.double().abs().max().item() + 1e-30)
 
     n_fused = 0
+    gsum, nprod, n_ident, root_of = {}, Counter(), Counter(), {}      # per gradient buffer: fp32 sum of its consumers' contributions
+
+    def contribute(root, g, identity=False):
+        k = id(root)
+        root_of[k] = root
+        gsum[k] = g.double() if k not in gsum else gsum[k] + g.double()
+        nprod[k] += 1
+        n_ident[k] += 1 if identity else 0
+
     for u in plan.units:
         name = names[id(u.conv)]
         conv, bn = u.conv, u.bn
@@ -209,7 +240,8 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
         if u.dtype == torch.bfloat16:                  # (the ASPP image-pooling unit lives in fp32 storage: fp32 weights)
             wq = wq.to(torch.bfloat16).float()
         wq = wq.contiguous().requires_grad_(True)
-        xr = x.clone().requires_grad_(consumers[id(u.x.root)] == 1 and u.x is u.x.root and u.x.root.grad is not None)
+        has_grad = u.x is u.x.root and u.x.root.grad is not None
+        xr = x.clone().requires_grad_(has_grad)
         y_ref = F.conv2d(xr, wq, None, conv.stride, conv.padding, conv.dilation)
         y = _nchw(_act(u.y), u.y.B, u.y.H, u.y.W)
         note("conv fwd (stored y vs fp32 conv of the stored operands)", name, relmax(y, y_ref.detach()), 1.05 * ULP)
@@ -241,14 +273,36 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed):
         # ---- weight / data gradient from the stored x and dy
         y_ref.backward(dy)
         note("weight gradient", name, relmax(conv.weight.grad.cpu(), wq.grad), 2e-3)
-        if xr.requires_grad:
+        if xr.requires_grad and consumers[id(u.x.root)] == 1:
             gx = _nchw(_act(u.x.root.grad), u.x.B, u.x.H, u.x.W)[:, :cin]
             note("data gradient", name, relmax(gx, xr.grad), 1.05 * ULP)
+        elif xr.requires_grad:
+            contribute(u.x.root, xr.grad)
+        if u.res is not None and u.res is u.res.root and u.res.root.grad is not None and consumers[id(u.res.root)] > 1:
+            contribute(u.res.root, g.float(), identity=True)      # the identity branch hands the masked block-output gradient on
+    # the image-pooling branch reads `out` through the global average pool: its input gradient / HW reaches every pixel
+    rec = plan.heads[0]
+    out_root = rec.branches[0].x.root
+    gp = _act(rec.pooled.root.grad)                                            # [B, C]
+    contribute(out_root, (gp / (out_root.H * out_root.W)).view(out_root.B, -1, 1, 1).expand(-1, -1, out_root.H, out_root.W))
+    n_multi = 0
+    for k, tot in gsum.items():
+        root = root_of[k]
+        stored = _nchw(_act(root.grad), root.B, root.H, root.W)[:, :tot.shape[1]]
+        # the identity branch's term is a masked copy of a stored bf16 tensor: it adds no rounding of its own
+        roundings = 1 if root.g32 is not None else max(1, nprod[k] - n_ident[k])
+        nm = next((names[id(uu.conv)] for uu in plan.units if uu.x is root), "?")
+        note("gradient with several producers, %d rounding%s" % (roundings, "s" if roundings > 1 else ""),
+             "%d producers, input of %s" % (nprod[k], nm), relmax(stored, tot), 1.05 * ULP * roundings)
+        n_multi += 1
+    assert n_multi >= 33                      # every block input + d(out) + d(low) (= layer2.0's input)
     dsc_fused = sum(1 for fn, args in plan.bwd if fn is plan.lib.dml_conv_igemm and args[0]._obj.bnr_partials)
     print("units %d, data gradients with the fused BN-backward sums %d; worst: %s"
           % (len(plan.units), dsc_fused, "; ".join("%s %.2e (%s)" % (k, v[0], v[1]) for k, v in worst.items())))
     assert len(plan.units) == 113 - 1          # 112 conv+BN units (the final 1x1 conv has no BN)
     assert dsc_fused >= 60                      # the timed configuration: most reduces run inside the data gradients
+    n_acc32 = sum(1 for fn, args in plan.bwd if fn is plan.lib.dml_conv_igemm and args[0]._obj.acc32)
+    assert n_acc32 == (5 if stage32 else 0), n_acc32       # d(out) + the four blocks with a downsample branch (low = layer2.0's)
 
 
 def test_fp32_768_bs2_against_oracle():

@@ -499,6 +499,41 @@ def test_self_distillation_model_both_heads_against_oracle():
     assert np.median(errs) <= 1e-3 and np.percentile(errs, 95) <= 3e-2 and errs.max() <= 0.2
 
 
+@pytest.mark.parametrize("both", [True, False])
+def test_multihead_bf16_fp32_staged_gradients(both, monkeypatch):
+    """DML_GRAD_STAGE32=1 on the two-head bf16 plan: d(out) is summed in fp32 over BOTH heads' segments and rounded by
+    a conversion at the head of the backbone segment (which head runs last is only known per step), d(low) by layer2.0's
+    downsample data gradient.  Same forward, so the gradients must equal the per-producer-rounding plan's up to that
+    rounding noise -- with a loss on both heads and with the base head's segment skipped."""
+    import utils
+    img = H.synth_tensor(12, "g12.img", (2, 3, 96, 96)).cuda()
+    lab16 = H.synth_labels(13, "mh.lab16", (2, 96, 96), 16, 255, ignore_frac=0.05).cuda()
+    lab17 = H.synth_labels(12, "g12.lab", (2, 96, 96), 17, 255, ignore_rows=3).cuda()
+    grads = {}
+    for stage in ("0", "1"):
+        monkeypatch.setenv("DML_GRAD_STAGE32", stage)
+        m = _multihead(torch.bfloat16)
+        logits, _, feats = m(img)
+        crit = utils.DMLLoss(alpha=0.01, ignore_index=255)
+        loss = 0.5 * crit(logits[1], lab17, feats[1])
+        if both:
+            loss = loss + crit(logits[0], lab16, feats[0])
+        loss.backward()
+        plan = next(p for k, p in m._engine.plans.items() if k[4])
+        n_stage = sum(1 for fn, args in plan.bwd if fn is plan.lib.dml_conv_igemm and args[0]._obj.acc32)
+        assert n_stage == (4 if stage == "1" else 0)          # the four downsample blocks; d(out) goes through the conversion
+        grads[stage] = {k: p.grad.detach().double().cpu().flatten() for k, p in m.named_parameters() if p.grad is not None}
+    omc = []
+    for k, a in grads["0"].items():
+        b = grads["1"][k]
+        if float(a.norm()) == 0.0 and float(b.norm()) == 0.0:
+            continue
+        omc.append(1.0 - float(a @ b) / (float(a.norm()) * float(b.norm()) + 1e-30))
+    omc = np.array(omc)
+    print("two heads, bf16: staged vs per-producer 1 - cos median %.2e max %.2e over %d tensors" % (np.median(omc), omc.max(), len(omc)))
+    assert len(omc) > 300 and np.median(omc) <= 2e-3 and omc.max() <= 5e-2
+
+
 def test_incremental_head_recipe_skips_the_trunk_backward():
     """main_self_distillation.py:354-357,432-435,497-499: only `classifier_1` trains, every BatchNorm2d on running
     statistics, loss on the last head.  With requires_grad = False on trunk and base head the backward plan stops at

@@ -1103,3 +1103,60 @@ def test_dgrad_adds_the_masked_residual_gradient_in_its_epilogue(lib, bnr):
     d = make_desc(lib, dy, wt, y1, B, Hh, Ww, Cout, Hh, Ww, Cin, 1, 1, 1, 0, 1, mode=1, accum=1)
     d.res_dz, d.res_mask, d.res_ld = dz.data_ptr(), bits.data_ptr(), Cin
     assert lib.dml_conv_igemm(C.byref(d), st()) != 0
+
+
+@pytest.mark.parametrize("shape", [(3, 21, 19, 64, 256, 1, 1), (3, 21, 19, 256, 64, 1, 1), (1, 24, 24, 512, 128, 3, 2),
+                                   (2, 17, 13, 96, 256, 3, 1)])
+def test_dgrad_rounds_a_staged_gradient_once(lib, shape):
+    """DmlConvDesc.acc32: a gradient with several producers (d(out) of the ASPP, a block input that also feeds a downsample
+    branch) is summed in an fp32 staging tensor by the earlier producers (y_f32, accum) and the last producer writes
+    bf16(conv + staging) -- one rounding of the fp32 total, as autograd does in the reference (network/utils.py:360,
+    resnet.py:112-113).  Checked against torch on the bf16 operands: the result is the correctly rounded fp32 sum (up to
+    the summation order of the fp32 accumulators), while rounding after every producer is measurably further away.
+    Shapes: 64- and 128-wide LDS-DMA tiles, the 256-row variant (K = 4608), and a channel count the DMA kernels do not
+    take (C = 96), which must be refused."""
+    import torch.nn.functional as F
+    B, Hh, Ww, Cout, Cin, k, dil = shape                      # data gradient of a conv Cin -> Cout: writes [M][Cin]
+    M, pad = B * Hh * Ww, dil * (k - 1) // 2
+    g = torch.Generator(device="cuda").manual_seed(11)
+    dys = [torch.randn(B, Hh, Ww, Cout, device="cuda", generator=g).to(torch.bfloat16) for _ in range(3)]
+    wts = [(torch.randn(Cin, k, k, Cout, device="cuda", generator=g) * (1.0 / (Cout * k * k)) ** 0.5).to(torch.bfloat16)
+           for _ in range(3)]
+
+    def ref(i):         # conv^T as a correlation with the flipped taps; fp64 on the bf16 operands
+        w = wts[i].double().flip(1, 2).permute(0, 3, 1, 2)                   # [Cin][Cout][k][k]
+        return F.conv2d(dys[i].double().permute(0, 3, 1, 2), w, None, 1, pad, dil).permute(0, 2, 3, 1).reshape(M, Cin)
+
+    stage = torch.empty(M, Cin, device="cuda", dtype=torch.float32)
+    y = torch.empty(M, Cin, device="cuda", dtype=torch.bfloat16)
+    d = make_desc(lib, dys[2], wts[2], y, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, dil, pad, 1, mode=1)
+    d.acc32, d.acc32_ld = stage.data_ptr(), Cin
+    if Cout % 32:
+        assert lib.dml_conv_igemm(C.byref(d), st()) != 0      # no LDS-DMA kernel for this shape: refused, not mis-computed
+        return
+    for i in range(2):
+        di = make_desc(lib, dys[i], wts[i], stage, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, dil, pad, 1, mode=1, y_f32=1, accum=i)
+        chk(lib.dml_conv_igemm(C.byref(di), st()))
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    # the old way: bf16 buffer, rounded after every producer
+    y3 = torch.empty(M, Cin, device="cuda", dtype=torch.bfloat16)
+    for i in range(3):
+        di = make_desc(lib, dys[i], wts[i], y3, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, dil, pad, 1, mode=1, accum=1 if i else 0)
+        chk(lib.dml_conv_igemm(C.byref(di), st()))
+    torch.cuda.synchronize()
+    total = ref(0) + ref(1) + ref(2)
+    want = total.float().to(torch.bfloat16)
+    same = (y.view(torch.int16) == want.view(torch.int16)).float().mean().item()
+    e1 = (y.double() - total).abs().max().item() / total.abs().max().item()
+    e3 = (y3.double() - total).abs().max().item() / total.abs().max().item()
+    r1 = ((y.double() - total) ** 2).mean().sqrt().item()
+    r3 = ((y3.double() - total) ** 2).mean().sqrt().item()
+    print("staged: %.4f of the elements are the correctly rounded sum, max err %.2e (three roundings %.2e), rms %.3e vs %.3e"
+          % (same, e1, e3, r1, r3))
+    assert same > 0.995 and e1 <= 2.0 ** -8
+    assert r1 < 0.8 * r3
+    # refused combinations
+    d.accum = 1
+    assert lib.dml_conv_igemm(C.byref(d), st()) != 0
+    d.accum, d.y_f32 = 0, 1
+    assert lib.dml_conv_igemm(C.byref(d), st()) != 0
