@@ -84,9 +84,14 @@ typedef struct DmlConvDesc {
     /* optional (bf16, LDS-DMA kernel): balance a launch whose tile count leaves the last round of workgroups mostly
      * empty (576 tiles of 128 x 128 on 256 CUs x 3 slots: a quarter of the CUs carry three tiles, the rest two).  The
      * tiles beyond the last multiple of the CU count are split along K into q workgroups each, so that every CU gets
-     * the same share; the parts park their fp32 accumulators in tail_ws ([tiles][q][128*128] floats) and the part that
-     * finishes last (agent-scope release / acquire around a counter in tail_counters, zero on entry, reset on exit) adds
-     * them in part order and runs the epilogue.  NULL = never split. */
+     * the same share; the parts park their fp32 accumulators in tail_ws ([tiles][q][128*128] floats) with write-through
+     * (sc1) stores, wait for them to drain, and take a RELAXED ticket from tail_counters; the part that draws the last
+     * ticket reads all parts back with sc1 loads, adds them in part order (deterministic) and runs the epilogue -- no
+     * release / acquire fences (an agent-scope release would write back every dirty line of the XCD's L2).
+     * tail_counters must be zero on entry and is zero again when the launch has completed.  tail_ws / tail_counters may
+     * be shared by every conv of a plan ONLY if those launches are serialised on one stream (two concurrent launches
+     * would mix their slabs and tickets); after an aborted launch the caller must zero tail_counters.  NULL = never
+     * split. */
     float* tail_ws;
     int64_t tail_ws_elems;
     int32_t* tail_counters;

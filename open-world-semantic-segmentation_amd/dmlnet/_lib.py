@@ -176,5 +176,10 @@ _ERR = {-1: "invalid argument", -2: "misaligned / non-vectorisable shape", -3: "
 
 
 def check(rc: int, what: str):
-    if rc != 0:
-        raise DmlError("%s failed: %s (code %d)" % (what, _ERR.get(rc, "hipError"), rc))
+    """0 = ok; negative = a DML_E* argument check of the library; positive = the hipError_t of a failed launch, event
+    record or stream wait (include/dmlnet_hip.h, conventions)."""
+    if rc == 0:
+        return
+    if rc > 0:
+        raise DmlError("%s failed: HIP runtime error, hipError_t %d" % (what, rc))
+    raise DmlError("%s failed: %s (code %d)" % (what, _ERR.get(rc, "unknown DML error"), rc))

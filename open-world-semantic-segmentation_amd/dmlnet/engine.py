@@ -119,10 +119,13 @@ class NativeList:
                 args[k] = v                          # packs through __setitem__
         self.n = n
         self.failed = C.c_int(-1)
+        self.on_error = None
 
     def run(self, first, last, stream, side_stream=None, events=None, n_events=0):
         rc = self.lib.dml_plan_run(self.arr, first, last, stream, side_stream, events, n_events, C.byref(self.failed))
         if rc:
+            if self.on_error is not None:
+                self.on_error()
             _lib.check(rc, "native plan op %d" % self.failed.value)
 
 
@@ -695,6 +698,45 @@ class Plan:
         if need_dgrad:
             self.conv_dgrad(dy, u.conv, u.wt, u.x, final=final)
 
+    def block_fwd(self, x: Act, blk: nn.Module):
+        """one Bottleneck (resnet.py:95-115): 1x1 -> 3x3 -> 1x1, + identity or downsample branch, ReLU"""
+        u1 = self.cbr(x, blk.conv1, blk.bn1)
+        u2 = self.cbr(u1.z, blk.conv2, blk.bn2)
+        ud = None
+        if blk.downsample is not None:
+            ud = self.cbr(x, blk.downsample[0], blk.downsample[1], relu=False)
+            idt = ud.z
+        else:
+            idt = x
+        u3 = self.cbr(u2.z, blk.conv3, blk.bn3, relu=True, res=idt)
+        return (x, u1, u2, u3, ud)
+
+    def block_bwd(self, rec):
+        """backward of block_fwd: consumes d(block output), produces d(block input)"""
+        xb, u1, u2, u3, ud = rec
+        dz = self.grad_of(u3.z)
+        if ud is not None:
+            dres = self.grad_of(ud.z)
+            self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
+            ud.z.grad_init = True
+        elif (self.fuse_res_grad and self.dtype == torch.bfloat16 and not xb.root.grad_init and xb is xb.root
+              and u3.relu and u3.mask is not None and u3.drop is None and xb.C % 8 == 0 and xb.C > 32
+              and dz.ld == xb.C and self.conv_geom(u1.conv, xb)[:3] == (1, 1, 1)):
+            # The masked output gradient is this block's contribution to d(xb) through the identity branch.  Instead
+            # of having the BN-backward apply write that copy (75 MB per layer3 block) for conv1's data gradient to
+            # accumulate onto, conv1's data gradient reads dz and the mask itself (DmlConvDesc.res_*).
+            self.unit_bwd(u3, dz, dres=None)
+            self.res_src[id(xb)] = (dz, u3.mask)
+        else:
+            dres = self.grad_of(xb)
+            self.unit_bwd(u3, dz, dres=dres, dres_accum=xb.root.grad_init)
+            xb.root.grad_init = True
+        self.unit_bwd(u2, self.grad_of(u2.z))
+        self.unit_bwd(u1, self.grad_of(u1.z), final=ud is None)
+        assert not self.res_src, "conv1's data gradient did not take the identity-branch gradient"
+        if ud is not None:
+            self.unit_bwd(ud, self.grad_of(ud.z))
+
     # ---- the network -------------------------------------------------------------------------
     def build(self):
         lib, m, st = self.lib, self.e.model, self.e.store
@@ -730,17 +772,8 @@ class Plan:
         x = p0
         for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
             for blk in layer:
-                u1 = self.cbr(x, blk.conv1, blk.bn1)
-                u2 = self.cbr(u1.z, blk.conv2, blk.bn2)
-                ud = None
-                if blk.downsample is not None:
-                    ud = self.cbr(x, blk.downsample[0], blk.downsample[1], relu=False)
-                    idt = ud.z
-                else:
-                    idt = x
-                u3 = self.cbr(u2.z, blk.conv3, blk.bn3, relu=True, res=idt)
-                blocks.append((x, u1, u2, u3, ud))
-                x = u3.z
+                blocks.append(self.block_fwd(x, blk))
+                x = blocks[-1][3].z
             if layer is bb.layer1:
                 low = x
         out = x
@@ -782,29 +815,8 @@ class Plan:
         backbone_start = len(self.bwd)
         if out.g32 is not None and len(self.heads) > 1:
             self.round_staged(out)                      # several heads: which of them runs last is only known per step
-        for (xb, u1, u2, u3, ud) in reversed(blocks):
-            dz = self.grad_of(u3.z)
-            if ud is not None:
-                dres = self.grad_of(ud.z)
-                self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
-                ud.z.grad_init = True
-            elif (self.fuse_res_grad and self.dtype == torch.bfloat16 and not xb.root.grad_init and xb is xb.root
-                  and u3.relu and u3.mask is not None and u3.drop is None and xb.C % 8 == 0 and xb.C > 32
-                  and dz.ld == xb.C and self.conv_geom(u1.conv, xb)[:3] == (1, 1, 1)):
-                # The masked output gradient is this block's contribution to d(xb) through the identity branch.  Instead
-                # of having the BN-backward apply write that copy (75 MB per layer3 block) for conv1's data gradient to
-                # accumulate onto, conv1's data gradient reads dz and the mask itself (DmlConvDesc.res_*).
-                self.unit_bwd(u3, dz, dres=None)
-                self.res_src[id(xb)] = (dz, u3.mask)
-            else:
-                dres = self.grad_of(xb)
-                self.unit_bwd(u3, dz, dres=dres, dres_accum=xb.root.grad_init)
-                xb.root.grad_init = True
-            self.unit_bwd(u2, self.grad_of(u2.z))
-            self.unit_bwd(u1, self.grad_of(u1.z), final=ud is None)
-            assert not self.res_src, "conv1's data gradient did not take the identity-branch gradient"
-            if ud is not None:
-                self.unit_bwd(ud, self.grad_of(ud.z))
+        for rec in reversed(blocks):
+            self.block_bwd(rec)
         # max pool + stem
         dz0 = self.grad_of(z0)
         self.call(self.bwd, lib.dml_maxpool3x3s2_bwd, self.grad_of(p0).ptr, amax.data_ptr(), dz0.ptr, B, z0.H, z0.W,
@@ -911,6 +923,7 @@ class Plan:
         df = self.fbuf(B * H * W * Kp)
         rec.df = df
         de = self.new(B, emb.H, emb.W, Kp)
+        rec.de = de                     # gradient of the low-resolution embedding
         # Two ways from d(loss)/d(logits) to the low-resolution embedding gradient `de`; Engine.backward skips one.
         # (1) the loss handed over a deferred gradient (dmlnet/lazy_grad.py) and the shape is the fused kernel's (16
         #     prototypes, exact x4 upsample): loss gradient + distance gradient + transposed upsample in one pass;
@@ -1014,6 +1027,9 @@ class Plan:
         nat = self._nat.get(key)
         if nat is None:
             nat = NativeList(self.lib, ops, self.side if ops is self.bwd else None)
+            # an aborted replay may leave tickets of a K-split tail (DmlConvDesc.tail_counters) behind: the counters must be
+            # zero when the next launch that uses them starts
+            nat.on_error = self.tail_cnt.zero_
             self._nat[key] = nat
         return nat
 
@@ -1262,9 +1278,13 @@ class Engine:
         B, _, H, W = x.shape
         logits, feats = [], []
         for rec in plan.heads:
+            # a deferred loss gradient of this head's PREVIOUS forward that never reached backward() (the loss was dropped,
+            # or a second forward ran first) is void now: its features buffer is about to be replaced
+            lazy_grad.drop_for(getattr(rec, "logits_ref", None))
             lg = torch.empty((B, rec.K, H, W), dtype=torch.float32, device=x.device)
             ft = torch.empty((B, H, W, rec.Kp), dtype=torch.float32, device=x.device)
             rec.feats_p = ft                 # the kernels' (channel-padded) features; the backward reads them again
+            rec.feats_version = None
             rec.logits_ref = lg
             rec.head_args[2], rec.head_args[3] = lg.data_ptr(), ft.data_ptr()
             logits.append(lg)
@@ -1288,6 +1308,8 @@ class Engine:
                 self.store.flat_nbt.add_(plan.nbt_inc)      # layers with fixed statistics do not count the batch
         plan.run_forward(stream)
         plan.last_input = x
+        for rec in plan.heads:
+            rec.feats_version = rec.feats_p._version
         for hi, rec in enumerate(plan.heads):
             if rec.Kp != rec.K:              # features_out has exactly num_classes channels (utils.py:95-97)
                 feats[hi] = feats[hi][..., :rec.K].contiguous()
@@ -1305,8 +1327,16 @@ class Engine:
                 skip.append(plan.head_bwd_range[hi])         # accumulating segment: nothing to add
                 continue
             lazy = lazy_grad.take(gl)
-            if lazy is not None and rec.fused_args is not None and gf is None:
-                # deferred loss gradient + a shape the fused kernel covers: one pass, no d(loss)/d(logits) tensor
+            if lazy is not None and (lazy.logits is not rec.logits_ref
+                                     or tuple(lazy.logits.shape) != (plan.B, rec.K, plan.H, plan.W)):
+                # the marker belongs to another forward of this plan than the one whose activations it holds now (a second
+                # train-mode forward ran before this backward): the stored tensors are not the ones the loss saw
+                raise RuntimeError("backward through logits of an earlier forward: the plan's activations were replaced by "
+                                   "a later forward of the same shape (run backward before the next forward)")
+            if lazy is not None and rec.fused_args is not None and gf is None and rec.feats_p._version == rec.feats_version:
+                # deferred loss gradient + a shape the fused kernel covers: one pass, no d(loss)/d(logits) tensor (the kernel
+                # recomputes the logits from the features handed to the user: an in-place edit of those since the forward
+                # sends the step down the materialising path below, which uses the logits the loss saw)
                 a = rec.fused_args
                 a[0], a[1], a[2], a[3] = rec.feats_p.data_ptr(), lazy.labels.data_ptr(), lazy.sums.data_ptr(), lazy.gout.data_ptr()
                 a[13], a[14], a[15] = int(lazy.ignore_index), float(lazy.alpha), float(lazy.n_images)

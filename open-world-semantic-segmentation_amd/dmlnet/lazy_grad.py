@@ -49,5 +49,7 @@ def outstanding_for(logits) -> bool:
 
 
 def drop_for(logits):
+    if logits is None or not _pending:
+        return
     for k in [k for k, rec in _pending.items() if rec.logits is logits]:
         del _pending[k]

@@ -53,6 +53,31 @@ class FusedSGD(torch.optim.Optimizer):
         self._ranges = ranges
 
     @torch.no_grad()
+    def load_state_dict(self, state_dict):
+        """torch's load_state_dict replaces every momentum buffer by a detached copy.  Before the first step that copy is
+        carried into the flat buffer when it is created (step()); AFTER it -- a mid-run reload -- the kernel would keep
+        updating the old flat buffer and the restored momentum would be silently ignored: copy the loaded buffers into the
+        flat views and re-point the state at them."""
+        super().load_state_dict(state_dict)
+        for st in getattr(self, "_stores", ()):
+            if st.flat_v is None:
+                continue
+            mine = {id(q) for g in self.param_groups for q in g["params"]}
+            for p, off in zip(st.params, st.offsets):
+                if id(p) not in mine:
+                    continue
+                view = st._view(st.flat_v, off, p)
+                old = self.state[p].get("momentum_buffer") if p in self.state else None
+                if old is None:
+                    view.zero_()
+                elif old.data_ptr() != view.data_ptr():
+                    if tuple(old.shape) != tuple(p.shape):
+                        raise RuntimeError("FusedSGD: restored momentum buffer of shape %s does not match its parameter %s"
+                                           % (tuple(old.shape), tuple(p.shape)))
+                    view.copy_(old.to(device=view.device, dtype=view.dtype))
+                self.state[p]["momentum_buffer"] = view
+
+    @torch.no_grad()
     def step(self, closure=None):
         loss = closure() if closure is not None else None
         if not hasattr(self, "_stores"):

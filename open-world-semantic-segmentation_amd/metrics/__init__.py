@@ -1,1 +1,1 @@
-from .stream_metrics import StreamSegMetrics  # noqa: F401
+from .stream_metrics import StreamSegMetrics, AverageMeter  # noqa: F401

@@ -45,9 +45,14 @@ class StreamSegMetrics(object):
         """Sum the confusion matrix over the ranks of a data-parallel evaluation (each rank has seen its shard of the
         images); afterwards every rank reports the scores of the whole set.  No-op outside a process group."""
         import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1 \
-                and self.confusion_matrix is not None:
-            dist.all_reduce(self.confusion_matrix, group=group)
+        if not (dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1):
+            return
+        if self.confusion_matrix is None:
+            # a rank that scored no image (fewer images than ranks) must still issue the SAME collective as the others:
+            # skipping it would pair this rank's next all_reduce with their matrix all_reduce (hang / corrupted sums)
+            self.confusion_matrix = torch.zeros((self.n_classes, self.n_classes), dtype=torch.int64,
+                                                device=torch.device("cuda", torch.cuda.current_device()))
+        dist.all_reduce(self.confusion_matrix, group=group)
 
     def get_results(self):
         """The scores of stream_metrics.py:57-83 of the reference from the n x n count matrix (rows = true class,
@@ -73,3 +78,30 @@ class StreamSegMetrics(object):
     def reset(self):
         if self.confusion_matrix is not None:
             self.confusion_matrix.zero_()
+
+
+class AverageMeter(object):
+    """Named running means -- the host-side helper the reference exports next to StreamSegMetrics
+    (metrics/stream_metrics.py:86-114 there): update(id, val) adds a sample, get_results(id) is the mean so far,
+    reset(id) zeroes one entry and reset_all() forgets every name.  `book` maps id -> [sum, count] as there."""
+
+    def __init__(self):
+        self.book = {}
+
+    def update(self, id, val):
+        entry = self.book.setdefault(id, [0, 0])
+        entry[0] = entry[0] + val if entry[1] else val
+        entry[1] += 1
+
+    def get_results(self, id):
+        if id not in self.book:
+            raise AssertionError("no samples recorded under %r" % (id,))
+        total, count = self.book[id]
+        return total / count
+
+    def reset(self, id):
+        if id in self.book:
+            self.book[id][:] = [0, 0]
+
+    def reset_all(self):
+        self.book = {}

@@ -91,9 +91,10 @@ def main():
         mean_meas = (tot[:3] / max(n_meas, 1)).tolist()
     else:
         mean_meas = [float(np.mean(v)) if v else float("nan") for v in (aurocs, auprs, fprs)]
-    if n_meas and rank == 0:
+    if rank == 0:
         print(seg_metrics.to_str(seg_metrics.get_results()))
-        anom_utils.print_measures(mean_meas[0], mean_meas[1], mean_meas[2], "dissum")
+        if n_meas:          # frames without a novel-class pixel have no OOD measures (anom_utils.eval_ood_measure -> None)
+            anom_utils.print_measures(mean_meas[0], mean_meas[1], mean_meas[2], "dissum")
     if n:
         print("rank %d: %.2f img/s at %dx%d (%d novel-class pixels in the last image, score mean %.4f)"
               % (rank, n / (time.perf_counter() - t0), o.height, o.width, int((preds == o.num_classes).sum()),

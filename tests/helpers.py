@@ -107,3 +107,85 @@ def rel_err(a: torch.Tensor, b: torch.Tensor) -> float:
 
 def max_abs(a, b) -> float:
     return (a.detach().double().cpu() - b.detach().double().cpu()).abs().max().item()
+
+
+# ---------------------------------------------------------------------------------------------------
+# test-only: plans of ONE piece of the network, built from the product's own plan pieces (dmlnet.engine.Plan.block_fwd /
+# block_bwd / _head_fwd / _head_bwd), so that the per-block and head-only fixtures (G4, G3: SURVEY 8(c) calls them "the
+# binding fixtures") bind the HIP path and not only the oracle
+# ---------------------------------------------------------------------------------------------------
+def piece_plan(kind: str, module: torch.nn.Module, in_shapes, dtype=torch.float32):
+    """kind = "block": module is a network.modeling.Bottleneck, in_shapes = [(B, C, H, W)];
+    kind = "head": module is a network.modeling.DeepLabHeadV3Plus, in_shapes = [low (B,256,h,w), out (B,2048,h',w')].
+    Returns a PiecePlan with .run(inputs, grad_out) -> (output, input gradients); parameter gradients / running
+    statistics land in the module (p.grad, buffers) exactly as in the full model."""
+    import torch.nn as nn
+    from dmlnet import engine as E
+
+    class _Holder(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.backbone = nn.ModuleDict({"blk": module} if kind == "block" else {})
+            self.classifier = module if kind == "head" else nn.Module()
+
+    class PiecePlan(E.Plan):
+        def build(self):
+            self.bn_eval, self.pre_prep, self.nbt_inc = [], [], None
+            self.to_backbone_ops, self.head_bwd_range = [], {}
+            if kind == "block":
+                B, Cc, Hh, Ww = in_shapes[0]
+                self.inputs = [self.new(B, Hh, Ww, Cc)]
+                rec = self.block_fwd(self.inputs[0], module)
+                self.output = rec[3].z
+                self.grad_out = self.grad_of(self.output)
+                self.output.root.grad_init = True
+                self.block_bwd(rec)
+                self.flush_wgrad()
+                self.skip = []
+            else:
+                (B, Cl, hl, wl), (_, Co, ho, wo) = in_shapes
+                low, out = self.new(B, hl, wl, Cl), self.new(B, ho, wo, Co)
+                self.inputs = [low, out]
+                rec = self._head_fwd(module, low, out)
+                self.heads = [rec]
+                self.n_fwd = len(self.fwd) - 1              # without the final upsample + distance op (needs per-call outputs)
+                self.output = rec.emb
+                self._head_bwd(rec, low, out)
+                self.flush_wgrad()
+                self.grad_out = rec.de
+                self.skip = [r for r in (rec.fused_range, rec.unfused_range) if r is not None]
+
+        @staticmethod
+        def _fill(act, t):          # NCHW cpu tensor -> the plan's NHWC buffer
+            v = t.permute(0, 2, 3, 1).contiguous().to(act.t.device, act.t.dtype)
+            act.t.view(act.B, act.H, act.W, act.ld)[..., :act.C].copy_(v)
+
+        @staticmethod
+        def _read(act):
+            return act.t.view(act.B, act.H, act.W, act.ld)[..., :act.C].permute(0, 3, 1, 2).float().cpu()
+
+        def run(self, inputs, grad_out):
+            st = self.e.store
+            stream = torch.cuda.current_stream(self.device).cuda_stream
+            self.refresh_weights(stream)
+            for a, t in zip(self.inputs, inputs):
+                self._fill(a, t)
+            for args, idx, bn in self.momentum_slots:
+                args[idx] = float(bn.momentum)
+            st.flat_nbt.add_(1)
+            self._exec(self.fwd, stream, 0, getattr(self, "n_fwd", None))
+            y = self._read(self.output)
+            self._fill(self.grad_out, grad_out)
+            st.begin_backward()
+            self.skip_ranges = self.skip
+            self.run_backward()
+            st.end_backward()
+            torch.cuda.synchronize()
+            return y, [self._read(self.grad_of(a)) for a in self.inputs]
+
+    holder = _Holder().cuda()
+    eng = E.Engine(holder)
+    eng.store.bind(torch.device("cuda", torch.cuda.current_device()))
+    (B, _, Hh, Ww) = in_shapes[0]
+    H_full, W_full = (Hh, Ww) if kind == "block" else (4 * Hh, 4 * Ww)
+    return PiecePlan(eng, B, H_full, W_full, dtype, True)

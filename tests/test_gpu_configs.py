@@ -121,6 +121,18 @@ def test_eval_driver_synthetic_one_and_two_ranks():
     assert len(s1) == 4 and s1.keys() == s2.keys()
     for k in s1:
         assert abs(s1[k] - s2[k]) <= 1e-6, (k, s1[k], s2[k])
+    # fewer images than ranks: rank 1 scores nothing and never creates its confusion matrix, but must still take part in
+    # the SAME collectives (it used to skip the matrix all_reduce and pair its next one with rank 0's: hang / corruption)
+    one = [drv, "--synthetic", "--height", "256", "--width", "512", "--num_images", "1", "--dtype", "f32"]
+    r3 = subprocess.run([sys.executable] + one, capture_output=True, text=True, cwd=H.PKG, timeout=900)
+    r4 = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
+                         "127.0.0.1", "--master-port", str(_free_port())] + one, env=env, capture_output=True, text=True,
+                        cwd=H.PKG, timeout=300)
+    assert r3.returncode == 0 and r4.returncode == 0, r4.stdout[-2000:] + r4.stderr[-3000:]
+    s3, s4 = scores(r3.stdout), scores(r4.stdout)
+    assert len(s3) == 4 and s3.keys() == s4.keys()
+    for k in s3:
+        assert abs(s3[k] - s4[k]) <= 1e-6, (k, s3[k], s4[k])
 
 
 def test_optimizer_state_survives_save_and_resume():
@@ -179,3 +191,20 @@ def test_optimizer_state_survives_save_and_resume():
     # the momentum itself: non-zero and equal (a zero-restart would differ at the 1e-2 level after one step)
     va, vb = a._engine.store.flat_v, b._engine.store.flat_v
     assert float(va.abs().max()) > 0 and H.rel_err(vb, va) <= 1e-6
+    # a reload in the MIDDLE of a run (after the flat momentum buffer exists): c takes two steps of its own, then loads
+    # the checkpoint; its next step must equal a's third step, i.e. the kernel must update the restored momentum
+    buf.seek(0)
+    ck = torch.load(buf, map_location="cpu")
+    c, opt_c = make()
+    prepare(c)
+    step(c, opt_c)
+    step(c, opt_c)
+    step(c, opt_c)                                            # c's momentum now differs from the checkpoint's
+    c.load_state_dict(ck["model_state"])
+    opt_c.load_state_dict(ck["optimizer_state"])
+    loss_c = step(c, opt_c)
+    assert abs(loss_a - loss_c) <= 1e-6 * abs(loss_a)
+    vc = c._engine.store.flat_v
+    assert H.rel_err(vc, va) <= 1e-6
+    p0 = next(iter(c.backbone.parameters()))
+    assert opt_c.state[p0]["momentum_buffer"].data_ptr() == c._engine.store._view(vc, 0, p0).data_ptr()

@@ -499,6 +499,73 @@ def test_self_distillation_model_both_heads_against_oracle():
     assert np.median(errs) <= 1e-3 and np.percentile(errs, 95) <= 3e-2 and errs.max() <= 0.2
 
 
+def test_g3_head_fixture_through_the_hip_plan():
+    """G3 (minted from the reference's DeepLabHeadV3Plus, network/utils.py:8-32,308-361): the head alone -- low-level
+    projection, five ASPP branches incl. the image-pooling BatchNorm, projection, x4 bilinear, concat, 3x3, final 1x1
+    with bias -- forward, input gradients, parameter gradients and running statistics, from the plan's own head pieces."""
+    from collections import OrderedDict
+    import network.modeling as NM
+    g = H.load_golden("g3_head")
+    head = NM.DeepLabHeadV3Plus(2048, 256, 16, [6, 12, 18])
+    shapes = OrderedDict(("classifier." + k, tuple(v.shape)) for k, v in head.state_dict().items())
+    sd = H.synth_state_dict(shapes, seed=3)
+    head.load_state_dict(OrderedDict((k[len("classifier."):], v) for k, v in sd.items()))
+    head.train()
+    head.aspp.project[3].eval()
+    low = H.synth_tensor(3, "g3.low", (2, 256, 16, 16))
+    out = H.synth_tensor(3, "g3.out", (2, 2048, 4, 4))
+    wgt = H.synth_tensor(3, "g3.wgt", (2, 16, 16, 16))
+    plan = H.piece_plan("head", head, [tuple(low.shape), tuple(out.shape)])
+    y, (dlow, dout) = plan.run([low, out], wgt)
+    relclose(y, T(g["y"]), TOL, "head output")
+    relclose(dlow, T(g["dlow"]), TOL, "d low_level")
+    relclose(dout, T(g["dout"]), TOL, "d out")
+    pg = dict((k, p.grad) for k, p in head.named_parameters())
+    for n, cs in zip([str(n) for n in g["grad_names"]], g["grad_checksums"]):
+        assert np.allclose(H.checksum(pg[n]), cs, rtol=2e-3, atol=1e-5), n
+    relclose(pg["classifier.3.weight"], T(g["grad__classifier_3_weight"]), TOL, "final conv weight gradient")
+    relclose(pg["aspp.convs.2.0.weight"].detach().cpu()[::8, ::64], T(g["grad_sample__aspp_convs_2_0_weight"]), TOL, "aspp d12 sample")
+    bufs = dict(head.named_buffers())
+    relclose(bufs["project.1.running_var"], T(g["rv_project"]), TOL, "running_var")
+    relclose(bufs["aspp.convs.4.2.running_mean"], T(g["rm_pool"]), TOL, "pooled running_mean")
+
+
+@pytest.mark.parametrize("name,cfg", [
+    ("s1", dict(inplanes=64, planes=16, stride=1, dilation=1, downsample=False)),
+    ("s2", dict(inplanes=32, planes=16, stride=2, dilation=1, downsample=True)),
+    ("d2", dict(inplanes=64, planes=16, stride=1, dilation=2, downsample=False)),
+])
+def test_g4_bottleneck_fixture_through_the_hip_plan(name, cfg):
+    """G4 (minted from the reference's Bottleneck, backbone/resnet.py:75-115): stride 1, stride 2 + downsample branch,
+    dilation 2 -- output, input gradient, every parameter gradient and the running statistics from Plan.block_fwd /
+    block_bwd, the code the full model's plan is made of."""
+    from collections import OrderedDict
+    import torch.nn as nn
+    import network.modeling as NM
+    g = H.load_golden("g4_bottleneck")
+    ds = None
+    if cfg["downsample"]:
+        ds = nn.Sequential(nn.Conv2d(cfg["inplanes"], cfg["planes"] * 4, 1, stride=cfg["stride"], bias=False),
+                           nn.BatchNorm2d(cfg["planes"] * 4))
+    blk = NM.Bottleneck(cfg["inplanes"], cfg["planes"], cfg["stride"], cfg["dilation"], ds)
+    shapes = OrderedDict(("backbone.blk." + k, tuple(v.shape)) for k, v in blk.state_dict().items())
+    sd = H.synth_state_dict(shapes, seed=4)
+    blk.load_state_dict(OrderedDict((k[len("backbone.blk."):], v) for k, v in sd.items()))
+    blk.train()
+    x = H.synth_tensor(4, "g4.x." + name, (2, cfg["inplanes"], 8, 8))
+    yshape = tuple(g[name + "_y"].shape)
+    w = H.synth_tensor(4, "g4.w." + name, yshape)
+    plan = H.piece_plan("block", blk, [tuple(x.shape)])
+    y, (dx,) = plan.run([x], w)
+    relclose(y, T(g[name + "_y"]), TOL, "block output")
+    relclose(dx, T(g[name + "_dx"]), TOL, "d x")
+    for k, p in blk.named_parameters():
+        relclose(p.grad, T(g[name + "_grad__" + k.replace(".", "_")]), 2 * TOL, "grad " + k)
+    for k, b in blk.named_buffers():
+        if "num_batches" not in k:
+            relclose(b, T(g[name + "_buf__" + k.replace(".", "_")]), TOL, k)
+
+
 @pytest.mark.parametrize("both", [True, False])
 def test_multihead_bf16_fp32_staged_gradients(both, monkeypatch):
     """DML_GRAD_STAGE32=1 on the two-head bf16 plan: d(out) is summed in fp32 over BOTH heads' segments and rounded by
