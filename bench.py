@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 PEAK = {"bf16": 2.5e15, "f32": 157.3e12}      # dense MFMA peaks, MI355X_MICROARCH.md
 HBM_PEAK = 8.0e12
-ROUND = "r02"
+ROUND = "r03"
 
 
 def csrc_sha():
@@ -117,20 +117,7 @@ def synth_batch(batch, size, rank, device):
 def conv_bytes_of_plan(plan):
     """Algorithmic HBM bytes of the conv launches of one train step: every operand read once, every result written
     once (accumulating data gradients read their target too), storage types of the plan; weight gradients fp32."""
-    lib = plan.lib
-    es = plan.es
-    total = 0.0
-    for ops in (plan.fwd, plan.bwd):
-        for fn, args in ops:
-            if fn is lib.dml_conv_igemm:
-                d = args[0]._obj
-                rd = d.B * d.Hi * d.Wi * d.C * es + d.N * d.R * d.S * d.C * es
-                wr = d.B * d.Ho * d.Wo * d.N * (4 if d.y_f32 else es)
-                total += rd + wr * (2 if (d.accum or d.res_dz) else 1)      # accumulate / masked residual source: one more read
-            elif fn is lib.dml_conv_wgrad or fn is lib.dml_conv_wgrad_group:
-                for d in ([args[0]._obj] if fn is lib.dml_conv_wgrad else args.meta):
-                    total += d.B * d.Hi * d.Wi * d.C * es + d.B * d.Ho * d.Wo * d.N * es + 2 * 4 * d.N * d.R * d.S * d.C
-    return total
+    return float(sum(m["alg_bytes"] for op in conv_op_list(plan) for m in op["members"]))
 
 
 def conv_flops_of_plan(plan):
@@ -224,6 +211,86 @@ def dump_conv_table(plan, path):
                                      tflops=f1 / s1 / 1e12 if s1 > 0 else 0.0, gflop=f1 / 1e9))
     with open(path, "w") as f:
         json.dump(rows, f)
+
+
+def _conv_class(d, igemm):
+    """(kind, label) of one conv launch; the label is the FORWARD convolution's signature for all three kinds"""
+    if igemm and d.mode == 1:          # data gradient: x = dY [Ho_fwd x Wo_fwd x Cout], result = dX
+        kind, cin, cout, hw = "dgrad", (304 if d.N == 320 else d.N), d.C, (d.Hi, d.Wi)
+    else:
+        kind = "fwd" if igemm else "wgrad"
+        cin, cout, hw = (3 if d.C == 8 else (304 if d.C == 320 else d.C)), d.N, (d.Ho, d.Wo)
+    lab = "%dx%d %d->%d @%dx%d" % (d.R, d.S, cin, cout, hw[0], hw[1])
+    if d.stride != 1:
+        lab += " s%d" % d.stride
+    if d.dil != 1:
+        lab += " d%d" % d.dil
+    return kind, lab
+
+
+def _conv_alg_bytes(d, igemm, es):
+    """algorithmic HBM bytes of one launch: every operand read once, every result written once"""
+    if igemm:
+        rd = d.B * d.Hi * d.Wi * d.C * es + d.N * d.R * d.S * d.C * es
+        wr = d.B * d.Ho * d.Wo * d.N * (4 if d.y_f32 else es)
+        return rd + wr * (2 if (d.accum or d.res_dz) else 1) + (wr * 2 if d.acc32 else 0)
+    return d.B * d.Hi * d.Wi * d.C * es + d.B * d.Ho * d.Wo * d.N * es + 2 * 4 * d.N * d.R * d.S * d.C
+
+
+def conv_op_list(plan):
+    """the conv launches of one step in issue order (forward list, then backward list): one entry per launch with its
+    member layers -- tools/pmc_by_class.py zips this with the profiler's dispatch sequence of a serial run"""
+    lib = plan.lib
+    out = []
+    for name, ops in (("fwd", plan.fwd), ("bwd", plan.bwd)):
+        for i, (fn, args) in enumerate(ops):
+            if fn is lib.dml_conv_igemm or fn is lib.dml_conv_wgrad or fn is lib.dml_conv_wgrad_group:
+                ig = fn is lib.dml_conv_igemm
+                descs = args.meta if fn is lib.dml_conv_wgrad_group else [args[0]._obj]
+                out.append({"list": name, "op": i, "members": [
+                    {"kind": _conv_class(d, ig)[0], "label": _conv_class(d, ig)[1], "flops": _conv_flops(d, ig),
+                     "alg_bytes": _conv_alg_bytes(d, ig, plan.es)} for d in descs]})
+    return out
+
+
+def conv_class_table(plan, dtype, min_ms=0.1):
+    """Per shape class of the profiled pass: launches, ms per step, TFLOP/s, and the class's OWN two-roof bound
+    bound_ms = max(FLOPs / MFMA peak, algorithmic bytes / 8 TB/s) with frac = bound_ms / ms (hard part 1: the
+    roofline of this network has to be read per layer class -- the 1x1 layers on the large maps are streaming GEMMs)."""
+    peak = PEAK[dtype]
+    rows = {}
+    for op in conv_op_list(plan):
+        ops = plan.fwd if op["list"] == "fwd" else plan.bwd
+        sec = profile_convs.per_op.get((id(ops), op["op"]), 0.0)
+        ftot = sum(m["flops"] for m in op["members"])
+        for m in op["members"]:
+            r = rows.setdefault((m["kind"], m["label"]), {"kind": m["kind"], "shape": m["label"], "launches": 0, "ms": 0.0,
+                                                          "gflop": 0.0, "alg_MB": 0.0})
+            r["launches"] += 1
+            r["ms"] += sec * m["flops"] / ftot * 1e3              # a grouped launch: its time is shared out by FLOPs
+            r["gflop"] += m["flops"] / 1e9
+            r["alg_MB"] += m["alg_bytes"] / 1e6
+    out, rest = [], {}
+    for r in rows.values():
+        if r["ms"] < min_ms:
+            o = rest.setdefault(r["kind"], {"kind": r["kind"], "shape": "other (< %.1f ms per class)" % min_ms, "launches": 0,
+                                            "ms": 0.0, "gflop": 0.0, "alg_MB": 0.0})
+            for k in ("launches", "ms", "gflop", "alg_MB"):
+                o[k] += r[k]
+        else:
+            out.append(r)
+    out += list(rest.values())
+    for r in out:
+        t_mfma, t_hbm = r["gflop"] * 1e9 / peak * 1e3, r["alg_MB"] * 1e6 / HBM_PEAK * 1e3
+        r["bound"] = "mfma" if t_mfma >= t_hbm else "hbm"
+        r["bound_ms"] = max(t_mfma, t_hbm)
+        r["frac_of_bound"] = r["bound_ms"] / r["ms"] if r["ms"] > 0 else 0.0
+        r["tflops"] = r["gflop"] / r["ms"] if r["ms"] > 0 else 0.0
+        r["mfma_frac"] = r["tflops"] * 1e12 / peak
+        for k in ("ms", "gflop", "alg_MB", "bound_ms", "frac_of_bound", "tflops", "mfma_frac"):
+            r[k] = round(r[k], 4)
+    out.sort(key=lambda r: -r["ms"])
+    return out
 
 
 def _time_launches(fn, n=20, warm=3):
@@ -596,11 +663,10 @@ def main():
             # the reference's arithmetic is fp32 (network/utils.py:84-118): the same step in the exact-fp32 mode
             # (v_mfma_f32_16x16x4_f32, the mode the 1e-3 parity tests run), driver-timed next to the bf16 headline
             torch.cuda.empty_cache()
-            f = train_pass(args, "f32", device, rank, world, steps=max(3, args.steps // 4), warmup=2, profile=True)
+            f = train_pass(args, "f32", device, rank, world, steps=args.steps, warmup=args.warmup, profile=True)
             out["fp32_companion"] = {"dtype": "f32", "value": f["value"], "unit": "images/sec", "ms_per_step": f["ms_per_step"],
-                                     "steps": max(3, args.steps // 4), "warmup": 2, "final_loss": f["final_loss"],
-                                     "roofline": {k: f["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac",
-                                                                               "conv_ms_per_step", "flops_per_step")}}
+                                     "steps": args.steps, "warmup": args.warmup, "final_loss": f["final_loss"],
+                                     "roofline": f["roofline"]}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
         if "input_pipeline" in out:
@@ -678,6 +744,11 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
     torch.cuda.synchronize()
     res = {"value": args.batch * world * steps / elapsed, "ms_per_step": elapsed / steps * 1e3,
            "final_loss": final_loss, "host_ms": host / 3 * 1e3}
+    if os.environ.get("DML_BENCH_OPLOG") and rank == 0:
+        # the conv launches of a step in issue order, for tools/pmc_by_class.py (profiler runs)
+        plan = next(p for k, p in model._engine.plans.items() if k[4])
+        with open(os.environ["DML_BENCH_OPLOG"], "w") as fh:
+            json.dump({"dtype": dtype, "steps_in_run": warmup + steps + 3, "ops": conv_op_list(plan)}, fh)
     if profile:
         plan = next(p for k, p in model._engine.plans.items() if k[4])
         flops, _ = conv_flops_of_plan(plan)
@@ -694,14 +765,14 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
         # --pmc FETCH_SIZE / WRITE_SIZE runs, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024).  Quoted only when the file was
         # collected on exactly these kernel sources (csrc_sha inside the file), else null.
         traffic, traffic_src = None, None
-        tpath = os.path.join(ROOT, "profiles", ROUND + "_traffic_pmc.json")
-        if os.path.exists(tpath) and args.batch == 16 and args.size == 768 and dtype == "bf16":
+        tpath = os.path.join(ROOT, "profiles", ROUND + ("_traffic_pmc.json" if dtype == "bf16" else "_fp32_traffic_pmc.json"))
+        if os.path.exists(tpath) and args.batch == 16 and args.size == 768:
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("csrc_sha") == csrc_sha():
                 traffic = tj["conv_GB_per_step"] * 1e9 / n_launch      # per launch OF THIS PLAN (a grouped launch is one)
-                traffic_src = "profiles/%s_traffic_pmc.json (rocprofv3 --pmc, %.1f GB per step over the conv launches, csrc %s)" \
-                    % (ROUND, tj["conv_GB_per_step"], tj["csrc_sha"])
+                traffic_src = "profiles/%s (rocprofv3 --pmc, %.1f GB per step over the conv launches, csrc %s)" \
+                    % (os.path.basename(tpath), tj["conv_GB_per_step"], tj["csrc_sha"])
         roof = {"bound": "mfma", "kernel": "every convolution launch of a step (conv_igemm*_kernel forward / data gradient, "
                                            "conv_wgrad*_kernel weight gradient)",
                 "achieved": flops / conv_sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
@@ -716,6 +787,7 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
         if traffic is not None:
             roof["traffic_over_algorithmic"] = traffic * n_launch / alg_bytes
             roof["hbm_frac_of_same_launches"] = traffic * n_launch / conv_sec / 8e12
+        roof["classes"] = conv_class_table(plan, dtype)
         res["roofline"] = roof
     del model, opt, sched, crit, step
     torch.cuda.empty_cache()

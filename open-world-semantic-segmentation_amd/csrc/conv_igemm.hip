@@ -778,14 +778,17 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // BM = 128: 4 waves (2 x 2), three workgroups per CU.  BM = 256: 8 waves (4 x 2) on the same 64 x 64 wave tile -- the
 // weight tile is shared by twice the rows, so a K step moves 24 KB into LDS for 2.1 MFLOP (85 FLOP/B against 64) -- two
 // workgroups per CU (72 KB of LDS each, 128-register budget).
-template <int BN, int MODE, int NST, int WPE = 3, int BM = 128>
-__global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(WPE))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
+// TMW = 128 (with BM = 256): 4 waves (2 x 2) on a 128 x 64 WAVE tile -- 32 MFMAs per wave and K step against 12 KB of
+// fragment reads (the 64 x 64 wave tile: 16 against 8 KB), half the barriers per FLOP; 128 accumulator registers, two
+// workgroups per CU = two waves per SIMD.
+template <int BN, int MODE, int NST, int WPE = 3, int BM = 128, int TMW = 64>
+__global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(WPE))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
                                                                   const uint32_t w_bytes) {
     typedef bf16_t T;
-    constexpr int LA = NST - 1, NTH = BM * 2, WAVES = BM / 32;
+    constexpr int WAVES = BM / TMW * 2, NTH = WAVES * 64, LA = NST - 1;
     constexpr int STAGE = (BM + BN) * BK;          // elements per ring stage
-    constexpr int TM = 64, TN = BN / 2, MT = 4, NT = TN / 16;
-    constexpr int A_I = 2, B_I = BN / 16 / WAVES;   // DMA instructions per wave per tile (1 KiB = 16 rows each)
+    constexpr int TM = TMW, TN = BN / 2, MT = TM / 16, NT = TN / 16;
+    constexpr int A_I = BM / 16 / WAVES, B_I = BN / 16 / WAVES;   // DMA instructions per wave per tile (1 KiB = 16 rows each)
     static_assert(B_I >= 1, "tile too narrow for this many waves");
     constexpr int NI = A_I + B_I;
     constexpr uint32_t OOB = 0x80000000u;
@@ -980,7 +983,21 @@ __global__ __launch_bounds__(BM * 2) __attribute__((amdgpu_waves_per_eu(WPE))) v
                 }
         }
     }
-    conv_epilogue<T, NT, MT, MODE>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+    if constexpr (MT == 4) {
+        conv_epilogue<T, NT, MT, MODE>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+    } else {
+        // 128-row wave tile: the epilogue's statistics / BN-backward partials are per DML_STAT_ROWS = 64 rows, so it runs
+        // once per 64-row half (which also halves its register footprint)
+#pragma unroll
+        for (int h = 0; h < MT / 4; ++h) {
+            f32x4 sub[NT][4];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) sub[i][j] = acc[i][h * 4 + j];
+            conv_epilogue<T, NT, 4, MODE>(sub, a, m0 + wm * TM + h * 64, n0 + wn * TN, lr, lq);
+        }
+    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1898,7 +1915,17 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             static const int bm256 = getenv("DML_CONV_BM256") ? atoi(getenv("DML_CONV_BM256")) : 1;
             const int tiles256 = ((a.M + 255) / 256) * (a.N / 128);
             const bool long_k = bm256 >= 64 ? a.Ktot >= bm256 : (a.Ktot >= 4608 || (a.Ktot >= 2304 && tiles256 >= 512));
-            if ((bm256 == 2 || (bm256 != 0 && long_k)) && a.N >= 128 && !narrow && a.N % 128 == 0) {
+            // The 256-row tile runs as 4 waves on 128 x 64 WAVE tiles (conv_igemm_dma_kernel<..., 256, 128>: 32 MFMAs per
+            // wave and K step against 12 KB of fragment reads, half the barriers per FLOP) instead of 8 waves on 64 x 64:
+            // in the plan (serial profile, r03) decoder 3x3 data gradient 1.064 -> 0.957 ms, forward 0.869 -> 0.832, layer4
+            // 3x3 d2 data gradients 0.440 -> 0.370, forward 0.371 -> 0.345, ASPP 3x3 unchanged (~1000-1070 TFLOP/s either
+            // way); whole step 385.3 -> 388.3 images/s.  It does NOT help the layers the rule above keeps on 128-row tiles:
+            // layer3's 3x3 (K = 2304, 288 such tiles = one per CU at ONE wave per SIMD) 662 -> 640 / 603 -> 540 TFLOP/s.
+            // DML_CONV_WW: 0 = the 8-wave variant, 1 = this (default), >= 64 = also every eligible layer with K >= that
+            static const int ww = getenv("DML_CONV_WW") ? atoi(getenv("DML_CONV_WW")) : 1;
+            const bool ww_extra = ww >= 64 && a.Ktot >= ww;
+            const bool wide_wave = ww != 0;
+            if ((bm256 == 2 || (bm256 != 0 && long_k) || ww_extra) && a.N >= 128 && !narrow && a.N % 128 == 0) {
                 // 256-row tiles: whole tiles on the first multiple of 256 workgroups, the remainder split along K
                 constexpr int CUS = 256;
                 a.nblk_m = (a.M + 255) / 256;
@@ -1917,8 +1944,12 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                     }
                 }
                 const int grid = a.tail_q > 1 ? a.tail_full + (ntiles - a.tail_full) * a.tail_q : ntiles;
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3, 4, 256>), dim3(grid), dim3(512), 0, st, a, (uint32_t)xb,
-                                   (uint32_t)wb);
+                if (wide_wave)
+                    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3, 2, 256, 128>), dim3(grid), dim3(256), 0, st, a,
+                                       (uint32_t)xb, (uint32_t)wb);
+                else
+                    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3, 4, 256>), dim3(grid), dim3(512), 0, st, a, (uint32_t)xb,
+                                       (uint32_t)wb);
                 DML_LAUNCH_CHECK();
                 return 0;
             }

@@ -22,16 +22,20 @@ def test_conv_ops_through_the_register_staged_kernel():
     assert "passed" in r.stdout
 
 
-def test_every_unit_locally_exact_through_the_256_row_tiles():
-    """The 256-row tile variant of the LDS-DMA kernel runs by itself only on very large maps (the decoder's 3x3 at 16 x
-    192 x 192); DML_CONV_BM256=2 forces it on every eligible layer of a bf16 train step -- fused statistics, fused
-    BN-backward sums, accumulate, the K-split tail -- and every unit must still be exact to one bf16 ulp."""
-    env = dict(os.environ, DML_CONV_BM256="2")
+@pytest.mark.parametrize("wide_wave", ["1", "0"])
+def test_every_unit_locally_exact_through_the_256_row_tiles(wide_wave):
+    """The 256-row tile variants of the LDS-DMA kernel run by themselves only on the long-K layers (K >= 4608, or the
+    decoder's 3x3 at 16 x 192 x 192); DML_CONV_BM256=2 forces them on every eligible layer of a bf16 train step -- fused
+    statistics, fused BN-backward sums, accumulate, the K-split tail -- and every unit must still be exact to one bf16
+    ulp.  wide_wave = 1 (default): 4 waves on 128 x 64 wave tiles (conv_igemm_dma_kernel<.., 256, 128>), all three cases
+    of the locally-exact gate incl. 768 x 768; 0: the 8-wave variant on 64 x 64 wave tiles, the small case."""
+    env = dict(os.environ, DML_CONV_BM256="2", DML_CONV_WW=wide_wave)
+    sel = "locally_exact" if wide_wave == "1" else "locally_exact and shape1"
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_bf16_parity.py"), "-m", "gpu",
-                        "-q", "-x", "-k", "locally_exact", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                        "-q", "-x", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                        cwd=H.ROOT, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "2 passed" in r.stdout
+    assert ("3 passed" if wide_wave == "1" else "1 passed") in r.stdout
 
 
 def test_sync_batchnorm_two_ranks_match_one_process():
@@ -69,6 +73,60 @@ def test_data_parallel_reducer_two_ranks():
                        env=env, capture_output=True, text=True, cwd=H.ROOT, timeout=1200)
     assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]
     assert "parameters identical across ranks after 3 steps: True" in r.stdout and "uneven shards" in r.stdout
+
+
+def test_data_parallel_reducer_four_ranks_small_and_large_buckets():
+    """config #4 readiness without the hardware: FOUR gloo ranks sharing this GPU, 2-3 images per rank (uneven), with
+    1 MB buckets (225 collectives per step, launched all along the backward) and 32 MB buckets (the bench's setting):
+    reduced gradient = sum of the per-rank ones, replicas bit-identical after 3 optimizer steps (tools/check_ddp.py)."""
+    env = dict(os.environ, DML_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", DDP_BUCKET_MBS="1,32", DDP_DTYPES="f32")
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "4", "--master-addr",
+                        "127.0.0.1", "--master-port", str(_free_port()), os.path.join(H.ROOT, "tools", "check_ddp.py")],
+                       env=env, capture_output=True, text=True, cwd=H.ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-3000:]
+    assert r.stdout.count("parameters identical across ranks after 3 steps: True") == 8          # 4 ranks x 2 bucket sizes
+    assert "1 MB buckets" in r.stdout and "32 MB buckets" in r.stdout
+
+
+def test_reducer_launch_points_overlap_the_backward_at_768():
+    """Overlap evidence for the 8-rank run this pool cannot execute: at the benchmark's shape the reducer's 32 MB buckets
+    (reverse parameter order) become ready -- Plan.param_last_op: the last backward op that writes into the bucket --
+    while most of the backward is still to come.  Counted in conv FLOPs of the backward plan still ahead at each launch
+    point: all buckets but the one holding the stem's parameters start before the last op, and half of them with > 30 %
+    of the backward left to hide a 32 MB all-reduce under."""
+    import torch
+    import network
+    import utils
+    import bench
+    from dmlnet import parallel
+    m = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
+    m.cuda().train()
+    m.set_compute_dtype(torch.bfloat16)
+    utils.set_bn_momentum(m.backbone, 0.01)
+    img = torch.randn(2, 3, 768, 768, device="cuda")
+    m(img)
+    plan = next(p for k, p in m._engine.plans.items() if k[4])
+    red = parallel.GradReducer(m._engine.store, bucket_mb=32.0, average=False)
+    sched = red._schedule(plan)
+    n_b = len(red.buckets)          # 235 MB in buckets of at least 32 MB: 7
+    assert n_b in (7, 8) and sum(hi - lo for lo, hi, _ in red.buckets) == m._engine.store.total
+    _, per_op = bench.conv_flops_of_plan(plan)
+    bwd = {i: f for (name, i), f in per_op.items() if name == "bwd"}
+    total = sum(bwd.values())
+    rows = []
+    for op_i in sorted(sched):
+        left = sum(f for i, f in bwd.items() if i > op_i) / total
+        for b in sched[op_i]:
+            lo, hi, _ = red.buckets[b]
+            rows.append((b, op_i, (hi - lo) * 4 / 2 ** 20, left))
+    print("bucket  launch op (of %d)  MB     backward conv FLOPs still ahead" % len(plan.bwd))
+    for b, op_i, mb, left in rows:
+        print("%4d %12d %9.1f %10.1f %%" % (b, op_i, mb, 100 * left))
+    early = [r for r in rows if r[1] < len(plan.bwd) - 1]
+    assert len(early) >= n_b - 1, rows          # only the bucket holding the stem's parameters waits for the last op
+    assert sum(1 for r in rows if r[3] > 0.30) >= n_b // 2, rows
+    launch_order = [r[0] for r in rows]
+    assert launch_order == sorted(launch_order)          # bucket 0 (the head's parameters) first, the stem's last
 
 
 def test_rccl_backend_runs_the_reducer_with_one_forced_rank():

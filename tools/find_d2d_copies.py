@@ -23,3 +23,13 @@ import collections
 names = collections.Counter(e.name for e in prof.events())
 for n, k in names.most_common(60):
     if k >= 50: print(k, n[:100])
+print("---- copy-like events with stacks")
+seen = collections.Counter()
+for e in prof.events():
+    if "copy" in e.name.lower() or "memcpy" in e.name.lower():
+        st = tuple(s for s in (e.stack or [])[:6])
+        seen[(e.name[:60], st)] += 1
+for (n, st), k in seen.most_common(12):
+    print(k, n)
+    for s in st:
+        print("      ", s[:140])
