@@ -253,10 +253,11 @@ def conv_op_list(plan):
     return out
 
 
-def conv_class_table(plan, dtype, min_ms=0.1):
+def conv_class_table(plan, dtype, top=12):
     """Per shape class of the profiled pass: launches, ms per step, TFLOP/s, and the class's OWN two-roof bound
     bound_ms = max(FLOPs / MFMA peak, algorithmic bytes / 8 TB/s) with frac = bound_ms / ms (hard part 1: the
-    roofline of this network has to be read per layer class -- the 1x1 layers on the large maps are streaming GEMMs)."""
+    roofline of this network has to be read per layer class -- the 1x1 layers on the large maps are streaming GEMMs).
+    Returns (rows for the JSON line: the `top` classes by time + one "other" row per kind, all rows)."""
     peak = PEAK[dtype]
     rows = {}
     for op in conv_op_list(plan):
@@ -270,27 +271,32 @@ def conv_class_table(plan, dtype, min_ms=0.1):
             r["ms"] += sec * m["flops"] / ftot * 1e3              # a grouped launch: its time is shared out by FLOPs
             r["gflop"] += m["flops"] / 1e9
             r["alg_MB"] += m["alg_bytes"] / 1e6
-    out, rest = [], {}
-    for r in rows.values():
-        if r["ms"] < min_ms:
-            o = rest.setdefault(r["kind"], {"kind": r["kind"], "shape": "other (< %.1f ms per class)" % min_ms, "launches": 0,
-                                            "ms": 0.0, "gflop": 0.0, "alg_MB": 0.0})
-            for k in ("launches", "ms", "gflop", "alg_MB"):
-                o[k] += r[k]
-        else:
-            out.append(r)
-    out += list(rest.values())
-    for r in out:
+
+    def finish(r):
         t_mfma, t_hbm = r["gflop"] * 1e9 / peak * 1e3, r["alg_MB"] * 1e6 / HBM_PEAK * 1e3
         r["bound"] = "mfma" if t_mfma >= t_hbm else "hbm"
-        r["bound_ms"] = max(t_mfma, t_hbm)
-        r["frac_of_bound"] = r["bound_ms"] / r["ms"] if r["ms"] > 0 else 0.0
-        r["tflops"] = r["gflop"] / r["ms"] if r["ms"] > 0 else 0.0
-        r["mfma_frac"] = r["tflops"] * 1e12 / peak
-        for k in ("ms", "gflop", "alg_MB", "bound_ms", "frac_of_bound", "tflops", "mfma_frac"):
-            r[k] = round(r[k], 4)
-    out.sort(key=lambda r: -r["ms"])
-    return out
+        r["bound_ms"] = round(max(t_mfma, t_hbm), 3)
+        r["frac"] = round(r["bound_ms"] / r["ms"], 3) if r["ms"] > 0 else 0.0
+        r["tflops"] = round(r["gflop"] / r["ms"], 1) if r["ms"] > 0 else 0.0
+        r["ms"], r["gflop"], r["alg_MB"] = round(r["ms"], 3), round(r["gflop"], 1), round(r["alg_MB"], 1)
+        return r
+
+    full = sorted((finish(dict(r)) for r in rows.values()), key=lambda r: -r["ms"])
+    head, rest = full[:top], {}
+    for r in rows.values():
+        if not any(h["kind"] == r["kind"] and h["shape"] == r["shape"] for h in head):
+            o = rest.setdefault(r["kind"], {"kind": r["kind"], "shape": "other classes", "launches": 0, "ms": 0.0, "gflop": 0.0,
+                                            "alg_MB": 0.0})
+            for k in ("launches", "ms", "gflop", "alg_MB"):
+                o[k] += r[k]
+    # compact rows (the driver keeps the TAIL of stdout: the line has to stay a few KB): columns = CLASS_COLS
+    line = [[r["kind"], r["shape"].replace("x48", "").replace("x192", "").replace("x96", ""), r["launches"], r["ms"], r["bound"],
+             r["bound_ms"], r["frac"], r["tflops"]] for r in head + sorted((finish(o) for o in rest.values()), key=lambda r: -r["ms"])]
+    return line, full
+
+
+CLASS_COLS = ["kind", "conv (kxk Cin->Cout @map)", "launches", "ms", "own_bound", "bound_ms=max(flops/peak,alg_bytes/8TB/s)",
+              "frac=bound_ms/ms", "TFLOP/s"]
 
 
 def _time_launches(fn, n=20, warm=3):
@@ -663,10 +669,14 @@ def main():
             # the reference's arithmetic is fp32 (network/utils.py:84-118): the same step in the exact-fp32 mode
             # (v_mfma_f32_16x16x4_f32, the mode the 1e-3 parity tests run), driver-timed next to the bf16 headline
             torch.cuda.empty_cache()
-            f = train_pass(args, "f32", device, rank, world, steps=args.steps, warmup=args.warmup, profile=True)
+            f = train_pass(args, "f32", device, rank, world, steps=args.steps, warmup=args.warmup, profile=True,
+                           dump_conv=(args.dump_conv + ".fp32") if args.dump_conv else None)
             out["fp32_companion"] = {"dtype": "f32", "value": f["value"], "unit": "images/sec", "ms_per_step": f["ms_per_step"],
                                      "steps": args.steps, "warmup": args.warmup, "final_loss": f["final_loss"],
-                                     "roofline": f["roofline"]}
+                                     "roofline": {k: f["roofline"][k] for k in (
+                                         "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes",
+                                         "traffic_over_algorithmic", "flops_per_step", "launches_per_step", "conv_ms_per_step",
+                                         "classes") if k in f["roofline"]}}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
         if "input_pipeline" in out:
@@ -771,23 +781,28 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
                 tj = json.load(fh)
             if tj.get("csrc_sha") == csrc_sha():
                 traffic = tj["conv_GB_per_step"] * 1e9 / n_launch      # per launch OF THIS PLAN (a grouped launch is one)
-                traffic_src = "profiles/%s (rocprofv3 --pmc, %.1f GB per step over the conv launches, csrc %s)" \
-                    % (os.path.basename(tpath), tj["conv_GB_per_step"], tj["csrc_sha"])
-        roof = {"bound": "mfma", "kernel": "every convolution launch of a step (conv_igemm*_kernel forward / data gradient, "
-                                           "conv_wgrad*_kernel weight gradient)",
+                traffic_src = "profiles/%s (rocprofv3 --pmc, %.1f GB/step over the conv launches)" \
+                    % (os.path.basename(tpath), tj["conv_GB_per_step"])
+        roof = {"bound": "mfma", "kernel": "all conv launches of a step (conv_igemm*: fwd / dgrad, conv_wgrad*: wgrad)",
                 "achieved": flops / conv_sec / 1e12, "peak": peak / 1e12, "unit": "TFLOP/s",
-                "frac": flops / conv_sec / peak, "traffic": traffic, "traffic_unit": "bytes per launch (mean)",
+                "frac": flops / conv_sec / peak, "traffic": traffic, "traffic_unit": "B/launch",
                 "traffic_source": traffic_src, "algorithmic_bytes": alg_bytes / n_launch,
                 "flops_per_step": flops, "launches_per_step": n_launch,
                 "avg_launch_ms": conv_sec / n_launch * 1e3, "conv_ms_per_step": conv_sec * 1e3,
                 "igemm_ms_per_step": tsec["igemm"] * 1e3, "wgrad_ms_per_step": tsec["wgrad"] * 1e3,
-                "whole_step_frac": flops / (elapsed / steps) / peak, "csrc_sha": csrc_sha(),
-                "note": "data-gradient launches also compute the BatchNorm-backward sums of the tensor they "
-                        "write (bn_bwd_reduce folded into their epilogues); their time is charged to the convolutions here"}
+                "whole_step_frac": flops / (elapsed / steps) / peak, "csrc_sha": csrc_sha()}
+        # (data-gradient launches also compute the BatchNorm-backward sums of the tensor they write -- bn_bwd_reduce folded
+        # into their epilogues; that time is charged to the convolutions here)
         if traffic is not None:
             roof["traffic_over_algorithmic"] = traffic * n_launch / alg_bytes
             roof["hbm_frac_of_same_launches"] = traffic * n_launch / conv_sec / 8e12
-        roof["classes"] = conv_class_table(plan, dtype)
+        # per-class two-roof table: the dozen most expensive classes on the line, every class in --dump-conv's side file and
+        # in profiles/ (tools/run_r03_profiles.sh); the fp32 companion carries six
+        roof["classes_cols"] = CLASS_COLS
+        roof["classes"], full = conv_class_table(plan, dtype, top=12 if dtype == "bf16" else 3)
+        if dump_conv:
+            with open(dump_conv + ".classes.json", "w") as fh:
+                json.dump(full, fh, indent=0)
         res["roofline"] = roof
     del model, opt, sched, crit, step
     torch.cuda.empty_cache()

@@ -161,7 +161,7 @@ def test_committed_bench_line_carries_the_contract_fields():
     files = [f for f in glob.glob(os.path.join(H.ROOT, "profiles", "r*_bench_v*.json")) if re.search(r"r\d+_bench_v\d+\.json$", f)]
     newest = max(files, key=lambda f: tuple(int(x) for x in re.findall(r"r(\d+)_bench_v(\d+)", f)[0]))
     d = json.load(open(newest))
-    assert os.path.basename(newest).startswith("r02"), newest
+    assert os.path.basename(newest).startswith("r03"), newest
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "fp32_companion", "hbm_kernel"):
         assert k in d, k
@@ -172,8 +172,16 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
     assert r["algorithmic_bytes"] > 0 and (r["traffic"] is None or r["traffic"] > 0.5 * r["algorithmic_bytes"])
     assert abs(r["achieved"] * 1e12 - r["flops_per_step"] / (r["conv_ms_per_step"] * 1e-3)) < 1e-6 * r["achieved"] * 1e12
+    # per-class two-roof table: rows follow classes_cols; every class's own bound is max(FLOPs / peak, bytes / 8 TB/s)
+    cols = r["classes_cols"]
+    assert len(cols) == 8 and len(r["classes"]) >= 12 and all(len(row) == len(cols) for row in r["classes"])
+    assert abs(sum(row[3] for row in r["classes"]) - r["conv_ms_per_step"]) < 0.02 * r["conv_ms_per_step"]
+    assert all(row[4] in ("mfma", "hbm") and 0 < row[6] <= 1.0 for row in r["classes"])
+    assert len(json.dumps(d)) < 8000          # the driver keeps the tail of stdout: the line stays a few KB
     f = d["fp32_companion"]
     assert f["dtype"] == "f32" and f["value"] > 0 and abs(f["roofline"]["frac"] - f["roofline"]["achieved"] / 157.3) < 1e-6
+    assert f["steps"] == d["steps"] and f["warmup"] == d["warmup"]          # first-class: the headline's K and W
+    assert f["roofline"]["traffic"] is None or f["roofline"]["traffic"] > 0.5 * f["roofline"]["algorithmic_bytes"]
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and str(c["cores"]) in c["by_threads"]
     h = d["hbm_kernel"]
