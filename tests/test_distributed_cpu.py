@@ -1,4 +1,4 @@
-"""CPU, world_size 2, gloo: the N>1 path -- bucketed gradient reduction over the flat buffer and the
+"""CPU, world_size 2 and 4 (uneven shards: 6 images over 4 ranks), gloo: the N>1 path -- bucketed gradient reduction over the flat buffer and the
 global-batch loss normalisation -- gives the gradients of the single-process run on the concatenated batch.
 The compute on each rank is plain torch (allowed in tests); the small net has no BatchNorm because the
 reference's DataParallel replicas (and this design) keep BatchNorm statistics per rank."""
@@ -65,11 +65,15 @@ def _worker(rank, world, port, out):
     dist.destroy_process_group()
 
 
-def test_two_rank_gradients_equal_single_process(tmp_path):
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_multi_rank_gradients_equal_single_process(tmp_path, world):
     from oracle import dmlnet_ref as O
     out = str(tmp_path / "g.pt")
-    port = 29500 + (os.getpid() % 500)
-    mp.start_processes(_worker, args=(2, port, out), nprocs=2, join=True, start_method="spawn")
+    port = 29500 + (os.getpid() % 500) + world
+    mp.start_processes(_worker, args=(world, port, out), nprocs=world, join=True, start_method="spawn")
     flat = torch.load(out)
     model = _small_model()
     x = H.synth_tensor(21, "ddp.x", (6, 3, 10, 12))
