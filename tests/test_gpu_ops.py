@@ -753,7 +753,8 @@ def test_rejects_bad_arguments(lib):
 
 @pytest.mark.parametrize("geom", [(2, 13, 20), (1, 7, 14), (3, 29, 5), (1, 192, 192)])
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
-def test_head_backward_fused_vs_plain_torch(lib, geom, dname):
+@pytest.mark.parametrize("proto_kind", ["general", "3I", "diagonal"])
+def test_head_backward_fused_vs_plain_torch(lib, geom, dname, proto_kind):
     """dml_head_bwd_fused (loss gradient + distance-head gradient + transposed x4 upsample in one pass) against autograd
     through the reference's arithmetic (network/utils.py:88-118 + anomaly/models/models.py:42-78: interpolate ->
     distances -> CE/n + alpha VAR/n) on the CPU, and against the unfused kernel chain.  Tiles are 7 x 14 low-resolution
@@ -765,7 +766,13 @@ def test_head_backward_fused_vs_plain_torch(lib, geom, dname):
     Hh, Ww = 4 * h, 4 * w
     emb = rnd("hb.emb%d%d" % (h, w), (B, 16, h, w), 1.5).requires_grad_(True)
     lab = H.synth_labels(5, "hb.lab%d%d" % (h, w), (B, Hh, Ww), 16, 255, ignore_frac=0.1)
-    protos = O.prototypes_3I(16) + 0.05 * rnd("hb.pr", (16, 16))
+    # general matrix: the kernel's general path; 3 * I (the reference's centers) and another diagonal: its closed-form path
+    if proto_kind == "general":
+        protos = O.prototypes_3I(16) + 0.05 * rnd("hb.pr", (16, 16))
+    elif proto_kind == "3I":
+        protos = O.prototypes_3I(16)
+    else:
+        protos = torch.diag(3.0 + rnd("hb.prd", (16,)))
     up = F.interpolate(emb, size=(Hh, Ww), mode="bilinear", align_corners=False)
     logits, _, feats = O.distance_head(up, protos)
     loss = O.dml_loss(logits, lab, alpha=0.01, ignore_index=255) * 1.7            # gout = 1.7
