@@ -253,7 +253,7 @@ def conv_op_list(plan):
     return out
 
 
-def conv_class_table(plan, dtype, top=12):
+def conv_class_table(plan, dtype, top=12, pmc_classes=None):
     """Per shape class of the profiled pass: launches, ms per step, TFLOP/s, and the class's OWN two-roof bound
     bound_ms = max(FLOPs / MFMA peak, algorithmic bytes / 8 TB/s) with frac = bound_ms / ms (hard part 1: the
     roofline of this network has to be read per layer class -- the 1x1 layers on the large maps are streaming GEMMs).
@@ -282,6 +282,10 @@ def conv_class_table(plan, dtype, top=12):
         return r
 
     full = sorted((finish(dict(r)) for r in rows.values()), key=lambda r: -r["ms"])
+    # PMC bytes of the class over its algorithmic bytes (profiles/*_traffic_pmc.json "classes", same kernel sources only)
+    pmc = {(c["kind"], c["shape"]): c["pmc_over_alg"] for c in (pmc_classes or [])}
+    for r in full:
+        r["pmc_over_alg"] = pmc.get((r["kind"], r["shape"]))
     head, rest = full[:top], {}
     for r in rows.values():
         if not any(h["kind"] == r["kind"] and h["shape"] == r["shape"] for h in head):
@@ -291,12 +295,13 @@ def conv_class_table(plan, dtype, top=12):
                 o[k] += r[k]
     # compact rows (the driver keeps the TAIL of stdout: the line has to stay a few KB): columns = CLASS_COLS
     line = [[r["kind"], r["shape"].replace("x48", "").replace("x192", "").replace("x96", ""), r["launches"], r["ms"], r["bound"],
-             r["bound_ms"], r["frac"], r["tflops"]] for r in head + sorted((finish(o) for o in rest.values()), key=lambda r: -r["ms"])]
+             r["bound_ms"], r["frac"], r["tflops"], r.get("pmc_over_alg")]
+            for r in head + sorted((finish(o) for o in rest.values()), key=lambda r: -r["ms"])]
     return line, full
 
 
 CLASS_COLS = ["kind", "conv (kxk Cin->Cout @map)", "launches", "ms", "own_bound", "bound_ms=max(flops/peak,alg_bytes/8TB/s)",
-              "frac=bound_ms/ms", "TFLOP/s"]
+              "frac=bound_ms/ms", "TFLOP/s", "PMC bytes / algorithmic bytes"]
 
 
 def _time_launches(fn, n=20, warm=3):
@@ -774,13 +779,14 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
         # HBM bytes per conv launch from the committed PMC passes of this same command (tools/run_traffic.sh: separate
         # --pmc FETCH_SIZE / WRITE_SIZE runs, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024).  Quoted only when the file was
         # collected on exactly these kernel sources (csrc_sha inside the file), else null.
-        traffic, traffic_src = None, None
+        traffic, traffic_src, pmc_classes = None, None, None
         tpath = os.path.join(ROOT, "profiles", ROUND + ("_traffic_pmc.json" if dtype == "bf16" else "_fp32_traffic_pmc.json"))
         if os.path.exists(tpath) and args.batch == 16 and args.size == 768:
             with open(tpath) as fh:
                 tj = json.load(fh)
             if tj.get("csrc_sha") == csrc_sha():
                 traffic = tj["conv_GB_per_step"] * 1e9 / n_launch      # per launch OF THIS PLAN (a grouped launch is one)
+                pmc_classes = tj.get("classes")
                 traffic_src = "profiles/%s (rocprofv3 --pmc, %.1f GB/step over the conv launches)" \
                     % (os.path.basename(tpath), tj["conv_GB_per_step"])
         roof = {"bound": "mfma", "kernel": "all conv launches of a step (conv_igemm*: fwd / dgrad, conv_wgrad*: wgrad)",
@@ -799,7 +805,7 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
         # per-class two-roof table: the dozen most expensive classes on the line, every class in --dump-conv's side file and
         # in profiles/ (tools/run_r03_profiles.sh); the fp32 companion carries six
         roof["classes_cols"] = CLASS_COLS
-        roof["classes"], full = conv_class_table(plan, dtype, top=12 if dtype == "bf16" else 3)
+        roof["classes"], full = conv_class_table(plan, dtype, top=12 if dtype == "bf16" else 3, pmc_classes=pmc_classes)
         if dump_conv:
             with open(dump_conv + ".classes.json", "w") as fh:
                 json.dump(full, fh, indent=0)

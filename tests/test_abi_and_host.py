@@ -174,7 +174,8 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert abs(r["achieved"] * 1e12 - r["flops_per_step"] / (r["conv_ms_per_step"] * 1e-3)) < 1e-6 * r["achieved"] * 1e12
     # per-class two-roof table: rows follow classes_cols; every class's own bound is max(FLOPs / peak, bytes / 8 TB/s)
     cols = r["classes_cols"]
-    assert len(cols) == 8 and len(r["classes"]) >= 12 and all(len(row) == len(cols) for row in r["classes"])
+    assert len(cols) == 9 and len(r["classes"]) >= 12 and all(len(row) == len(cols) for row in r["classes"])
+    assert all(row[8] is None or row[8] > 0.9 for row in r["classes"][:12])          # PMC bytes never below the algorithmic ones
     assert abs(sum(row[3] for row in r["classes"]) - r["conv_ms_per_step"]) < 0.02 * r["conv_ms_per_step"]
     assert all(row[4] in ("mfma", "hbm") and 0 < row[6] <= 1.0 for row in r["classes"])
     assert len(json.dumps(d)) < 8000          # the driver keeps the tail of stdout: the line stays a few KB
