@@ -28,7 +28,9 @@ for p in (ROOT, PKG, os.path.join(ROOT, "tests")):
 import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
-PEAK = {"bf16": 2.5e15, "f32": 157.3e12}      # dense MFMA peaks, MI355X_MICROARCH.md
+# dense MFMA peaks, MI355X_MICROARCH.md; "f32x3" = fp32 storage with the convolutions' products on the bf16 matrix cores through
+# a three-term split (six bf16 MFMAs per fp32-accurate block): its ceiling in fp32-equivalent FLOPs is the bf16 peak / 6
+PEAK = {"bf16": 2.5e15, "f32": 157.3e12, "f32x3": 2.5e15 / 6}
 HBM_PEAK = 8.0e12
 ROUND = "r03"
 
@@ -607,7 +609,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x3"],
+                    help="bf16 (headline), f32 = exact fp32 MFMA (the reference's arithmetic), f32x3 = fp32 storage, conv products "
+                         "through the three-term bf16 split (fp32-level error)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=768)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -682,6 +686,14 @@ def main():
                                          "bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_source", "algorithmic_bytes",
                                          "traffic_over_algorithmic", "flops_per_step", "launches_per_step", "conv_ms_per_step",
                                          "classes") if k in f["roofline"]}}
+            # fp32 storage, the convolutions' products on the bf16 matrix cores through the three-term split (fp32-level error:
+            # tests/test_gpu_ops.py::test_conv_f32_three_term_split_is_fp32_accurate, G5 / G8 with products="bf16x3")
+            torch.cuda.empty_cache()
+            f3 = train_pass(args, "f32x3", device, rank, world, steps=args.steps, warmup=args.warmup, profile=True, dump_conv=None)
+            out["fp32_companion"]["split_products"] = {
+                "dtype": "f32x3", "value": f3["value"], "ms_per_step": f3["ms_per_step"], "final_loss": f3["final_loss"],
+                "conv_ms_per_step": f3["roofline"].get("conv_ms_per_step"), "achieved": f3["roofline"].get("achieved"),
+                "peak": f3["roofline"].get("peak"), "frac": f3["roofline"].get("frac")}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args.size, args.cpu_threads)
         if "input_pipeline" in out:
@@ -705,7 +717,8 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
     torch.manual_seed(1)
     model = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
     model.to(device)
-    model.set_compute_dtype(torch.bfloat16 if dtype == "bf16" else torch.float32)
+    model.set_compute_dtype(torch.bfloat16 if dtype == "bf16" else torch.float32,
+                            fp32_products="bf16x3" if dtype == "f32x3" else "exact")
     model.train()
     utils.set_bn_momentum(model.backbone, momentum=0.01)                     # main_embedding.py:379
     lr = 0.01
@@ -780,7 +793,7 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
         # --pmc FETCH_SIZE / WRITE_SIZE runs, bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024).  Quoted only when the file was
         # collected on exactly these kernel sources (csrc_sha inside the file), else null.
         traffic, traffic_src, pmc_classes = None, None, None
-        tpath = os.path.join(ROOT, "profiles", ROUND + ("_traffic_pmc.json" if dtype == "bf16" else "_fp32_traffic_pmc.json"))
+        tpath = os.path.join(ROOT, "profiles", ROUND + {"bf16": "_traffic_pmc.json", "f32": "_fp32_traffic_pmc.json"}.get(dtype, "_none"))
         if os.path.exists(tpath) and args.batch == 16 and args.size == 768:
             with open(tpath) as fh:
                 tj = json.load(fh)

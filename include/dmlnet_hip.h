@@ -110,7 +110,12 @@ typedef struct DmlConvDesc {
      * staging tensor acc32 [M][N] (pitch acc32_ld floats) by the earlier producers (y_f32 = 1, accum = 0 / 1) and the
      * LAST producer adds it to its accumulators and rounds the total once into the bf16 tensor y. */
     const float* acc32;
-    int32_t acc32_ld, acc32_reserved;
+    int32_t acc32_ld;
+    /* dtype DML_F32 only: 1 = compute the products on the bf16 matrix cores through a three-term split of both operands
+     * (x = hi + mid + lo, six bf16 MFMAs per block: fp32-level error, 2.7x fewer matrix cycles than v_mfma_f32_16x16x4_f32);
+     * 0 = the exact fp32 MFMA, the reference's arithmetic (network/utils.py:84-118 computes in fp32).  Shapes the split kernel
+     * does not take (C % 32 != 0, N <= 32) run exact either way. */
+    int32_t f32_split;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
@@ -129,6 +134,8 @@ typedef struct DmlWgradDesc {
     int32_t Cm;           /* un-padded input channels of dw ([N][R][S][Cm]); 0 = C.  Cm < C needs `ws`        */
     float* ws;            /* optional workspace: slices store partials [splitk][N][R*S*C] with plain stores  */
     int64_t ws_elems;     /* and a second kernel folds them into dw (no fp32 atomics); capacity in floats     */
+    int32_t f32_split;    /* dtype DML_F32 only: products through the three-term bf16 split (DmlConvDesc.f32_split) */
+    int32_t reserved;
 } DmlWgradDesc;
 
 int dml_conv_wgrad(const DmlWgradDesc* d, void* stream);

@@ -63,6 +63,7 @@ struct ConvArgs {
     // data-gradient mode: fp32 sum of the earlier producers of this gradient, added before the one rounding (DmlConvDesc::acc32)
     const float* acc32;
     int acc32_ld;
+    int f32_split;      // fp32 tensors: products through the three-term bf16 split (DmlConvDesc::f32_split)
     // bit 0: the epilogue's bf16 output stores carry the non-temporal hint, bit 1: its partial-statistics stores (launch_conv)
     int nt_out;
 };
@@ -766,6 +767,199 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) v
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 tensors, products on the bf16 matrix cores: three-term split.
+// The exact mode's v_mfma_f32_16x16x4_f32 runs at 1/16 of the bf16 rate.  Here every fp32 operand value x is split once,
+// on its way from the staging registers into LDS, into hi = bf16(x), mid = bf16(x - hi), lo = bf16(x - hi - mid) (24 mantissa
+// bits, each residual exact in fp32), LDS holds three bf16 planes per operand tile, and a 16 x 16 x 32 block is the six
+// bf16 MFMAs whose terms are above 2^-26 of the product: lo*hi', hi*lo', mid*mid', mid*hi', hi*mid', hi*hi' (small terms
+// first; every bf16 x bf16 product is exact in the fp32 accumulator).  96 MFMA cycles per block instead of 256; results at
+// fp32 rounding level (NOT the reference's fp32 arithmetic bit for bit: DmlConvDesc.f32_split).
+// One LDS buffer of 3 x (BM + BN) x 32 bf16 = 48 KB, two barriers per K step, global loads of the next tile in flight in
+// registers meanwhile; 256-register budget = two workgroups per CU.  ALIGNED shapes only (C % 32 == 0).
+// ------------------------------------------------------------------------------------------------
+template <int BN, int MODE>
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_igemm_x3_kernel(const ConvArgs a) {
+    typedef float T;
+    constexpr int BM = 128, ES = 4;
+    constexpr int KV = BK / 4;                   // 16-byte chunks (4 floats) per tile row
+    constexpr int RPP = NTHREADS / KV;           // rows staged per pass
+    constexpr int A_LD = BM / RPP, B_LD = BN / RPP;
+    constexpr int TM = 64, TN = BN / 2, MT = TM / 16, NT = TN / 16;
+    constexpr int PA = BM * BK, PB = BN * BK;    // bf16 elements per plane
+    constexpr uint32_t OOB = 0x80000000u;
+    __shared__ __attribute__((aligned(256))) bf16_t smem[3 * (PA + PB)];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int tile = xcd_remap(blockIdx.x, gridDim.x);
+    const int blk_m = tile / a.nblk_n, blk_n = tile - blk_m * a.nblk_n;
+    const int m0 = blk_m * BM, n0 = blk_n * BN;
+    const int kvec = tid % KV, prow = tid / KV;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    const int sh2 = (MODE != 0 && a.stride == 2) ? 1 : 0;
+    int a_base[A_LD];
+    uint32_t a_mask[A_LD], b_base[B_LD];
+#pragma unroll
+    for (int j = 0; j < A_LD; ++j) {
+        const int m = m0 + prow + j * RPP;
+        a_base[j] = 0;
+        a_mask[j] = 0;
+        if (m < a.M) {
+            const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+            const uint32_t yo = fdiv(rem, a.div_wo);
+            const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+            const int iy = MODE == 0 ? (int)yo * a.stride - a.pad : (int)yo + a.pad;
+            const int ix = MODE == 0 ? (int)xo * a.stride - a.pad : (int)xo + a.pad;
+            const int by = MODE == 0 ? iy : (iy >> sh2), bx = MODE == 0 ? ix : (ix >> sh2);
+            a_base[j] = ((((int)b * a.Hi + by) * a.Wi + bx) * a.ldx + kvec * 4) * ES;
+            uint32_t mk = 0;
+            for (int r = 0, t = 0; r < a.R; ++r)
+                for (int q = 0; q < a.S; ++q, ++t) {
+                    bool ok;
+                    if (MODE == 0) {
+                        const int ys = iy + r * a.dil, xs = ix + q * a.dil;
+                        ok = ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+                    } else {
+                        const int ty = iy - r * a.dil, tx = ix - q * a.dil;
+                        ok = (sh2 == 0 || (((ty | tx) & 1) == 0)) && ty >= 0 && tx >= 0 && ((ty >> sh2) < a.Hi) &&
+                             ((tx >> sh2) < a.Wi);
+                    }
+                    mk |= ok ? (1u << t) : 0u;
+                }
+            a_mask[j] = mk;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < B_LD; ++j) {
+        const int row = prow + j * RPP, n = n0 + row;
+        b_base[j] = (n < a.N) ? (uint32_t)((n * a.Ktot + kvec * 4) * ES) : OOB;
+    }
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t a_reg[A_LD], b_reg[B_LD];
+    int tap_r = 0, tap_s = 0, c0 = 0;
+    const int KT = a.Ktot / BK;
+    auto load_tiles = [&](int kt) {          // kt >= KT: every lane out of range (zeros, no memory access) -- keeps the loop branch-free
+        const uint32_t tapbit = kt < KT ? 1u << ((tap_r * a.S + tap_s) & 31) : 0u;
+        const int soff = (MODE == 0 ? ((tap_r * a.dil) * a.Wi + tap_s * a.dil) * a.ldx
+                                    : -((((tap_r * a.dil) >> sh2) * a.Wi + ((tap_s * a.dil) >> sh2)) * a.ldx)) * ES + c0 * ES;
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const uint32_t voff = (a_mask[j] & tapbit) ? (uint32_t)(a_base[j] + soff) : OOB;
+            a_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j)
+            b_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(kt < KT ? b_base[j] : OOB), kt < KT ? kt * BK * ES : 0, 0);
+        c0 += BK;
+        if (c0 >= a.C) {
+            c0 = 0;
+            if (++tap_s == a.S) { tap_s = 0; ++tap_r; }
+        }
+    };
+    // x -> (hi, mid, lo), four values at a time, packed as bf16 pairs; the 8-byte piece is half a 16-byte bf16 chunk
+    auto split_store = [&](const u32x4_t v, bf16_t* plane0, int plane_elems, int off) {
+        const float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        uint32_t h[2], m[2], l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
+            const float r0 = x[2 * e] - __uint_as_float(h[e] << 16), r1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+            m[e] = pack_bf16x2(r0, r1);
+            const float s0 = r0 - __uint_as_float(m[e] << 16), s1 = r1 - __uint_as_float(m[e] & 0xffff0000u);
+            l[e] = pack_bf16x2(s0, s1);
+        }
+        *reinterpret_cast<uint2*>(plane0 + off) = make_uint2(h[0], h[1]);
+        *reinterpret_cast<uint2*>(plane0 + plane_elems + off) = make_uint2(m[0], m[1]);
+        *reinterpret_cast<uint2*>(plane0 + 2 * plane_elems + off) = make_uint2(l[0], l[1]);
+    };
+    auto store_tiles = [&]() {
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) {
+            const int row = prow + j * RPP;
+            split_store(a_reg[j], smem, PA, row * BK + swz_chunk<bf16_t>(row, kvec >> 1) * 8 + (kvec & 1) * 4);
+        }
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) {
+            const int row = prow + j * RPP;
+            split_store(b_reg[j], smem + 3 * PA, PB, row * BK + swz_chunk<bf16_t>(b_rho<NT>(row), kvec >> 1) * 8 + (kvec & 1) * 4);
+        }
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_tiles(0);
+    store_tiles();
+    __syncthreads();
+    load_tiles(1);                                  // stays in registers until it is split under the MFMAs of K step 0
+    const int lr = lane & 15, lq = lane >> 4;
+    const bf16_t* as = smem + (wm * TM) * BK;
+    const bf16_t* bs = smem + 3 * PA + (wn * TN) * BK;
+    for (int kt = 0; kt < KT; ++kt) {
+        // all 24 fragments of this K step first (96 registers) ...
+        mfma_bf16x8 af[3][MT], bf[3][NT];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int row = j * 16 + lr;
+                af[p][j] = *reinterpret_cast<const mfma_bf16x8*>(as + p * PA + row * BK + swz_chunk<bf16_t>(row, lq) * 8);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+                bf[p][i] = *reinterpret_cast<const mfma_bf16x8*>(bs + p * PB + b_row<NT>(i, lr) * BK + swz_chunk<bf16_t>(lr, lq) * 8);
+        }
+        __syncthreads();                        // ... so that the one LDS buffer is free while the MFMAs run
+        auto mm = [&](int pb, int pa) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[pb][i], af[pa][j], acc[i][j], 0, 0, 0);
+        };
+        // six MFMA groups (small terms first), the split + store of the NEXT tile's eight staged chunks in between: ~2.4 VALU /
+        // LDS-write instructions per MFMA, which issue in the shadow of the 16-cycle matrix operations
+        auto st_a = [&](int j) {
+            if (j < A_LD) {
+                const int row = prow + j * RPP;
+                split_store(a_reg[j], smem, PA, row * BK + swz_chunk<bf16_t>(row, kvec >> 1) * 8 + (kvec & 1) * 4);
+            }
+        };
+        auto st_b = [&](int j) {
+            if (j < B_LD) {
+                const int row = prow + j * RPP;
+                split_store(b_reg[j], smem + 3 * PA, PB, row * BK + swz_chunk<bf16_t>(b_rho<NT>(row), kvec >> 1) * 8 + (kvec & 1) * 4);
+            }
+        };
+        mm(2, 0); st_a(0); st_a(1);             // lo(w) * hi(x)
+        mm(1, 1); st_a(2); st_a(3);             // mid * mid
+        mm(1, 0); st_b(0); st_b(1);             // mid * hi
+        mm(0, 2); st_b(2); st_b(3);             // hi * lo
+        mm(0, 1);                               // hi * mid
+        load_tiles(kt + 2);                     // staging registers are free again: a whole K step of latency to land
+        mm(0, 0);                               // hi * hi
+        // pin the interleaving: one MFMA, then up to three VALU and one LDS write, for the four groups that have stores
+#pragma unroll
+        for (int q = 0; q < 16 * NT * MT / 4; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+    conv_epilogue<T, NT, MT, MODE>(acc, a, m0 + wm * TM, n0 + wn * TN, lr, lq);
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 forward / data-gradient kernel, LDS-DMA version (requires C % 32 == 0).
 // Operand tiles go HBM -> LDS with buffer_load ... lds (no VGPR round trip, no ds_write): an NST-stage ring (3: 48 KB,
 // three workgroups per CU), tiles issued NST-1 K-steps ahead, counted vmcnt waits and ONE barrier per K-step.  Zero padding / masked rows
@@ -1395,6 +1589,171 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
 }
 
 // ------------------------------------------------------------------------------------------------
+// fp32 weight gradient with the products on the bf16 matrix cores (three-term split, see conv_igemm_x3_kernel): the
+// 128 x 128 tile / split-K scheme of conv_wgrad_kernel<float>, the fp32 operand tiles split into (hi, mid, lo) bf16 planes
+// on their way from the staging registers into LDS -- in conv_wgrad_kernel<bf16_t>'s sub-tiled image, so that the
+// fragments come out of ds_read_b64_tr_b16 -- and six MFMA groups per K step.  One LDS buffer (51 KB), two barriers per
+// step, the next tile's split + store interleaved with the MFMAs, global loads a whole step ahead in registers.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_x3_kernel(const WgradArgs a) {
+    constexpr int TILE = 128, CV = TILE / 4, RPP = NTHREADS / CV, LD = BK / RPP;      // 32 float4 per row, 8 rows per pass, 4 loads
+    constexpr int SUB = 528, PL = (TILE / 16) * SUB;                                   // bf16 elements per operand plane
+    constexpr int MT = 4, NT = 4;
+    __shared__ __attribute__((aligned(16))) bf16_t smem[6 * PL];
+    bf16_t* const Ys = smem;                     // planes hi, mid, lo of dy
+    bf16_t* const Xs = smem + 3 * PL;            // planes of x
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int ntile = a.nblk_n * a.nblk_k;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntile, tile_id = logical - split * ntile;
+    const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
+    const int n0 = blk_n * TILE, kc0 = blk_k * TILE;
+    const float* __restrict__ X = static_cast<const float*>(a.x);
+    const float* __restrict__ DY = static_cast<const float*>(a.dy);
+    const int vcol = tid % CV, prow = tid / CV;
+    const int kc = kc0 + vcol * 4;
+    const bool kc_ok = kc < a.Ktot;
+    const uint32_t tap = fdiv((uint32_t)(kc_ok ? kc : 0), a.div_c);
+    const int xc = (kc_ok ? kc : 0) - (int)tap * a.C;
+    const int tr = (int)tap / a.S, ts = (int)tap - tr * a.S;
+    const int dyo = tr * a.dil - a.pad, dxo = ts * a.dil - a.pad;
+    const int yn = n0 + vcol * 4;
+    const bool yn_ok = yn < a.N;
+    const int tile_beg = split * a.slab_tiles;
+    const int tiles_total = (a.M + BK - 1) / BK;
+    const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
+    const bool lin1x1 = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
+
+    uint4 y_reg[LD], x_reg[LD];
+    auto load_tiles = [&](int t) {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int m = t * BK + prow + j * RPP;
+            uint4 yv = make_uint4(0, 0, 0, 0), xv = make_uint4(0, 0, 0, 0);
+            if (t < tile_end && m < a.M) {
+                if (yn_ok) yv = *reinterpret_cast<const uint4*>(DY + (int64_t)m * a.ldy + yn);
+                if (kc_ok && lin1x1) {
+                    xv = *reinterpret_cast<const uint4*>(X + (int64_t)m * a.ldx + xc);
+                } else if (kc_ok) {
+                    const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+                    const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+                    const uint32_t yo = fdiv(rem, a.div_wo);
+                    const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+                    const int ys = (int)yo * a.stride + dyo, xs = (int)xo * a.stride + dxo;
+                    if ((unsigned)ys < (unsigned)a.Hi && (unsigned)xs < (unsigned)a.Wi)
+                        xv = *reinterpret_cast<const uint4*>(X + ((int64_t)((int)b * a.Hi + ys) * a.Wi + xs) * a.ldx + xc);
+                }
+            }
+            y_reg[j] = yv;
+            x_reg[j] = xv;
+        }
+    };
+    auto split_store = [&](const uint4 v, bf16_t* plane0, int off) {
+        const float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+        uint32_t h[2], m[2], l[2];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            h[e] = pack_bf16x2(x[2 * e], x[2 * e + 1]);
+            const float r0 = x[2 * e] - __uint_as_float(h[e] << 16), r1 = x[2 * e + 1] - __uint_as_float(h[e] & 0xffff0000u);
+            m[e] = pack_bf16x2(r0, r1);
+            const float s0 = r0 - __uint_as_float(m[e] << 16), s1 = r1 - __uint_as_float(m[e] & 0xffff0000u);
+            l[e] = pack_bf16x2(s0, s1);
+        }
+        *reinterpret_cast<uint2*>(plane0 + off) = make_uint2(h[0], h[1]);
+        *reinterpret_cast<uint2*>(plane0 + PL + off) = make_uint2(m[0], m[1]);
+        *reinterpret_cast<uint2*>(plane0 + 2 * PL + off) = make_uint2(l[0], l[1]);
+    };
+    // conv_wgrad_kernel<bf16_t>'s image: 16-column sub-tiles [col / 16][k'][16], k rows with bits 2 / 3 swapped; this
+    // thread's four columns are a quarter of a sub-tile row
+    auto lds_off = [&](int j) {
+        const int row = prow + j * RPP;
+        const int prow_ = (row & 0x13) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 3);
+        return (vcol >> 2) * SUB + prow_ * 16 + (vcol & 3) * 4;
+    };
+
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    load_tiles(tile_beg);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) {
+        split_store(y_reg[j], Ys, lds_off(j));
+        split_store(x_reg[j], Xs, lds_off(j));
+    }
+    __syncthreads();
+    load_tiles(tile_beg + 1);
+    const int lr = lane & 15, lq = lane >> 4;
+    const int p_lo = ((lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4)) * 16 + (lr & 3) * 4;
+    const int p_hi = p_lo + 8 * 16;
+    const bf16_t* ys = Ys + wn * 4 * SUB;
+    const bf16_t* xs = Xs + wk * 4 * SUB;
+    for (int t = tile_beg; t < tile_end; ++t) {
+        mfma_bf16x8 af[3][NT], bfr[3][MT];
+#pragma unroll
+        for (int p = 0; p < 3; ++p) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                const bf16x4 lo = lds_tr16_b64(ys + p * PL + i * SUB + p_lo);
+                const bf16x4 hi = lds_tr16_b64(ys + p * PL + i * SUB + p_hi);
+                bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                af[p][i] = __builtin_bit_cast(mfma_bf16x8, v);
+            }
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const bf16x4 lo = lds_tr16_b64(xs + p * PL + j * SUB + p_lo);
+                const bf16x4 hi = lds_tr16_b64(xs + p * PL + j * SUB + p_hi);
+                bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+                bfr[p][j] = __builtin_bit_cast(mfma_bf16x8, v);
+            }
+        }
+        __syncthreads();
+        auto mm = [&](int py, int px) {
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[py][i], bfr[px][j], acc[i][j], 0, 0, 0);
+        };
+        mm(2, 0); split_store(y_reg[0], Ys, lds_off(0)); split_store(x_reg[0], Xs, lds_off(0));
+        mm(0, 2); split_store(y_reg[1], Ys, lds_off(1)); split_store(x_reg[1], Xs, lds_off(1));
+        mm(1, 1); split_store(y_reg[2], Ys, lds_off(2)); split_store(x_reg[2], Xs, lds_off(2));
+        mm(1, 0); split_store(y_reg[3], Ys, lds_off(3)); split_store(x_reg[3], Xs, lds_off(3));
+        mm(0, 1);
+        mm(0, 0);
+#pragma unroll
+        for (int q = 0; q < 64; ++q) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+        }
+        load_tiles(t + 2);
+        __syncthreads();
+    }
+    // acc[i][j][q] = dw[n = n0 + wn*64 + i*16 + lq*4 + q][kc = kc0 + wk*64 + j*16 + lr]
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + i * 16 + lq * 4 + q;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int k = kc0 + wk * 64 + j * 16 + lr;
+                if (k < a.Ktot) {
+                    if (a.ws != nullptr)
+                        a.ws[((int64_t)split * a.N + n) * a.Ktot + k] = acc[i][j][q];
+                    else
+                        atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q]);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
 // bf16 weight gradient for N <= 64 output channels (layer1's 3x3 and 1x1 convolutions, the stem, the 48- and
 // 16-channel head convolutions): tile 64 (n) x 256 (kc), 4 waves side by side along kc (wave tile 64 x 64).  In the
 // 128 x 128 kernel half of every MFMA row block is padding for these layers and two of the four waves idle; here all
@@ -2002,6 +2361,20 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             return 0;
         }
     }
+    if constexpr (sizeof(T) == 4 && MODE != 2) {
+        if (a.f32_split && aligned && a.N > 32) {
+            static const int x3bn = getenv("DML_X3_BN") ? atoi(getenv("DML_X3_BN")) : 128;
+            if (a.N > 64 && x3bn != 64) {
+                a.nblk_n = (a.N + 127) / 128;
+                hipLaunchKernelGGL((conv_igemm_x3_kernel<128, MODE>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a);
+            } else {
+                a.nblk_n = (a.N + 63) / 64;
+                hipLaunchKernelGGL((conv_igemm_x3_kernel<64, MODE>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a);
+            }
+            DML_LAUNCH_CHECK();
+            return 0;
+        }
+    }
     if constexpr (MODE == 2) {
         return DML_EUNSUPPORTED;      // acc32: LDS-DMA kernels only (bf16, C % 32 == 0, N > 32)
     } else {
@@ -2051,7 +2424,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
-    a.acc32 = nullptr; a.acc32_ld = 0;
+    a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = (d->dtype == DML_F32 && d->f32_split) ? 1 : 0;
     if (d->acc32) {
         // fp32 staging of a gradient with several producers: the 16-byte-vector bf16 path of the data gradient only
         if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || d->accum || d->res_dz || d->bnr_partials) return DML_EINVAL;
@@ -2138,7 +2511,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
-    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.acc32 = nullptr; a.acc32_ld = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2278,6 +2651,8 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         hipLaunchKernelGGL(conv_wgrad_n64_kernel, grid, dim3(NTHREADS), 0, st, a);
     else if (d->dtype == DML_BF16)
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);
+    else if (d->f32_split)
+        hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(NTHREADS), 0, st, a);
     else
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
     if (use_ws) {

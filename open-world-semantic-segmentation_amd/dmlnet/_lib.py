@@ -40,7 +40,7 @@ class ConvDesc(C.Structure):
                 ("tail_counters_len", C.c_int32), ("tail_reserved", C.c_int32),
                 ("res_dz", C.c_void_p), ("res_mask", C.c_void_p), ("res_ld", C.c_int32), ("res_reserved", C.c_int32),
                 # fp32 staging of a gradient with several producers, rounded once by the last one (see the header)
-                ("acc32", C.c_void_p), ("acc32_ld", C.c_int32), ("acc32_reserved", C.c_int32)]
+                ("acc32", C.c_void_p), ("acc32_ld", C.c_int32), ("f32_split", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 22
@@ -63,7 +63,7 @@ class WgradDesc(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
                 ("pad", C.c_int32), ("dtype", C.c_int32), ("splitk", C.c_int32), ("Cm", C.c_int32),
-                ("ws", c_p), ("ws_elems", C.c_int64)]
+                ("ws", c_p), ("ws_elems", C.c_int64), ("f32_split", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PrepDesc(C.Structure):

@@ -322,6 +322,9 @@ class Plan:
         self.last_dgrad = {}           # gradient buffer address -> ConvDesc of the data gradient that wrote it last
         self.res_src = {}              # id(block input) -> (dz of the block output, its ReLU mask): identity-branch gradient
         #                                that conv1's data gradient adds in its epilogue (DmlConvDesc.res_*)
+        # fp32 plans: products of the forward / data-gradient convolutions on the bf16 matrix cores through a three-term
+        # split of both operands (DmlConvDesc.f32_split; fp32-level error, not the exact fp32 MFMA): Engine.f32_split
+        self.f32_split = 1 if (engine.f32_split and dtype == torch.float32) else 0
         self.fuse_res_grad = os.environ.get("DML_FUSE_RES_GRAD", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
@@ -453,6 +456,7 @@ class Plan:
                        pre_shift=None, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
                        N=N or conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
                        y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
+        dsc.f32_split = self.f32_split
         if self.training:
             dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
             dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
@@ -473,6 +477,7 @@ class Plan:
                        pre_shift=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld, Ho=x.H, Wo=x.W, N=x.C,
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
                        accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
+        dsc.f32_split = self.f32_split
         g32 = x.g32 if x is x.root else None
         convert = False
         if g32 is not None and not (final and not x.root.grad_init):
@@ -522,7 +527,8 @@ class Plan:
         dsc = WgradDesc(x=x.ptr, dy=dy.ptr, dw=tmp.data_ptr() if tmp is not None else gptr, B=x.B, Hi=x.H, Wi=x.W, C=x.C,
                         ldx=x.ld, Ho=Ho, Wo=Wo,
                         N=Nw, ldy=dy.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, splitk=0,
-                        Cm=Cm, ws=self.wgrad_ws.data_ptr(), ws_elems=self.wgrad_ws.numel())
+                        Cm=Cm, ws=self.wgrad_ws.data_ptr(), ws_elems=self.wgrad_ws.numel(),
+                        f32_split=self.f32_split if self.dtype == torch.float32 else 0)
         self.keep.append(dsc)
         if tmp is None and self.group_wgrad and self.lib.dml_conv_wgrad_group_eligible(C.byref(dsc)):
             # joins the next grouped launch (dml_conv_wgrad_group): the weight gradients of a few consecutive layers
@@ -1189,6 +1195,8 @@ class Engine:
         self.overlap_wgrad = os.environ.get("DML_OVERLAP_WGRAD", "1") != "0"
         self.native = os.environ.get("DML_NATIVE_PLAN", "1") != "0"      # replay launch lists through dml_plan_run
         self.sync_bn, self.sync_group = False, None     # synchronised BatchNorm statistics over the process group
+        # fp32 compute dtype only: "bf16x3" products (model.set_compute_dtype(torch.float32, fp32_products="bf16x3"))
+        self.f32_split = os.environ.get("DML_F32_PRODUCTS", "exact").lower() == "bf16x3"
         self._side = {}
         self._branch = {}
         self.step_count = 0
@@ -1254,7 +1262,7 @@ class Engine:
             self.plans.clear()
             self._protos.clear()
         B, Cin, H, W = x.shape
-        key = (B, H, W, dtype, training, bool(self.sync_bn), self.bn_modes() if training else 0)
+        key = (B, H, W, dtype, training, bool(self.sync_bn), self.bn_modes() if training else 0, bool(self.f32_split))
         plan = self.plans.get(key)
         if plan is None:
             plan = self.plan_cls(self, B, H, W, dtype, training)

@@ -144,10 +144,18 @@ class DeepLabV3_embedding(nn.Module):
                 state_dict[k] = v.detach().clone(memory_format=torch.contiguous_format)
         return state_dict
 
-    def set_compute_dtype(self, dtype):
+    def set_compute_dtype(self, dtype, fp32_products=None):
+        """torch.float32: the reference's arithmetic (network/utils.py:84-118 computes in fp32) -- exact fp32 MFMAs by default;
+        `fp32_products="bf16x3"` keeps fp32 storage everywhere and computes the convolutions' products on the bf16 matrix
+        cores through a three-term split of both operands (fp32-level error, DmlConvDesc.f32_split).  torch.bfloat16: bf16
+        storage of activations / compute weights, fp32 accumulation (the throughput mode)."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be float32 or bfloat16")
+        if fp32_products not in (None, "exact", "bf16x3"):
+            raise ValueError("fp32_products must be 'exact' or 'bf16x3'")
         self.compute_dtype = dtype
+        if fp32_products is not None:
+            self._engine.f32_split = fp32_products == "bf16x3"
         return self
 
     def set_sync_batchnorm(self, enabled=True, group=None):

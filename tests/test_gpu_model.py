@@ -21,14 +21,14 @@ def relclose(got, ref, tol, what=""):
     assert err <= tol * scale, "%s: max|d|=%.3e scale=%.3e rel=%.3e > %.1e" % (what, err, scale, err / scale, tol)
 
 
-def build(dtype=torch.float32, train=True, seed=1, num_classes=16, output_stride=16):
+def build(dtype=torch.float32, train=True, seed=1, num_classes=16, output_stride=16, fp32_products=None):
     import network
     import utils
     m = network.deeplabv3plus_embedding_resnet101(num_classes=num_classes, output_stride=output_stride,
                                                   pretrained_backbone=False)
     m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=seed))
     m.cuda()
-    m.set_compute_dtype(dtype)
+    m.set_compute_dtype(dtype, fp32_products=fp32_products)
     if train:
         m.train()
         m.classifier.aspp.project[3].eval()          # F14: dropout off for parity
@@ -50,10 +50,13 @@ def g8_inputs():
     return img, lab
 
 
-def test_g5_full_train_step_matches_reference():
+@pytest.mark.parametrize("products", ["exact", "bf16x3"])
+def test_g5_full_train_step_matches_reference(products):
+    """fp32 compute dtype against the reference-minted fixture, with the exact fp32 MFMA and with the convolutions' products
+    on the bf16 matrix cores through the three-term split (same 1e-3 / 2e-3 bars: the split is fp32-accurate)."""
     import utils
     g = H.load_golden("g5_full_train")
-    m = build()
+    m = build(fp32_products=products)
     img, lab = g5_inputs()
     lg, ctr, ft = m(img)
     assert lg.shape == (2, 16, 64, 64) and ft.shape == (2, 64, 64, 16) and ctr.shape == (16, 16)
@@ -88,11 +91,12 @@ def test_g5_full_train_step_matches_reference():
     assert int(bufs["backbone.bn1.num_batches_tracked"]) == 1
 
 
-def test_g8_sgd_polylr_trajectory():
+@pytest.mark.parametrize("products", ["exact", "bf16x3"])
+def test_g8_sgd_polylr_trajectory(products):
     import utils
     from dmlnet.optim import FusedSGD
     t = H.load_golden("g8_trajectory")
-    m = build()
+    m = build(fp32_products=products)
     img, lab = g8_inputs()
     lr, total = float(t["lr"]), int(t["total_itrs"])
     opt = FusedSGD([{"params": m.backbone.parameters(), "lr": 0.1 * lr},
@@ -109,14 +113,19 @@ def test_g8_sgd_polylr_trajectory():
         sched.step()
         losses.append(loss.item())
     # the reference's own trajectory drifts with the CPU thread count (1 vs 8 threads: 1e-5 at step 1, 1.3e-3 at
-    # step 5: the dynamics are chaotic), so the bar widens with the step index
-    for it, (a, b, tol) in enumerate(zip(losses, t["losses"], (1e-5, 1e-4, 2e-4, 1e-3, 3e-3, 1e-2))):
+    # step 5: the dynamics are chaotic), so the bar widens with the
+    # step index; the split's rounding pattern differs from a sequential fp32 sum's (same size, test_conv_f32_three_term_split_
+    # is_fp32_accurate), and the same amplification takes it to 3.2e-3 at step 4: three times the late bars for it
+    bars = (1e-5, 1e-4, 2e-4, 1e-3, 3e-3, 1e-2) if products == "exact" else (1e-5, 1e-4, 6e-4, 3e-3, 1e-2, 3e-2)
+    print("g8 %s: relative loss differences" % products, ["%.1e" % (abs(a - b) / abs(b)) for a, b in zip(losses, t["losses"])])
+    for it, (a, b, tol) in enumerate(zip(losses, t["losses"], bars)):
         assert abs(a - b) <= tol * abs(b), "step %d: %.6f vs %.6f" % (it, a, b)
     assert np.allclose([g_["lr"] for g_ in opt.param_groups], t["lrs"][-1], rtol=1e-6)
     sd = m.state_dict()
-    relclose(sd["classifier.classifier.3.bias"], T(t["b_last"]), 5e-3, "final bias after 6 steps")
-    relclose(sd["backbone.conv1.weight"], T(t["w_stem"]), 2e-3, "stem weight after 6 steps")
-    relclose(sd["backbone.bn1.running_mean"], T(t["rm_stem"]), 2e-3, "stem running mean after 6 steps")
+    wide = 1.0 if products == "exact" else 3.0
+    relclose(sd["classifier.classifier.3.bias"], T(t["b_last"]), 5e-3 * wide, "final bias after 6 steps")
+    relclose(sd["backbone.conv1.weight"], T(t["w_stem"]), 2e-3 * wide, "stem weight after 6 steps")
+    relclose(sd["backbone.bn1.running_mean"], T(t["rm_stem"]), 2e-3 * wide, "stem running mean after 6 steps")
 
 
 def test_g5b_eval_forward_config1():

@@ -1167,3 +1167,58 @@ def test_dgrad_rounds_a_staged_gradient_once(lib, shape):
     assert lib.dml_conv_igemm(C.byref(d), st()) != 0
     d.accum, d.y_f32 = 0, 1
     assert lib.dml_conv_igemm(C.byref(d), st()) != 0
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[4] % 32 == 0], ids=[c[0] for c in CONV_CASES if c[4] % 32 == 0])
+def test_conv_f32_three_term_split_is_fp32_accurate(lib, case):
+    """DmlConvDesc.f32_split: fp32 tensors, products on the bf16 matrix cores through hi + mid + lo of both operands (six bf16
+    MFMAs per block).  Forward (with BN statistics) and data gradient against an fp64 torch convolution: the error must be at
+    the level of the EXACT fp32 kernel's (same launch with f32_split = 0), far below the 1e-3 parity bar -- while a plain bf16
+    rounding of the operands would sit at 4e-3."""
+    name, B, Hh, Ww, Cin, Cout, k, stride, dil = case
+    x = rnd(name + ".x", (B, Cin, Hh, Ww)).double().requires_grad_(True)
+    w = rnd(name + ".w", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5).double().requires_grad_(True)
+    y_ref, pad = conv_ref(x, w, k, stride, dil)
+    Ho, Wo = y_ref.shape[2:]
+    gy = rnd(name + ".gy", tuple(y_ref.shape)).double()
+    y_ref.backward(gy)
+    xd = nhwc(x.detach().float(), torch.float32)
+    wd = w.detach().float().permute(0, 2, 3, 1).contiguous().cuda()
+    wtd = w.detach().float().permute(1, 2, 3, 0).contiguous().cuda()
+    gyd = nhwc(gy.float(), torch.float32)
+    M = B * Ho * Wo
+    errs = {}
+    for split in (0, 1):
+        yd = torch.empty((B, Ho, Wo, Cout), device="cuda")
+        stats = torch.zeros((M + 63) // 64 * Cout * 2, device="cuda")
+        d = make_desc(lib, xd, wd, yd, B, Hh, Ww, Cin, Ho, Wo, Cout, k, stride, dil, pad, 0, stats=stats)
+        d.f32_split = split
+        chk(lib.dml_conv_igemm(C.byref(d), st()))
+        dxd = torch.empty((B, Hh, Ww, Cin), device="cuda")
+        dd = make_desc(lib, gyd, wtd, dxd, B, Ho, Wo, Cout, Hh, Ww, Cin, k, stride, dil, pad, 0, mode=1)
+        dd.f32_split = split
+        chk(lib.dml_conv_igemm(C.byref(dd), st()))
+        torch.cuda.synchronize()
+        ef = (nchw(yd).double() - y_ref.detach()).abs().max().item() / y_ref.detach().abs().max().item()
+        eg = (nchw(dxd).double() - x.grad).abs().max().item() / x.grad.abs().max().item()
+        # statistics partials: sum over each 64-row group of the fp32 accumulators
+        yflat = y_ref.detach().permute(0, 2, 3, 1).reshape(M, Cout)
+        g0 = yflat[:min(64, M)].sum(0)
+        es = (stats.view(-1, Cout, 2)[0, :, 0].double().cpu() - g0).abs().max().item() / (g0.abs().max().item() + 1e-30)
+        # weight gradient: atomics path and workspace (plain stores + fold) path
+        from dmlnet._lib import WgradDesc
+        ew = []
+        ws = torch.empty(6 * Cout * k * k * Cin, device="cuda")
+        for use_ws, sk in ((0, 0), (0, 3), (1, 4)):
+            dw = torch.zeros((Cout, k, k, Cin), device="cuda")
+            wg = WgradDesc(x=xd.data_ptr(), dy=gyd.data_ptr(), dw=dw.data_ptr(), B=B, Hi=Hh, Wi=Ww, C=Cin, ldx=Cin, Ho=Ho, Wo=Wo,
+                           N=Cout, ldy=Cout, R=k, S=k, stride=stride, dil=dil, pad=pad, dtype=0, splitk=sk, f32_split=split,
+                           ws=ws.data_ptr() if use_ws else None, ws_elems=ws.numel() if use_ws else 0)
+            chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+            torch.cuda.synchronize()
+            ew.append((dw.cpu().permute(0, 3, 1, 2).double() - w.grad).abs().max().item() / w.grad.abs().max().item())
+        errs[split] = (ef, eg, es, max(ew))
+    print("%s: fwd / dgrad / stats / wgrad error vs fp64: exact fp32 MFMA %.2e %.2e %.2e %.2e | three-term split %.2e %.2e %.2e %.2e"
+          % ((name,) + errs[0] + errs[1]))
+    for a_, b_ in zip(errs[1], errs[0]):
+        assert a_ <= max(4.0 * b_, 2e-6), errs
