@@ -841,23 +841,38 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
     u32x4_t a_reg[A_LD], b_reg[B_LD];
     int tap_r = 0, tap_s = 0, c0 = 0;
     const int KT = a.Ktot / BK;
-    auto load_tiles = [&](int kt) {          // kt >= KT: every lane out of range (zeros, no memory access) -- keeps the loop branch-free
-        const uint32_t tapbit = kt < KT ? 1u << ((tap_r * a.S + tap_s) & 31) : 0u;
-        const int soff = (MODE == 0 ? ((tap_r * a.dil) * a.Wi + tap_s * a.dil) * a.ldx
-                                    : -((((tap_r * a.dil) >> sh2) * a.Wi + ((tap_s * a.dil) >> sh2)) * a.ldx)) * ES + c0 * ES;
-#pragma unroll
-        for (int j = 0; j < A_LD; ++j) {
-            const uint32_t voff = (a_mask[j] & tapbit) ? (uint32_t)(a_base[j] + soff) : OOB;
-            a_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
-        }
-#pragma unroll
-        for (int j = 0; j < B_LD; ++j)
-            b_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(kt < KT ? b_base[j] : OOB), kt < KT ? kt * BK * ES : 0, 0);
+    // loads of K step kt (kt >= KT: every lane out of range -- zeros, no memory access: keeps the loop branch-free), in three
+    // parts so that each staging register can be refilled right after its split has been stored
+    uint32_t ld_tapbit = 0, ld_boff = 0;
+    int ld_soff = 0;
+    bool ld_valid = false;
+    auto tap_setup = [&](int kt) {
+        ld_valid = kt < KT;
+        ld_tapbit = ld_valid ? 1u << ((tap_r * a.S + tap_s) & 31) : 0u;
+        ld_soff = (MODE == 0 ? ((tap_r * a.dil) * a.Wi + tap_s * a.dil) * a.ldx
+                             : -((((tap_r * a.dil) >> sh2) * a.Wi + ((tap_s * a.dil) >> sh2)) * a.ldx)) * ES + c0 * ES;
+        ld_boff = ld_valid ? (uint32_t)(kt * BK * ES) : 0u;
         c0 += BK;
         if (c0 >= a.C) {
             c0 = 0;
             if (++tap_s == a.S) { tap_s = 0; ++tap_r; }
         }
+    };
+    auto load_a = [&](int j) {
+        if (j < A_LD) {
+            const uint32_t voff = (a_mask[j] & ld_tapbit) ? (uint32_t)(a_base[j] + ld_soff) : OOB;
+            a_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)voff, 0, 0);
+        }
+    };
+    auto load_b = [&](int j) {
+        if (j < B_LD) b_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)(ld_valid ? b_base[j] : OOB), (int)ld_boff, 0);
+    };
+    auto load_tiles = [&](int kt) {
+        tap_setup(kt);
+#pragma unroll
+        for (int j = 0; j < A_LD; ++j) load_a(j);
+#pragma unroll
+        for (int j = 0; j < B_LD; ++j) load_b(j);
     };
     // x -> (hi, mid, lo), four values at a time, packed as bf16 pairs; the 8-byte piece is half a 16-byte bf16 chunk
     auto split_store = [&](const u32x4_t v, bf16_t* plane0, int plane_elems, int off) {
@@ -936,19 +951,22 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
                 split_store(b_reg[j], smem + 3 * PA, PB, row * BK + swz_chunk<bf16_t>(b_rho<NT>(row), kvec >> 1) * 8 + (kvec & 1) * 4);
             }
         };
-        mm(2, 0); st_a(0); st_a(1);             // lo(w) * hi(x)
-        mm(1, 1); st_a(2); st_a(3);             // mid * mid
-        mm(1, 0); st_b(0); st_b(1);             // mid * hi
-        mm(0, 2); st_b(2); st_b(3);             // hi * lo
-        mm(0, 1);                               // hi * mid
-        load_tiles(kt + 2);                     // staging registers are free again: a whole K step of latency to land
-        mm(0, 0);                               // hi * hi
-        // pin the interleaving: one MFMA, then up to three VALU and one LDS write, for the four groups that have stores
+        // each staging register is refilled (K step kt + 2) as soon as its split has been stored: the load has the rest of
+        // this step and the next step's fragment reads to land
+        tap_setup(kt + 2);
+        mm(2, 0); st_a(0); st_a(1); load_a(0); load_a(1);             // lo(w) * hi(x)
+        mm(1, 1); st_a(2); st_a(3); load_a(2); load_a(3);             // mid * mid
+        mm(1, 0); st_b(0); st_b(1); load_b(0); load_b(1);             // mid * hi
+        mm(0, 2); st_b(2); st_b(3); load_b(2); load_b(3);             // hi * lo
+        mm(0, 1);                                                     // hi * mid
+        mm(0, 0);                                                     // hi * hi
+        // pin the interleaving: one MFMA, then up to three VALU and one LDS write, a global load every eighth
 #pragma unroll
         for (int q = 0; q < 16 * NT * MT / 4; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (q % (2 * NT) == 2 * NT - 1) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
         __syncthreads();
     }
@@ -1595,10 +1613,13 @@ __global__ __launch_bounds__(NTHREADS) void conv_wgrad_kernel(const WgradArgs a)
 // fragments come out of ds_read_b64_tr_b16 -- and six MFMA groups per K step.  One LDS buffer (51 KB), two barriers per
 // step, the next tile's split + store interleaved with the MFMAs, global loads a whole step ahead in registers.
 // ------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_x3_kernel(const WgradArgs a) {
+template <bool LIN>      // LIN: 1x1, stride 1, no padding -- pixel row m of x is output row m
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_x3_kernel(
+    const WgradArgs a, const uint32_t x_bytes, const uint32_t dy_bytes) {
     constexpr int TILE = 128, CV = TILE / 4, RPP = NTHREADS / CV, LD = BK / RPP;      // 32 float4 per row, 8 rows per pass, 4 loads
     constexpr int SUB = 528, PL = (TILE / 16) * SUB;                                   // bf16 elements per operand plane
     constexpr int MT = 4, NT = 4;
+    constexpr uint32_t OOB = 0x80000000u;
     __shared__ __attribute__((aligned(16))) bf16_t smem[6 * PL];
     bf16_t* const Ys = smem;                     // planes hi, mid, lo of dy
     bf16_t* const Xs = smem + 3 * PL;            // planes of x
@@ -1610,8 +1631,9 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
     const int split = logical / ntile, tile_id = logical - split * ntile;
     const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
     const int n0 = blk_n * TILE, kc0 = blk_k * TILE;
-    const float* __restrict__ X = static_cast<const float*>(a.x);
-    const float* __restrict__ DY = static_cast<const float*>(a.dy);
+    // out-of-range rows / columns / taps read through the descriptors' range check: zeros, no branch, no access
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy), 0, (int)dy_bytes, 0x00020000);
     const int vcol = tid % CV, prow = tid / CV;
     const int kc = kc0 + vcol * 4;
     const bool kc_ok = kc < a.Ktot;
@@ -1624,34 +1646,31 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
     const int tile_beg = split * a.slab_tiles;
     const int tiles_total = (a.M + BK - 1) / BK;
     const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
-    const bool lin1x1 = a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0;
 
-    uint4 y_reg[LD], x_reg[LD];
-    auto load_tiles = [&](int t) {
-#pragma unroll
-        for (int j = 0; j < LD; ++j) {
-            const int m = t * BK + prow + j * RPP;
-            uint4 yv = make_uint4(0, 0, 0, 0), xv = make_uint4(0, 0, 0, 0);
-            if (t < tile_end && m < a.M) {
-                if (yn_ok) yv = *reinterpret_cast<const uint4*>(DY + (int64_t)m * a.ldy + yn);
-                if (kc_ok && lin1x1) {
-                    xv = *reinterpret_cast<const uint4*>(X + (int64_t)m * a.ldx + xc);
-                } else if (kc_ok) {
-                    const uint32_t b = fdiv((uint32_t)m, a.div_howo);
-                    const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
-                    const uint32_t yo = fdiv(rem, a.div_wo);
-                    const uint32_t xo = rem - yo * (uint32_t)a.Wo;
-                    const int ys = (int)yo * a.stride + dyo, xs = (int)xo * a.stride + dxo;
-                    if ((unsigned)ys < (unsigned)a.Hi && (unsigned)xs < (unsigned)a.Wi)
-                        xv = *reinterpret_cast<const uint4*>(X + ((int64_t)((int)b * a.Hi + ys) * a.Wi + xs) * a.ldx + xc);
-                }
-            }
-            y_reg[j] = yv;
-            x_reg[j] = xv;
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t y_reg[LD], x_reg[LD];
+    auto load_row = [&](int t, int j) {
+        const int m = t * BK + prow + j * RPP;
+        const bool mv = t < tile_end && m < a.M;
+        uint32_t xo_b;
+        bool xv = mv && kc_ok;
+        if (LIN) {
+            xo_b = ((uint32_t)m * (uint32_t)a.ldx + (uint32_t)xc) * 4u;
+        } else {
+            const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+            const uint32_t yo = fdiv(rem, a.div_wo);
+            const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+            const int ys = (int)yo * a.stride + dyo, xs = (int)xo * a.stride + dxo;
+            xv = xv && (unsigned)ys < (unsigned)a.Hi && (unsigned)xs < (unsigned)a.Wi;
+            xo_b = ((uint32_t)(((int)b * a.Hi + ys) * a.Wi + xs) * (uint32_t)a.ldx + (uint32_t)xc) * 4u;
         }
+        const uint32_t yo_b = ((uint32_t)m * (uint32_t)a.ldy + (uint32_t)yn) * 4u;
+        y_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, (int)((mv && yn_ok) ? yo_b : OOB), 0, 0);
+        x_reg[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)(xv ? xo_b : OOB), 0, 0);
     };
-    auto split_store = [&](const uint4 v, bf16_t* plane0, int off) {
-        const float x[4] = {__uint_as_float(v.x), __uint_as_float(v.y), __uint_as_float(v.z), __uint_as_float(v.w)};
+    auto split_store = [&](const u32x4_t v, bf16_t* plane0, int off) {
+        const float x[4] = {__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
         uint32_t h[2], m[2], l[2];
 #pragma unroll
         for (int e = 0; e < 2; ++e) {
@@ -1678,14 +1697,16 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
     for (int i = 0; i < NT; ++i)
 #pragma unroll
         for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    load_tiles(tile_beg);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) load_row(tile_beg, j);
 #pragma unroll
     for (int j = 0; j < LD; ++j) {
         split_store(y_reg[j], Ys, lds_off(j));
         split_store(x_reg[j], Xs, lds_off(j));
     }
     __syncthreads();
-    load_tiles(tile_beg + 1);
+#pragma unroll
+    for (int j = 0; j < LD; ++j) load_row(tile_beg + 1, j);
     const int lr = lane & 15, lq = lane >> 4;
     const int p_lo = ((lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4)) * 16 + (lr & 3) * 4;
     const int p_hi = p_lo + 8 * 16;
@@ -1718,19 +1739,21 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
                 for (int j = 0; j < MT; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[py][i], bfr[px][j], acc[i][j], 0, 0, 0);
         };
-        mm(2, 0); split_store(y_reg[0], Ys, lds_off(0)); split_store(x_reg[0], Xs, lds_off(0));
-        mm(0, 2); split_store(y_reg[1], Ys, lds_off(1)); split_store(x_reg[1], Xs, lds_off(1));
-        mm(1, 1); split_store(y_reg[2], Ys, lds_off(2)); split_store(x_reg[2], Xs, lds_off(2));
-        mm(1, 0); split_store(y_reg[3], Ys, lds_off(3)); split_store(x_reg[3], Xs, lds_off(3));
+        // each staging register is refilled (tile t + 2) as soon as its split has been stored: the load has the rest of this
+        // step and the next step's fragment reads to land
+        mm(2, 0); split_store(y_reg[0], Ys, lds_off(0)); split_store(x_reg[0], Xs, lds_off(0)); load_row(t + 2, 0);
+        mm(0, 2); split_store(y_reg[1], Ys, lds_off(1)); split_store(x_reg[1], Xs, lds_off(1)); load_row(t + 2, 1);
+        mm(1, 1); split_store(y_reg[2], Ys, lds_off(2)); split_store(x_reg[2], Xs, lds_off(2)); load_row(t + 2, 2);
+        mm(1, 0); split_store(y_reg[3], Ys, lds_off(3)); split_store(x_reg[3], Xs, lds_off(3)); load_row(t + 2, 3);
         mm(0, 1);
         mm(0, 0);
 #pragma unroll
         for (int q = 0; q < 64; ++q) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-            __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, LIN ? 3 : 4, 0);
             __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+            if (q % 8 == 7) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-        load_tiles(t + 2);
         __syncthreads();
     }
     // acc[i][j][q] = dw[n = n0 + wn*64 + i*16 + lq*4 + q][kc = kc0 + wk*64 + j*16 + lr]
@@ -2647,13 +2670,19 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     a.slab_tiles = (tiles + splitk - 1) / splitk;
     splitk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
     dim3 grid(a.nblk_n * a.nblk_k * splitk);
+    // split-product kernel: operands through buffer descriptors (32-bit byte offsets)
+    const int64_t x3_xb = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 4, x3_yb = (((int64_t)a.M - 1) * a.ldy + a.N) * 4;
+    const bool x3_ok = x3_xb < (int64_t)0x7fffffff && x3_yb < (int64_t)0x7fffffff;
     if (n64)
         hipLaunchKernelGGL(conv_wgrad_n64_kernel, grid, dim3(NTHREADS), 0, st, a);
     else if (d->dtype == DML_BF16)
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);
-    else if (d->f32_split)
-        hipLaunchKernelGGL(conv_wgrad_x3_kernel, grid, dim3(NTHREADS), 0, st, a);
-    else
+    else if (d->f32_split && x3_ok) {
+        if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0)
+            hipLaunchKernelGGL(conv_wgrad_x3_kernel<true>, grid, dim3(NTHREADS), 0, st, a, (uint32_t)x3_xb, (uint32_t)x3_yb);
+        else
+            hipLaunchKernelGGL(conv_wgrad_x3_kernel<false>, grid, dim3(NTHREADS), 0, st, a, (uint32_t)x3_xb, (uint32_t)x3_yb);
+    } else
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
     if (use_ws) {
         const int64_t nrs = (int64_t)a.N * a.R * a.S;

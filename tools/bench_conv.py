@@ -88,6 +88,31 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         line += " | prologue %.0f (p90 %.0f) epilogue %.0f (p90 %.0f) loop %.0f cycles" % (
             full[:, 6].mean(), full[:, 6].quantile(0.9), full[:, 7].mean(), full[:, 7].quantile(0.9),
             ph.sum(1).mean() * (k * k * Cc // 32))
+    if which == "epi":
+        # data gradient of this conv (output = B x H x W x Cc) with the fused epilogue options of the train step
+        M_ = B * H * W
+        wt = (torch.randn(Cc, k, k, N, device="cuda") * 0.05).to(bf)
+        gx = torch.zeros(B, H, W, Cc, device="cuda", dtype=bf)
+        rdz = torch.randn(B, H, W, Cc, device="cuda").to(bf)
+        ypre = torch.randn(B, H, W, Cc, device="cuda").to(bf)
+        mask = torch.randint(0, 256, (M_ * Cc // 8,), dtype=torch.uint8, device="cuda")
+        mean, invstd = torch.randn(Cc, device="cuda") * 0.1, torch.rand(Cc, device="cuda") + 0.5
+        part = torch.empty((M_ + 63) // 64 * Cc * 2, device="cuda")
+        tws = torch.empty(512 * 128 * 128, device="cuda"); tcnt = torch.zeros(128, dtype=torch.int32, device="cuda")
+        fl_ = 2.0 * M_ * N * k * k * Cc
+        for nm, acc_, res_, bnr_ in (("plain", 0, 0, 0), ("accum", 1, 0, 0), ("res", 0, 1, 0), ("bnr", 0, 0, 1), ("res+bnr", 0, 1, 1)):
+            d = ConvDesc(x=dy.data_ptr(), w=wt.data_ptr(), y=gx.data_ptr(), bias=None, stats=None, pre_scale=None, pre_shift=None,
+                         B=B, Hi=H, Wi=W, C=N, ldx=N, Ho=H, Wo=W, N=Cc, ldy=Cc, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
+                         y_f32=0, accum=acc_, mode=1, pre_relu=0)
+            d.tail_ws, d.tail_ws_elems, d.tail_counters, d.tail_counters_len = tws.data_ptr(), tws.numel(), tcnt.data_ptr(), 128
+            if res_:
+                d.res_dz, d.res_mask, d.res_ld = rdz.data_ptr(), mask.data_ptr(), Cc
+            if bnr_:
+                d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ypre.data_ptr(), mask.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+                d.bnr_partials, d.bnr_ldy, d.bnr_relu = part.data_ptr(), Cc, 1
+            t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
+            by = 2.0 * M_ * (N + Cc * (1 + acc_ + res_ + bnr_)) + M_ * Cc / 8 * (res_ + bnr_)
+            line += "%s %.1fus %.0fTF %.2fTB/s | " % (nm, t * 1e6, fl_ / t / 1e12, by / t / 1e12)
     if which in ("all", "wgrad"):
         dw = torch.zeros(N, k, k, Cc, device="cuda")
         for sk in (0, 4, 8, 16, 32, 64):
