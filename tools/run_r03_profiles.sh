@@ -21,6 +21,9 @@ done
 DML_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/pf -- python3 $R/bench.py --dtype f32 --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $OUT/pf.log 2>&1
 find $OUT/pf -name "*kernel_stats.csv" -exec cp {} $OUT/fp32_kernel_stats_serial.csv \;
 rm -rf $OUT/pf
+DML_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/px -- python3 $R/bench.py --dtype f32x3 --steps 4 --warmup 2 --no-cpu-baseline --no-profile > $OUT/px.log 2>&1
+find $OUT/px -name "*kernel_stats.csv" -exec cp {} $OUT/fp32x3_kernel_stats_serial.csv \;
+rm -rf $OUT/px
 # kernel stats of the SAME short serial command the counter passes use (durations next to the SQ counters)
 DML_OVERLAP_WGRAD=0 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/ps -- python3 $B > $OUT/ps.log 2>&1
 find $OUT/ps -name "*kernel_stats.csv" -exec cp {} $OUT/kernel_stats_pmc_cmd.csv \;
