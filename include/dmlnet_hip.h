@@ -164,6 +164,9 @@ int dml_prep_weights(const DmlPrepDesc* descs_device, int count, int dtype, void
 int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int Cm, int Cp, void* stream);
 /* bias gradient: db[n] += sum_m dy[m][n]  (network/utils.py:23) */
 int dml_bias_grad(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, void* stream);
+/* the same as a fixed-order sum (bitwise reproducible): per-workgroup partial sums in ws (>= 1024 * N floats), then a fold.
+ * dml_bias_grad itself combines its workgroups with fp32 atomics. */
+int dml_bias_grad_ws(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, float* ws, int64_t ws_elems, void* stream);
 
 /* x[B,C,H,W] fp32 (the reference's input layout) -> NHWC with C padded to Cp, dtype. */
 int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int Cp, int dtype,

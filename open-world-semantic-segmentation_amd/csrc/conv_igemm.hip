@@ -2147,13 +2147,15 @@ __global__ __launch_bounds__(WB_THREADS) void conv_wgrad_group_kernel(const Wgra
     wgrad_big_body<DEPTH>(g.job[j], g.xb[j], g.yb[j], logical - g.start[j], smem);
 }
 
-// dw[n][rs][c < Cm] += sum_s ws[s][n][rs][c]   (fp32 atomics on the L2 are ~10x more expensive per byte than this)
-// blockIdx.y walks chunks of 16 splits so that a small weight tensor with hundreds of splits stays parallel.
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ ws, float* __restrict__ dw,
-                                                           int splits, int64_t NRS, int Cm, int Cp) {
+// dw[n][rs][c < Cm] += sum_s ws[s * slab_stride][n][rs][c]   (fp32 atomics on the L2 are ~10x more expensive per byte than this)
+// A small weight tensor with hundreds of splits stays parallel AND deterministic in two launches: with fold_only, blockIdx.y
+// walks chunks of 16 splits and leaves each chunk's sum in the chunk's first slab (every thread reads and writes only its own
+// element); the second launch then adds the chunk sums (slab_stride = 16) in order.
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(float* __restrict__ ws, float* __restrict__ dw, int splits, int64_t NRS,
+                                                           int Cm, int Cp, int slab_stride, int fold_only) {
     const int64_t total = NRS * Cm;
     const int64_t plane = NRS * Cp;
-    const int s0 = gridDim.y == 1 ? 0 : blockIdx.y * 16, s1 = gridDim.y == 1 ? splits : min(splits, s0 + 16);
+    const int s0 = fold_only ? blockIdx.y * 16 : 0, s1 = fold_only ? min(splits, s0 + 16) : splits;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
          i += (int64_t)gridDim.x * blockDim.x) {
         int64_t src = i;
@@ -2163,9 +2165,9 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         }
         float acc = 0.f;
         #pragma unroll 8
-        for (int sidx = s0; sidx < s1; ++sidx) acc += ws[sidx * plane + src];
-        if (gridDim.y == 1) dw[i] += acc;
-        else atomicAdd(dw + i, acc);
+        for (int sidx = s0; sidx < s1; ++sidx) acc += ws[(int64_t)sidx * slab_stride * plane + src];
+        if (fold_only) ws[(int64_t)s0 * plane + src] = acc;
+        else dw[i] += acc;
     }
 }
 
@@ -2576,8 +2578,11 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     if (cm > d->C) return DML_EINVAL;
     if (cm != d->C && !d->ws) return DML_EINVAL;      // dropping padded channels needs the workspace path
     const int64_t plane = (int64_t)a.N * a.Ktot;
-    // small weight tensors: the reduce pass would be latency-bound and atomic contention is low -> atomics
-    const bool use_ws = d->ws != nullptr && (plane >= 65536 || cm != d->C);
+    // With a workspace every weight gradient is a fixed-order sum of slabs: the train step is bitwise reproducible.  (Small
+    // weight tensors -- below 64 K elements -- used to take fp32 atomics instead, the reduce pass being latency-bound there;
+    // DML_WGRAD_ATOMICS=1 restores that.)  Without a workspace: atomics.
+    static const bool small_atomics = getenv("DML_WGRAD_ATOMICS") && atoi(getenv("DML_WGRAD_ATOMICS")) != 0;
+    const bool use_ws = d->ws != nullptr && (!small_atomics || plane >= 65536 || cm != d->C);
     int splitk = d->splitk;
     if (splitk <= 0) {
         const int base = a.nblk_n * a.nblk_k;
@@ -2643,7 +2648,7 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
             hipLaunchKernelGGL(conv_wgrad_big_kernel<1>, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), 1), dim3(256), 0, st, d->ws, d->dw, sk, nrs,
-                           cm, d->C);
+                           cm, d->C, 1, 0);
         DML_LAUNCH_CHECK();
         return 0;
     }
@@ -2686,10 +2691,17 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         hipLaunchKernelGGL(conv_wgrad_kernel<float>, grid, dim3(NTHREADS), 0, st, a);
     if (use_ws) {
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
-        // chunk the splits over blockIdx.y (atomic combine) only for small tensors with very many splits (stem)
+        // small tensors with very many splits: fold chunks of 16 splits first (two launches, see wgrad_reduce_kernel)
         const int ychunks = (nrs * cm < 65536 && splitk > 64) ? (splitk + 15) / 16 : 1;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), ychunks), dim3(256), 0, st, d->ws, d->dw,
-                           splitk, nrs, cm, d->C);
+        if (ychunks > 1) {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), ychunks), dim3(256), 0, st, d->ws, d->dw, splitk,
+                               nrs, cm, d->C, 1, 1);
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256)), dim3(256), 0, st, d->ws, d->dw, ychunks, nrs, cm,
+                               d->C, 16, 0);
+        } else {
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256)), dim3(256), 0, st, d->ws, d->dw, splitk, nrs, cm,
+                               d->C, 1, 0);
+        }
     }
     DML_LAUNCH_CHECK();
     return 0;

@@ -118,21 +118,40 @@ __global__ __launch_bounds__(256) void unpad_wgrad_kernel(const float* __restric
 // db[n] += sum_m dy[m][n]; one block per 64 rows-lanes x N columns
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t M,
-                                                        int N, int ldy) {
+                                                        int N, int ldy, float* __restrict__ part) {
     // thread -> column n = tid % N (N <= 256), row lane = tid / N
     const int n = threadIdx.x % N, rl = threadIdx.x / N, rt = blockDim.x / N;
     float acc = 0.f;
     if (rl < rt)
         for (int64_t m = (int64_t)blockIdx.x * rt + rl; m < M; m += (int64_t)gridDim.x * rt)
             acc += Elem<T>::ld(dy + m * ldy + n);
-    if (rl < rt) atomicAdd(db + n, acc);
+    if (rl < rt) {
+        if (part != nullptr) part[((int64_t)blockIdx.x * rt + rl) * N + n] = acc;
+        else atomicAdd(db + n, acc);
+    }
+}
+
+// db[n] += sum_r part[r][n] in row order (second stage of the deterministic bias gradient)
+__global__ __launch_bounds__(256) void bias_grad_fold_kernel(const float* __restrict__ part, float* __restrict__ db, int rows, int N) {
+    __shared__ float sh[256];
+    const int n = threadIdx.x % N, rl = threadIdx.x / N, rt = 256 / N;
+    float acc = 0.f;
+    if (rl < rt)
+        for (int r = rl; r < rows; r += rt) acc += part[(int64_t)r * N + n];
+    sh[threadIdx.x] = acc;
+    __syncthreads();
+    if (threadIdx.x < N) {
+        float t = 0.f;
+        for (int r = 0; r < rt; ++r) t += sh[r * N + threadIdx.x];
+        db[threadIdx.x] += t;
+    }
 }
 
 // vector form: a thread owns one 16-byte channel vector and walks rows; row lanes are folded through LDS so that a
 // block issues one atomic per channel
 template <typename T>
 __global__ __launch_bounds__(256) void bias_grad_vec_kernel(const T* __restrict__ dy, float* __restrict__ db, int64_t M,
-                                                            int N, int ldy, int rows_per_block) {
+                                                            int N, int ldy, int rows_per_block, float* __restrict__ part) {
     constexpr int V = Vec16<T>::N;
     __shared__ float sh[256 * V];
     const int NV = N / V, rt = 256 / NV;
@@ -156,7 +175,8 @@ __global__ __launch_bounds__(256) void bias_grad_vec_kernel(const T* __restrict_
         const int c = threadIdx.x / V, q = threadIdx.x % V;
         float t = 0.f;
         for (int r = 0; r < rt; ++r) t += sh[(r * NV + c) * V + q];
-        atomicAdd(db + threadIdx.x, t);
+        if (part != nullptr) part[(int64_t)blockIdx.x * N + threadIdx.x] = t;
+        else atomicAdd(db + threadIdx.x, t);
     }
 }
 
@@ -247,30 +267,48 @@ extern "C" int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int 
     return 0;
 }
 
-extern "C" int dml_bias_grad(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, void* stream) {
+// ws == nullptr: one launch, fp32 atomics across workgroups (order-dependent in the last bit).  With a workspace of at least
+// 1024 * N floats: partial sums per workgroup, then a fixed-order fold -- deterministic.
+static int bias_grad_impl(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, float* ws, int64_t ws_elems,
+                          void* stream) {
     if (!dy || !db || M <= 0 || N <= 0 || N > 256) return DML_EINVAL;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const int V = dtype == DML_BF16 ? 8 : 4;
     if (N % V == 0 && ldy % V == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0) {
         const int64_t rpb = (M + 1023) / 1024;
         const int grid = (int)((M + rpb - 1) / rpb);
+        if (ws != nullptr && (int64_t)grid * N > ws_elems) return DML_EINVAL;
         if (dtype == DML_BF16)
             hipLaunchKernelGGL(bias_grad_vec_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, db, M, N, ldy,
-                               (int)rpb);
+                               (int)rpb, ws);
         else
             hipLaunchKernelGGL(bias_grad_vec_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, db, M, N, ldy,
-                               (int)rpb);
+                               (int)rpb, ws);
+        if (ws != nullptr) hipLaunchKernelGGL(bias_grad_fold_kernel, dim3(1), dim3(256), 0, st, ws, db, grid, N);
         DML_LAUNCH_CHECK();
         return 0;
     }
     const int rt = 256 / N;
-    const int grid = grid_for((M + rt - 1) / rt, 1, 512);
+    int grid = grid_for((M + rt - 1) / rt, 1, 512);
+    if (ws != nullptr && (int64_t)grid * rt * N > ws_elems) grid = (int)(ws_elems / ((int64_t)rt * N));
+    if (grid < 1) return DML_EINVAL;
     if (dtype == DML_BF16)
-        hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, db, M, N, ldy);
+        hipLaunchKernelGGL(bias_grad_kernel<bf16_t>, dim3(grid), dim3(256), 0, st, (const bf16_t*)dy, db, M, N, ldy, ws);
     else
-        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, db, M, N, ldy);
+        hipLaunchKernelGGL(bias_grad_kernel<float>, dim3(grid), dim3(256), 0, st, (const float*)dy, db, M, N, ldy, ws);
+    if (ws != nullptr) hipLaunchKernelGGL(bias_grad_fold_kernel, dim3(1), dim3(256), 0, st, ws, db, grid * rt, N);
     DML_LAUNCH_CHECK();
     return 0;
+}
+
+extern "C" int dml_bias_grad(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, void* stream) {
+    return bias_grad_impl(dy, db, M, N, ldy, dtype, nullptr, 0, stream);
+}
+
+extern "C" int dml_bias_grad_ws(const void* dy, float* db, int64_t M, int N, int ldy, int dtype, float* ws, int64_t ws_elems,
+                                void* stream) {
+    if (!ws || ws_elems < (int64_t)N) return DML_EINVAL;
+    return bias_grad_impl(dy, db, M, N, ldy, dtype, ws, ws_elems, stream);
 }
 
 extern "C" int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int Cp, int dtype,

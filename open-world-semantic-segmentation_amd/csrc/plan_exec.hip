@@ -63,6 +63,7 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_prep_weights),
     DML_ENTRY(dml_unpad_wgrad),
     DML_ENTRY(dml_bias_grad),
+    DML_ENTRY(dml_bias_grad_ws),
     DML_ENTRY(dml_pack_input),
     DML_ENTRY(dml_bn_finalize),
     DML_ENTRY(dml_bn_moments),

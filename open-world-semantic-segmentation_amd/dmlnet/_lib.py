@@ -85,6 +85,7 @@ _PROTOS = {
     "dml_prep_weights": (c_i, [c_p, c_i, c_i, c_p]),
     "dml_unpad_wgrad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dml_bias_grad": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
+    "dml_bias_grad_ws": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_p]),
     "dml_pack_input": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_moments": (c_i, [c_p, c_i64, c_i, c_p, c_p]),

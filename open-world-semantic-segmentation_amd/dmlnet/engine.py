@@ -946,12 +946,15 @@ class Plan:
         self.call(self.bwd, lib.dml_bilinear_bwd, df.data_ptr(), de.ptr, B, emb.H, emb.W, H, W, Kp, Kp, Kp, self.dt, 1, 0)
         rec.unfused_range = (i1, i1 + 2)
         if fin.bias is not None:
+            bws = self.fbuf(1024 * Kp)          # per-workgroup partial sums: a fixed-order (reproducible) bias gradient
             if Kp == K:
-                self.call(self.bwd, lib.dml_bias_grad, de.ptr, st.grad_ptr_of(fin.bias), de.M, K, de.ld, self.dt)
+                self.call(self.bwd, lib.dml_bias_grad_ws, de.ptr, st.grad_ptr_of(fin.bias), de.M, K, de.ld, self.dt,
+                          bws.data_ptr(), bws.numel())
             else:
                 gb = self.fbuf(Kp)
                 self.call(self.bwd, lib.dml_fill_f32, gb.data_ptr(), Kp, 0.0)
-                self.call(self.bwd, lib.dml_bias_grad, de.ptr, gb.data_ptr(), de.M, Kp, de.ld, self.dt)
+                self.call(self.bwd, lib.dml_bias_grad_ws, de.ptr, gb.data_ptr(), de.M, Kp, de.ld, self.dt, bws.data_ptr(),
+                          bws.numel())
                 self.call(self.bwd, lib.dml_unpad_wgrad, gb.data_ptr(), st.grad_ptr_of(fin.bias), 1, 1, K, Kp)
             self.mark_grad(fin.bias)
         self.conv_wgrad(ucls.z, de, fin, 256, pad_rows=Kp)

@@ -91,6 +91,37 @@ def test_g5_full_train_step_matches_reference(products):
     assert int(bufs["backbone.bn1.num_batches_tracked"]) == 1
 
 
+@pytest.mark.parametrize("dtype", [torch.float32, torch.bfloat16], ids=["f32", "bf16"])
+def test_train_steps_are_bitwise_reproducible(dtype):
+    """Three SGD steps twice from the same state: every parameter, buffer and loss must come out bit for bit the same -- all
+    reductions of the step (weight-gradient slabs, K-split tails, BN partials, bias gradient, loss) are fixed-order sums, no
+    floating-point atomics.  (The 30-step equivalence gate and the trajectory fixtures rely on it: the dynamics amplify a
+    last-bit difference to 1e-2 within 20 steps.)"""
+    import utils
+    from dmlnet.optim import FusedSGD
+    img = H.synth_tensor(11, "rep.img", (4, 3, 96, 128)).cuda()
+    lab = H.synth_labels(11, "rep.lab", (4, 96, 128), 16, 255, ignore_rows=3).cuda()
+    runs = []
+    for rep in range(2):
+        m = build(dtype=dtype, seed=3)
+        opt = FusedSGD([{"params": m.backbone.parameters(), "lr": 0.01}, {"params": m.classifier.parameters(), "lr": 0.1}],
+                       lr=0.1, momentum=0.9, weight_decay=1e-4).bind(m)
+        crit = utils.CrossEntropyLoss(ignore_index=255)
+        losses = []
+        for it in range(3):
+            opt.zero_grad()
+            lg, _, ft = m(img)
+            loss = crit(lg, lab, ft)
+            loss.backward()
+            opt.step()
+            losses.append(loss.item())
+        torch.cuda.synchronize()
+        runs.append((losses, {k: v.detach().clone() for k, v in m.state_dict().items()}))
+    assert runs[0][0] == runs[1][0], (runs[0][0], runs[1][0])
+    diff = [k for k, v in runs[0][1].items() if not torch.equal(v, runs[1][1][k])]
+    assert not diff, "%d of %d tensors differ between two identical runs, e.g. %s" % (len(diff), len(runs[0][1]), diff[:5])
+
+
 @pytest.mark.parametrize("products", ["exact", "bf16x3"])
 def test_g8_sgd_polylr_trajectory(products):
     import utils

@@ -730,15 +730,28 @@ def test_sgd_matches_torch(lib):
     relclose(pd.cpu(), p_ref.detach(), 1e-6, "sgd params")
 
 
-def test_bias_grad(lib):
-    M, N = 1000, 16
-    dy = rnd("bg", (M, N))
+@pytest.mark.parametrize("M,N", [(1000, 16), (70001, 16), (5003, 12)])
+def test_bias_grad(lib, M, N):
+    """atomics form and the workspace form (per-workgroup partials + fixed-order fold: bitwise reproducible); vector and scalar
+    kernels (N = 12 is not a multiple of the 16-byte vector)"""
+    dy = rnd("bg%d" % M, (M, N))
     for dt, tdt in ((0, torch.float32), (1, torch.bfloat16)):
         d = dy.to("cuda", tdt)
         db = torch.ones(N, device="cuda")
         chk(lib.dml_bias_grad(d.data_ptr(), db.data_ptr(), M, N, N, dt, st()))
         torch.cuda.synchronize()
         relclose(db.cpu(), 1 + qz(dy, tdt).sum(0), 1e-4, "bias grad")
+        ws = torch.empty(1024 * N, device="cuda")
+        outs = []
+        for _ in range(3):
+            db = torch.ones(N, device="cuda")
+            ws.fill_(float("nan"))
+            chk(lib.dml_bias_grad_ws(d.data_ptr(), db.data_ptr(), M, N, N, dt, ws.data_ptr(), ws.numel(), st()))
+            torch.cuda.synchronize()
+            outs.append(db.cpu())
+        relclose(outs[0], 1 + qz(dy, tdt).sum(0), 1e-4, "bias grad (workspace)")
+        assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    assert lib.dml_bias_grad_ws(d.data_ptr(), db.data_ptr(), M, N, N, dt, None, 0, st()) != 0
 
 
 def test_rejects_bad_arguments(lib):
