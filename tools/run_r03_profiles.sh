@@ -54,3 +54,7 @@ rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/wr -- pyth
 python3 $R/tools/traffic_dist_summary.py $OUT/rd $OUT/wr $SHA > $OUT/traffic_dist_pmc.json 2> $OUT/traffic_dist.err
 rm -rf $OUT/rd $OUT/wr
 ls -la $OUT
+# the bench line again with this run's PMC summaries in place (bench.py quotes `traffic` only from files whose csrc_sha matches)
+cp $OUT/traffic_pmc.json $R/profiles/r03_traffic_pmc.json; cp $OUT/fp32_traffic_pmc.json $R/profiles/r03_fp32_traffic_pmc.json
+cp $OUT/traffic_dist_pmc.json $R/profiles/r03_traffic_dist_pmc.json
+python3 $R/bench.py --dump-conv $OUT/conv_table_final.json > $OUT/bench_final.json 2> $OUT/bench_final.err
