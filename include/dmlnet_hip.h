@@ -116,6 +116,11 @@ typedef struct DmlConvDesc {
      * 0 = the exact fp32 MFMA, the reference's arithmetic (network/utils.py:84-118 computes in fp32).  Shapes the split kernel
      * does not take (C % 32 != 0, N <= 32) run exact either way. */
     int32_t f32_split;
+    /* 1 = `w` is the tile-major copy dml_prep_weights writes (DmlPrepDesc.w_tiled: [N / 64][K / 32][64][32], K = R * S * C): the
+     * weight half of every LDS-DMA instruction is one contiguous KB (whole 128-byte lines) instead of sixteen 64-byte row
+     * segments.  bf16, C % 32 == 0, N % 64 == 0, LDS-DMA kernels only: DML_EUNSUPPORTED otherwise (never a silent re-layout). */
+    int32_t w_tiled;
+    int32_t reserved0;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
@@ -158,6 +163,10 @@ typedef struct DmlPrepDesc {
     void* w;              /* [N][RS][Cp] */
     void* wt;             /* [Cp][RS][N] or NULL */
     int32_t N, RS, Cm, Cp;
+    /* tile-major copies for the LDS-DMA kernels (DmlConvDesc.w_tiled): the matrix [rows][K] (w: rows = N, K = RS * Cp; wt: rows =
+     * Cp, K = RS * N) is stored as [rows / 64][K / 32][64][32], so that the 16 filter rows x 64 bytes one DMA instruction
+     * fetches per K step are ONE contiguous KB.  Requires rows % 64 == 0 and K % 32 == 0 (w: Cp % 32 == 0; wt: N % 32 == 0). */
+    int32_t w_tiled, wt_tiled;
 } DmlPrepDesc;
 int dml_prep_weights(const DmlPrepDesc* descs_device, int count, int dtype, void* stream);
 /* dst[N][RS][Cm] += src[N][RS][Cp] (drops the padding channels of a padded weight gradient). */

@@ -37,6 +37,7 @@ struct ConvArgs {
     FastDiv div_wo, div_howo, div_c;
     float* dbg;      // tuning builds only (ABL == 3): per-wave phase timings
     uint32_t x_bytes, w_bytes;   // operand extents for the buffer descriptors (fast path: both < 2^31)
+    int w_tiled;                 // weights in the tile-major layout (DmlConvDesc::w_tiled): LDS-DMA kernels only
     // data-gradient mode: BN-backward partial sums of the tensor being written (DmlConvDesc::bnr_*)
     const void* bnr_y;
     const uint8_t* bnr_mask;
@@ -1076,8 +1077,12 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
     for (int jj = 0; jj < B_I; ++jj) {
         const int row = (wave * B_I + jj) * 16 + prow, n = n0 + row;
         const int bchunk = swz_chunk<T>(b_rho<NT>(row), lane & 3);      // weight rows: swizzle keyed on the MFMA row
-        b_off[jj] = n < a.N ? (uint32_t)(((int64_t)n * a.Ktot + bchunk * 8) * 2) : OOB;
+        // tile-major weights [N / 64][K / 32][64][32]: the instruction's 16 rows x 64 bytes are one contiguous KB
+        b_off[jj] = n >= a.N ? OOB
+                    : a.w_tiled ? (uint32_t)(((int64_t)(n >> 6) * (a.Ktot / BK) * 2048 + (n & 63) * 32 + bchunk * 8) * 2)
+                                : (uint32_t)(((int64_t)n * a.Ktot + bchunk * 8) * 2);
     }
+    const uint32_t b_kstep = a.w_tiled ? 64u * BK * 2u : BK * 2u;       // bytes from one K step of a weight row to the next
 
     const int KTall = a.Ktot / BK;
     const int kbeg = (int)((int64_t)kpart * KTall / kparts), kend = (int)((int64_t)(kpart + 1) * KTall / kparts);
@@ -1100,7 +1105,7 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
         }
 #pragma unroll
         for (int jj = 0; jj < B_I; ++jj) {    // OOB + K offset stays past the descriptor's range (tensors < 2^31 bytes)
-            const uint32_t voff = b_off[jj] + (uint32_t)(kt * BK * 2);
+            const uint32_t voff = b_off[jj] + (uint32_t)kt * b_kstep;
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * BK + (wave * B_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
         }
         ic0 += BK;
@@ -2345,7 +2350,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // other two's K loops, and a static tile list loses the dispatcher's load balancing.
             const int persist_kt = g_persist_kt < 0 ? (g_persist_kt = getenv("DML_CONV_PERSIST") ? atoi(getenv("DML_CONV_PERSIST")) : 0)
                                                     : g_persist_kt;
-            if (MODE != 2 && persist_kt > 0 && a.tail_q == 1 && !narrow && a.Ktot / BK >= 2 && a.Ktot / BK <= persist_kt) {
+            if (MODE != 2 && persist_kt > 0 && !a.w_tiled && a.tail_q == 1 && !narrow && a.Ktot / BK >= 2 && a.Ktot / BK <= persist_kt) {
                 constexpr int SLOTS = 768;                      // three workgroups per CU
                 const bool wide = a.N > 64;
                 a.nblk_n = wide ? (a.N + 127) / 128 : (a.N + 63) / 64;
@@ -2386,6 +2391,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             return 0;
         }
     }
+    if (a.w_tiled) return DML_EUNSUPPORTED;      // tile-major weights: only the LDS-DMA kernels above read them
     if constexpr (sizeof(T) == 4 && MODE != 2) {
         if (a.f32_split && aligned && a.N > 32) {
             static const int x3bn = getenv("DML_X3_BN") ? atoi(getenv("DML_X3_BN")) : 128;
@@ -2450,6 +2456,11 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
     a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = (d->dtype == DML_F32 && d->f32_split) ? 1 : 0;
+    a.w_tiled = 0;
+    if (d->w_tiled) {
+        if (d->dtype != DML_BF16 || d->C % BK || d->N % 64) return DML_EUNSUPPORTED;
+        a.w_tiled = 1;
+    }
     if (d->acc32) {
         // fp32 staging of a gradient with several producers: the 16-byte-vector bf16 path of the data gradient only
         if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || d->accum || d->res_dz || d->bnr_partials) return DML_EINVAL;
@@ -2537,6 +2548,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = 0;
+    a.w_tiled = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -75,6 +75,20 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const DmlPrepDesc* __
     T* __restrict__ w = static_cast<T*>(d.w);
     T* __restrict__ wt = static_cast<T*>(d.wt);
     const int N = d.N, RS = d.RS, Cm = d.Cm, Cp = d.Cp;
+    // tile-major copies (DmlPrepDesc::w_tiled / wt_tiled): matrix [rows][K] as [rows / 64][K / 32][64][32]; a 32 x 32 tile of
+    // this loop (32-aligned in both directions) is 1024 consecutive elements there as well
+    const bool wtl = d.w_tiled != 0, wttl = d.wt_tiled != 0;
+    const int64_t KTw = (int64_t)RS * Cp / 32, KTt = (int64_t)RS * N / 32;
+    auto idx_w = [&](int n, int rs, int c) -> int64_t {
+        if (!wtl) return ((int64_t)n * RS + rs) * Cp + c;
+        const int64_t k = (int64_t)rs * Cp + c;
+        return ((int64_t)(n >> 6) * KTw + (k >> 5)) * 2048 + (n & 63) * 32 + (k & 31);
+    };
+    auto idx_wt = [&](int c, int rs, int n) -> int64_t {
+        if (!wttl) return ((int64_t)c * RS + rs) * N + n;
+        const int64_t k = (int64_t)rs * N + n;
+        return ((int64_t)(c >> 6) * KTt + (k >> 5)) * 2048 + (c & 63) * 32 + (k & 31);
+    };
     const int tn = (N + 31) / 32, tc = (Cp + 31) / 32;
     const int ntiles = tn * tc * RS;
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;      // 32 x 8
@@ -88,7 +102,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const DmlPrepDesc* __
             float v = 0.f;
             if (n < N && c < Cp) {
                 if (c < Cm) v = src[((int64_t)n * RS + rs) * Cm + c];
-                Elem<T>::st(w + ((int64_t)n * RS + rs) * Cp + c, v);
+                Elem<T>::st(w + idx_w(n, rs, c), v);
             }
             tile[ty + j * 8][tx] = v;
         }
@@ -97,7 +111,7 @@ __global__ __launch_bounds__(256) void prep_weights_kernel(const DmlPrepDesc* __
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
                 const int c = c0 + ty + j * 8, n = n0 + tx;
-                if (c < Cp && n < N) Elem<T>::st(wt + ((int64_t)c * RS + rs) * N + n, tile[tx][ty + j * 8]);
+                if (c < Cp && n < N) Elem<T>::st(wt + idx_wt(c, rs, n), tile[tx][ty + j * 8]);
             }
         }
         __syncthreads();

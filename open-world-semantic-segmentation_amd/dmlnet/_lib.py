@@ -40,7 +40,8 @@ class ConvDesc(C.Structure):
                 ("tail_counters_len", C.c_int32), ("tail_reserved", C.c_int32),
                 ("res_dz", C.c_void_p), ("res_mask", C.c_void_p), ("res_ld", C.c_int32), ("res_reserved", C.c_int32),
                 # fp32 staging of a gradient with several producers, rounded once by the last one (see the header)
-                ("acc32", C.c_void_p), ("acc32_ld", C.c_int32), ("f32_split", C.c_int32)]
+                ("acc32", C.c_void_p), ("acc32_ld", C.c_int32), ("f32_split", C.c_int32),
+                ("w_tiled", C.c_int32), ("reserved0", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 22
@@ -68,7 +69,7 @@ class WgradDesc(C.Structure):
 
 class PrepDesc(C.Structure):
     _fields_ = [("src", c_p), ("w", c_p), ("wt", c_p), ("N", C.c_int32), ("RS", C.c_int32), ("Cm", C.c_int32),
-                ("Cp", C.c_int32)]
+                ("Cp", C.c_int32), ("w_tiled", C.c_int32), ("wt_tiled", C.c_int32)]
 
 
 class AugSample(C.Structure):

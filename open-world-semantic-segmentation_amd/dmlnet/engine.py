@@ -335,6 +335,9 @@ class Plan:
         # per step (41.2 -> 42.0 ms).  The excess noise round 2 attributed to these roundings came from the bf16 rounding
         # of the image-pooling branch's B x C tensors (_head_fwd).
         self.stage32 = training and dtype == torch.bfloat16 and os.environ.get("DML_GRAD_STAGE32", "0") == "1"
+        # bf16 weight copies of the LDS-DMA layers in the tile-major layout (DmlPrepDesc.w_tiled): the weight half of every DMA
+        # instruction becomes one contiguous KB (whole cache lines) instead of sixteen 64-byte row segments.  DML_W_TILED=0: off
+        self.tiled_weights = os.environ.get("DML_W_TILED", "1") != "0" and os.environ.get("DML_CONV_V1") is None
         self.fork_branches = os.environ.get("DML_FORK_BRANCHES", "1") != "0"
         # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
         # of this network; backward: <= ~1100*N*2)
@@ -444,9 +447,15 @@ class Plan:
         kh, kw = conv.kernel_size
         w = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device)
         wt = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device) if need_wt else None
+        # tile-major copies for the LDS-DMA kernels (DmlConvDesc.w_tiled): bf16, the GEMM's K a multiple of 32 per filter tap and
+        # its row count a multiple of 64 -- the shapes those kernels take; conv_fwd / conv_dgrad pass the flag on
+        dma = self.tiled_weights and self.dtype == torch.bfloat16 and kh * kw <= 32
+        w.tiled = bool(dma and Cp % 32 == 0 and N % 64 == 0)
+        if wt is not None:
+            wt.tiled = bool(dma and N % 32 == 0 and Cp % 64 == 0)
         self.keep += [w, wt]
         self.prep.append((src_ptr or conv.weight.data_ptr(), w.data_ptr(), wt.data_ptr() if wt is not None else 0, N,
-                          kh * kw, Cm, Cp, self.dt))
+                          kh * kw, Cm, Cp, self.dt, 1 if w.tiled else 0, 1 if (wt is not None and wt.tiled) else 0))
         return w, wt
 
     def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None, post=None, N=None):
@@ -457,6 +466,7 @@ class Plan:
                        N=N or conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
                        y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
         dsc.f32_split = self.f32_split
+        dsc.w_tiled = 1 if getattr(w, "tiled", False) else 0
         if self.training:
             dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
             dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
@@ -478,6 +488,7 @@ class Plan:
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
                        accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
         dsc.f32_split = self.f32_split
+        dsc.w_tiled = 1 if getattr(wt, "tiled", False) else 0
         g32 = x.g32 if x is x.root else None
         convert = False
         if g32 is not None and not (final and not x.root.grad_init):
@@ -1022,8 +1033,8 @@ class Plan:
             for dt in sorted({e[7] for e in self.prep}):          # one table launch per storage type present in the plan
                 ent = [e for e in self.prep if e[7] == dt]
                 arr = (_lib.PrepDesc * len(ent))()
-                for i, (src, w, wt, N, RS, Cm, Cp, _) in enumerate(ent):
-                    arr[i] = _lib.PrepDesc(src, w, wt or None, N, RS, Cm, Cp)
+                for i, (src, w, wt, N, RS, Cm, Cp, _, w_tiled, wt_tiled) in enumerate(ent):
+                    arr[i] = _lib.PrepDesc(src, w, wt or None, N, RS, Cm, Cp, w_tiled, wt_tiled)
                 raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
                 self.prep_table.append((raw.to(self.device), len(ent), dt))
         for tab, n, dt in self.prep_table:

@@ -1235,3 +1235,69 @@ def test_conv_f32_three_term_split_is_fp32_accurate(lib, case):
           % ((name,) + errs[0] + errs[1]))
     for a_, b_ in zip(errs[1], errs[0]):
         assert a_ <= max(4.0 * b_, 2e-6), errs
+
+
+def _tile_major(mat):
+    """[rows][K] -> [rows / 64][K / 32][64][32] (DmlPrepDesc.w_tiled)"""
+    rows, K = mat.shape
+    return mat.reshape(rows // 64, 64, K // 32, 32).permute(0, 2, 1, 3).contiguous()
+
+
+@pytest.mark.parametrize("case", [("t1x1", 2, 24, 20, 64, 128, 1, 1, 1), ("t1x1_n64", 3, 17, 13, 256, 64, 1, 1, 1),
+                                  ("t3x3", 2, 19, 23, 64, 192, 3, 1, 1), ("t3x3_d2", 2, 16, 16, 128, 256, 3, 1, 2),
+                                  ("t3x3_s2", 2, 22, 18, 128, 128, 3, 2, 1), ("t_rows256", 4, 40, 40, 256, 256, 3, 1, 1)],
+                         ids=lambda c: c[0])
+def test_tile_major_weights_are_bit_identical(lib, case):
+    """DmlPrepDesc.w_tiled / wt_tiled + DmlConvDesc.w_tiled: dml_prep_weights writes the tile-major copies ([rows / 64][K / 32]
+    [64][32]); forward (with BN statistics) and data gradient through the LDS-DMA kernels must equal the plain layout bit for
+    bit (same products, same order; only the addresses of the weight tile's DMA change).  Kernels without the layout refuse."""
+    from dmlnet._lib import PrepDesc, ConvDesc
+    name, B, Hh, Ww, Cin, Cout, k, stride, dil = case
+    bf = torch.bfloat16
+    master = rnd(name + ".w", (Cout, k, k, Cin), scale=(2.0 / (Cin * k * k)) ** 0.5).cuda().contiguous()
+    RS = k * k
+    bufs = {}
+    for tiled in (0, 1):
+        w = torch.empty(Cout * RS * Cin, device="cuda", dtype=bf)
+        wt = torch.empty(Cout * RS * Cin, device="cuda", dtype=bf)
+        arr = (PrepDesc * 1)(PrepDesc(master.data_ptr(), w.data_ptr(), wt.data_ptr(), Cout, RS, Cin, Cin, tiled, tiled))
+        tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+        chk(lib.dml_prep_weights(tab.data_ptr(), 1, 1, st()))
+        torch.cuda.synchronize()
+        bufs[tiled] = (w, wt)
+    # the layout itself
+    w_plain = bufs[0][0].view(Cout, RS * Cin)
+    wt_plain = bufs[0][1].view(Cin, RS * Cout)
+    assert torch.equal(bufs[1][0].view(-1), _tile_major(w_plain).view(-1))
+    assert torch.equal(bufs[1][1].view(-1), _tile_major(wt_plain).view(-1))
+    x = nhwc(rnd(name + ".x", (B, Cin, Hh, Ww)), bf)
+    pad = dil * (k // 2)
+    Ho, Wo = (Hh + 2 * pad - dil * (k - 1) - 1) // stride + 1, (Ww + 2 * pad - dil * (k - 1) - 1) // stride + 1
+    M = B * Ho * Wo
+    gy = nhwc(rnd(name + ".gy", (B, Cout, Ho, Wo)), bf)
+    tws = torch.empty(512 * 128 * 128, device="cuda")
+    tcnt = torch.zeros(128, dtype=torch.int32, device="cuda")
+    outs = {}
+    for tiled in (0, 1):
+        y = torch.empty((B, Ho, Wo, Cout), device="cuda", dtype=bf)
+        stats = torch.zeros((M + 63) // 64 * Cout * 2, device="cuda")
+        d = make_desc(lib, x, bufs[tiled][0], y, B, Hh, Ww, Cin, Ho, Wo, Cout, k, stride, dil, pad, 1, stats=stats)
+        d.w_tiled = tiled
+        d.tail_ws, d.tail_ws_elems, d.tail_counters, d.tail_counters_len = tws.data_ptr(), tws.numel(), tcnt.data_ptr(), 128
+        chk(lib.dml_conv_igemm(C.byref(d), st()))
+        dx = torch.empty((B, Hh, Ww, Cin), device="cuda", dtype=bf)
+        dd = make_desc(lib, gy, bufs[tiled][1], dx, B, Ho, Wo, Cout, Hh, Ww, Cin, k, stride, dil, pad, 1, mode=1)
+        dd.w_tiled = tiled
+        dd.tail_ws, dd.tail_ws_elems, dd.tail_counters, dd.tail_counters_len = tws.data_ptr(), tws.numel(), tcnt.data_ptr(), 128
+        chk(lib.dml_conv_igemm(C.byref(dd), st()))
+        torch.cuda.synchronize()
+        outs[tiled] = (y, stats, dx)
+    for a_, b_, what in zip(outs[0], outs[1], ("forward", "statistics", "data gradient")):
+        assert torch.equal(a_, b_), "%s: %s differs with tile-major weights" % (name, what)
+    # refused where no LDS-DMA kernel would read the layout: fp32, C % 32 != 0, N % 64 != 0
+    bad = make_desc(lib, x.float(), master, torch.empty((B, Ho, Wo, Cout), device="cuda"), B, Hh, Ww, Cin, Ho, Wo, Cout, k, stride,
+                    dil, pad, 0)
+    bad.w_tiled = 1
+    assert lib.dml_conv_igemm(C.byref(bad), st()) != 0
+    d.N = Cout - 16
+    assert lib.dml_conv_igemm(C.byref(d), st()) != 0

@@ -48,6 +48,52 @@ __device__ __forceinline__ void dma_body(const char* src, int row_bytes, int row
     if (acc == 123.456f) sink[0] = acc;
 }
 
+// Mixed stage of 16 KB: 128 rows x 64-byte segments (the activation tile as it is) + 8 KB read as ONE contiguous run (a weight
+// tile pre-arranged tile-major: every 1 KB instruction covers eight whole 128-byte lines).  CONTIG_A: both halves contiguous.
+template <int NST, bool CONTIG_A>
+__device__ __forceinline__ void dma_mixed_body(const char* src, int row_bytes, int rows_total, int steps, float* sink) {
+    constexpr int STAGE = 16384, NI = 2;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * STAGE];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rows_total * row_bytes, 0x00020000);
+    const int row0 = (blockIdx.x * 256) % (rows_total - 256 + 1);
+    const int segs_per_row = row_bytes / 64;
+    uint32_t base_a[NI], base_b[NI];
+#pragma unroll
+    for (int j = 0; j < NI; ++j) {
+        const int r = (wave * NI + j) * 16 + lane / 4;
+        base_a[j] = CONTIG_A ? (uint32_t)(row0 * row_bytes + (wave * NI + j) * 1024 + lane * 16)
+                             : (uint32_t)((row0 + r) * row_bytes + (lane % 4) * 16);
+        base_b[j] = (uint32_t)((row0 + 128) * row_bytes + (wave * NI + j) * 1024 + lane * 16);      // 128 rows x row_bytes region, linear
+    }
+#define ISSUE_M(s_, stage_)                                                                                                \
+    do {                                                                                                               \
+        const uint32_t ka = CONTIG_A ? (uint32_t)(((s_) % segs_per_row) * 8192) : (uint32_t)(((s_) % segs_per_row) * 64); \
+        const uint32_t kb = (uint32_t)(((s_) % segs_per_row) * 8192);                                                  \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                       \
+            rs, (lds_ptr_t)(smem + (stage_) * STAGE + (wave * NI + j) * 1024), 16, base_a[j] + ka, 0, 0, 0);             \
+        _Pragma("unroll") for (int j = 0; j < NI; ++j) __builtin_amdgcn_raw_ptr_buffer_load_lds(                       \
+            rs, (lds_ptr_t)(smem + (stage_) * STAGE + 8192 + (wave * NI + j) * 1024), 16, base_b[j] + kb, 0, 0, 0);      \
+    } while (0)
+    constexpr int LA = NST - 1;
+#pragma unroll
+    for (int t = 0; t < LA; ++t) ISSUE_M(t, t);
+    float acc = 0.f;
+    for (int s = 0; s < steps; ++s) {
+        if (s + LA - 1 < steps) wait_vmcnt<(LA - 1) * 2 * NI>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s + LA < steps) ISSUE_M(s + LA, (s + LA) % NST);
+        acc += reinterpret_cast<const float*>(smem + (s % NST) * STAGE)[tid];
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+__global__ __launch_bounds__(256) void k_mixed(const char* src, int rb, int rows, int steps, float* sink) {
+    dma_mixed_body<3, false>(src, rb, rows, steps, sink);
+}
+__global__ __launch_bounds__(256) void k_contig(const char* src, int rb, int rows, int steps, float* sink) {
+    dma_mixed_body<3, true>(src, rb, rows, steps, sink);
+}
+
 #define KERNEL(SEG, ROWS, NST)                                                                                            \
     __global__ __launch_bounds__(256) void k_##SEG##_##ROWS##_##NST(const char* src, int rb, int rows, int steps, float* sink) { \
         dma_body<SEG, ROWS, NST>(src, rb, rows, steps, sink);                                                             \
@@ -80,5 +126,9 @@ int main(int argc, char** argv) {
                run(k_256_64_3, 256, 64, src, row_bytes, rows, w, total / 16, sink), run(k_64_512_2, 64, 512, src, row_bytes, rows, w, total / 32, sink),
                run(k_128_256_2, 128, 256, src, row_bytes, rows, w, total / 32, sink), run(k_256_128_2, 256, 128, src, row_bytes, rows, w, total / 32, sink));
     }
+    printf("16 KB x3 stages, half of it (the weight tile) as one contiguous run | both halves contiguous\n");
+    for (int w = 1; w <= 3; ++w)
+        printf("%d WG/CU | 8 KB of 64 B rows + 8 KB contiguous %.1f | 16 KB contiguous %.1f\n", w,
+               run(k_mixed, 64, 256, src, row_bytes, rows, w, 1024, sink), run(k_contig, 64, 256, src, row_bytes, rows, w, 1024, sink));
     return 0;
 }
