@@ -151,7 +151,7 @@ __device__ __forceinline__ void st16f(float* p, float a, float b, float c, float
 // shared epilogue: BN partial statistics, bias, accumulate, fp32 / storage-dtype stores
 // acc[i][j][e] = out[m = mw0 + j*16 + (lane&15)][n = nw0 + frag_chan<NT>(i, lane>>4) + e]
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT, int MT, int MODE>
+template <typename T, int NT, int MT, int MODE, bool WIDE_MASK = true>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int mw0, const int nw0,
                                               const int lr, const int lq) {
     constexpr int TM = MT * 16;
@@ -246,6 +246,27 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
             const bool resm = MODE == 1 && a.res_dz != nullptr;
             constexpr bool a32 = MODE == 2;      // its own instantiation: the hot MODE 1 kernels keep their register budget
             const bool post = MODE == 0 && a.post_scale != nullptr;
+            // ReLU-mask bits of the wave's whole 64 x 64 tile in ONE instruction per mask: lane L fetches row L's 64 bits (8
+            // bytes), and lane (lr, lq) later takes byte 4 g + lq of row 16 j + lr through a lane permute -- instead of one
+            // byte-load instruction per (j, g), each of which costs the texture addresser as much as a 1 KB load
+            // (profiles/r03_epi_pmc.txt).  Wave tiles of 64 channels inside N only; the others load bytes.
+            // (WIDE_MASK = false: the 256-row tile's kernel, at its 256-register limit, keeps the byte loads)
+            const bool wide_mask = WIDE_MASK && MODE == 1 && NT == 4 && MT == 4 && (a.N & 63) == 0 && nw0 + 64 <= a.N;
+            uint32_t rm_lo = 0xffffffffu, rm_hi = 0xffffffffu, bm_lo = 0xffffffffu, bm_hi = 0xffffffffu;
+            if (MODE == 1 && wide_mask) {
+                const int mrow = mw0 + lq * 16 + lr;              // lane L = lq * 16 + lr holds row L of the tile
+                if (mrow < a.M) {
+                    const int64_t mo = (int64_t)mrow * (a.N >> 3) + (nw0 >> 3);
+                    if (resm) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(a.res_mask + mo);
+                        rm_lo = v.x; rm_hi = v.y;
+                    }
+                    if (bnr && a.bnr_relu) {
+                        const uint2 v = *reinterpret_cast<const uint2*>(a.bnr_mask + mo);
+                        bm_lo = v.x; bm_hi = v.y;
+                    }
+                }
+            }
 #pragma unroll
             for (int g = 0; g < CL / 8; ++g) {
                 const int n8 = ch(g * 8);
@@ -283,7 +304,7 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         if (resm) {
                             told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.res_dz) +
                                                                       (int64_t)m * a.res_ld + n8);
-                            rbits[j] = a.res_mask[(int64_t)m * (a.N >> 3) + (n8 >> 3)];
+                            if (!wide_mask) rbits[j] = a.res_mask[(int64_t)m * (a.N >> 3) + (n8 >> 3)];
                         }
                         if (post && a.post_res != nullptr)
                             told[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.post_res) +
@@ -298,8 +319,17 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
                         if (bnr) {
                             ty[j] = *reinterpret_cast<const uint4*>(static_cast<const bf16_t*>(a.bnr_y) +
                                                                     (int64_t)m * a.bnr_ldy + n8);
-                            if (a.bnr_relu) bits[j] = a.bnr_mask[(int64_t)m * (a.N >> 3) + (n8 >> 3)];
+                            if (a.bnr_relu && !wide_mask) bits[j] = a.bnr_mask[(int64_t)m * (a.N >> 3) + (n8 >> 3)];
                         }
+                    }
+                }
+                if (MODE == 1 && wide_mask) {
+                    // (executed by every lane: the permute reads another lane's register)
+#pragma unroll
+                    for (int j = 0; j < MT; ++j) {
+                        const int src = j * 16 + lr;
+                        if (resm) rbits[j] = ((uint32_t)__shfl((int)(g == 0 ? rm_lo : rm_hi), src) >> (lq * 8)) & 0xffu;
+                        if (bnr && a.bnr_relu) bits[j] = ((uint32_t)__shfl((int)(g == 0 ? bm_lo : bm_hi), src) >> (lq * 8)) & 0xffu;
                     }
                 }
 #pragma unroll
@@ -1212,7 +1242,7 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < 4; ++j) sub[i][j] = acc[i][h * 4 + j];
-            conv_epilogue<T, NT, 4, MODE>(sub, a, m0 + wm * TM + h * 64, n0 + wn * TN, lr, lq);
+            conv_epilogue<T, NT, 4, MODE, false>(sub, a, m0 + wm * TM + h * 64, n0 + wn * TN, lr, lq);
         }
     }
 }
@@ -2475,6 +2505,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
         if (d->N % 8 || d->ldy % 8 || d->res_ld % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
             (reinterpret_cast<uintptr_t>(d->res_dz) & 15) || d->N <= 32)
             return DML_EALIGN;
+        if ((d->N & 63) == 0 && (reinterpret_cast<uintptr_t>(d->res_mask) & 7)) return DML_EALIGN;      // 8-byte mask rows
         a.res_dz = d->res_dz; a.res_mask = d->res_mask; a.res_ld = d->res_ld;
     }
     if (d->tail_ws && d->tail_counters && d->tail_ws_elems > 0 && d->tail_counters_len > 0) {
@@ -2496,6 +2527,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
         if (d->N % 8 || d->ldy % 8 || d->bnr_ldy % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
             (reinterpret_cast<uintptr_t>(d->bnr_y) & 15) || (reinterpret_cast<uintptr_t>(d->bnr_partials) & 15) || d->N <= 32)
             return DML_EUNSUPPORTED;
+        if (d->bnr_relu && (d->N & 63) == 0 && (reinterpret_cast<uintptr_t>(d->bnr_mask) & 7)) return DML_EALIGN;
         a.bnr_y = d->bnr_y; a.bnr_mask = d->bnr_mask; a.bnr_mean = d->bnr_mean; a.bnr_invstd = d->bnr_invstd;
         a.bnr_partials = d->bnr_partials; a.bnr_ldy = d->bnr_ldy; a.bnr_relu = d->bnr_relu;
     }
