@@ -94,6 +94,44 @@ __global__ __launch_bounds__(256) void k_contig(const char* src, int rb, int row
     dma_mixed_body<3, true>(src, rb, rows, steps, sink);
 }
 
+// Asymmetric ring in the same 48 KB: the activation tile as UNITS of two K steps (128 rows x 128 bytes = 16 KB, whole lines,
+// two units), the weight tile per K step (8 KB contiguous, two slots, issued ONE step ahead).  Per step 16 KB as before.
+__global__ __launch_bounds__(256) void k_asym(const char* src, int row_bytes, int rows_total, int steps, float* sink) {
+    __shared__ __attribute__((aligned(1024))) char smem[2 * 16384 + 2 * 8192];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)src, 0, rows_total * row_bytes, 0x00020000);
+    const int row0 = (blockIdx.x * 256) % (rows_total - 256 + 1);
+    const int units_per_row = row_bytes / 128, segs_per_row = row_bytes / 64;
+    uint32_t base_a[4], base_b[2];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) base_a[j] = (uint32_t)((row0 + (wave * 4 + j) * 8 + lane / 8) * row_bytes + (lane % 8) * 16);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) base_b[j] = (uint32_t)((row0 + 128) * row_bytes + (wave * 2 + j) * 1024 + lane * 16);
+    auto issue_a = [&](int u) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + (u & 1) * 16384 + (wave * 4 + j) * 1024), 16,
+                                                     base_a[j] + (uint32_t)((u % units_per_row) * 128), 0, 0, 0);
+    };
+    auto issue_b = [&](int s) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(smem + 32768 + (s & 1) * 8192 + (wave * 2 + j) * 1024), 16,
+                                                     base_b[j] + (uint32_t)((s % segs_per_row) * 8192), 0, 0, 0);
+    };
+    issue_a(0); issue_b(0);
+    float acc = 0.f;
+    for (int s = 0; s < steps; ++s) {
+        // outstanding, oldest first: [A unit s/2 + B(s) needed now] ... at odd s the A unit issued last step stays in flight
+        if (s & 1) wait_vmcnt<4>(); else wait_vmcnt<0>();
+        __builtin_amdgcn_s_barrier();
+        if (s + 1 < steps) issue_b(s + 1);
+        if (!(s & 1) && s + 2 < steps) issue_a(s / 2 + 1);
+        acc += reinterpret_cast<const float*>(smem + ((s >> 1) & 1) * 16384)[tid] + reinterpret_cast<const float*>(smem + 32768 + (s & 1) * 8192)[tid];
+    }
+    if (acc == 123.456f) sink[0] = acc;
+}
+
 #define KERNEL(SEG, ROWS, NST)                                                                                            \
     __global__ __launch_bounds__(256) void k_##SEG##_##ROWS##_##NST(const char* src, int rb, int rows, int steps, float* sink) { \
         dma_body<SEG, ROWS, NST>(src, rb, rows, steps, sink);                                                             \
@@ -130,5 +168,7 @@ int main(int argc, char** argv) {
     for (int w = 1; w <= 3; ++w)
         printf("%d WG/CU | 8 KB of 64 B rows + 8 KB contiguous %.1f | 16 KB contiguous %.1f\n", w,
                run(k_mixed, 64, 256, src, row_bytes, rows, w, 1024, sink), run(k_contig, 64, 256, src, row_bytes, rows, w, 1024, sink));
+    printf("asymmetric ring: activation units of two K steps (16 KB of 128-byte rows, 2 units) + weight tile 8 KB contiguous per step (2 slots, one step ahead)\n");
+    for (int w = 1; w <= 3; ++w) printf("%d WG/CU | %.1f\n", w, run(k_asym, 64, 256, src, row_bytes, rows, w, 1024, sink));
     return 0;
 }
