@@ -12,7 +12,8 @@ m.set_compute_dtype(torch.bfloat16); m.train()
 opt = FusedSGD([{"params": m.backbone.parameters(), "lr": 0.001}, {"params": m.classifier.parameters(), "lr": 0.01}],
                lr=0.01, momentum=0.9, weight_decay=1e-4).bind(m)
 crit = utils.DMLLoss(alpha=0.01, ignore_index=255)
-img = torch.randn(2, 3, 128, 128, device=dev); lab = torch.randint(0, 16, (2, 128, 128), device=dev)
+B_, S_ = int(os.environ.get("D2D_BATCH", "2")), int(os.environ.get("D2D_SIZE", "128"))
+img = torch.randn(B_, 3, S_, S_, device=dev); lab = torch.randint(0, 16, (B_, S_, S_), device=dev)
 def step():
     opt.zero_grad(); lg, c, f = m(img); loss = crit(lg, lab, f); loss.backward(); opt.step()
 for _ in range(3): step()
