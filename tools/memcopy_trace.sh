@@ -1,3 +1,7 @@
+#!/bin/bash
+# GPU box: memory-copy + kernel trace of a short bench run (no counters).  Used to place the 1352 __amd_rocclr_copyBuffer
+# dispatches of a bench trace: they are the 2 x 676 slice copies of the parameter-store flattening at model setup (runs of
+# consecutive copies next to torch's elementwise kernels), none of them inside a train step.
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/memcopy
