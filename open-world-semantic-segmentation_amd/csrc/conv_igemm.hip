@@ -1024,7 +1024,8 @@ template <int N> __device__ __forceinline__ void wait_vmcnt() { asm volatile("s_
 // TMW = 128 (with BM = 256): 4 waves (2 x 2) on a 128 x 64 WAVE tile -- 32 MFMAs per wave and K step against 12 KB of
 // fragment reads (the 64 x 64 wave tile: 16 against 8 KB), half the barriers per FLOP; 128 accumulator registers, two
 // workgroups per CU = two waves per SIMD.
-template <int BN, int MODE, int NST, int WPE = 3, int BM = 128, int TMW = 64>
+// PH (tuning builds only, dml_debug_conv_ablate 5): s_memtime stamps around the phases of a K step, per-wave sums to a.dbg
+template <int BN, int MODE, int NST, int WPE = 3, int BM = 128, int TMW = 64, bool PH = false>
 __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(WPE))) void conv_igemm_dma_kernel(const ConvArgs a, const uint32_t x_bytes,
                                                                   const uint32_t w_bytes) {
     typedef bf16_t T;
@@ -1157,13 +1158,22 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
         if (t < KT) issue(kbeg + t, t);
 
     const int lr = lane & 15, lq = lane >> 4;
+    uint64_t ph_t[5] = {0, 0, 0, 0, 0}, ph_sum[4] = {0, 0, 0, 0}, ph_begin = 0;
+    auto stamp = [&](int i) {
+        if constexpr (PH) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_t[i])::"memory");
+    };
+    if constexpr (PH) asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_begin)::"memory");
     for (int kt = 0; kt < KT; ++kt) {
+        stamp(0);
         // tiles kt .. min(kt + LA - 1, KT - 1) are in flight; tile kt must have landed
         if (LA > 2 && kt + 2 < KT) wait_vmcnt<(LA > 2 ? 2 : 0) * NI>();
         else if (LA > 1 && kt + 1 < KT) wait_vmcnt<(LA > 1 ? 1 : 0) * NI>();
         else wait_vmcnt<0>();
+        stamp(1);
         __builtin_amdgcn_s_barrier();
+        stamp(2);
         if (kt + LA < KT) issue(kbeg + kt + LA, (kt + LA) % NST);
+        stamp(3);
         const T* as = smem + (kt % NST) * STAGE + (wm * TM) * BK;
         const T* bs = smem + (kt % NST) * STAGE + BM * BK + (wn * TN) * BK;
         mfma_bf16x8 bf[NT], af[MT];
@@ -1180,6 +1190,27 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
 #pragma unroll
             for (int j = 0; j < MT; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
+        if constexpr (PH) {
+            stamp(4);          // (after the MFMAs were ISSUED: the matrix pipe may still be working)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) ph_sum[q] += ph_t[q + 1] - ph_t[q];
+        }
+    }
+    if constexpr (PH) {
+        uint64_t ph_end;
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(ph_end)::"memory");
+        if (a.dbg != nullptr && lane == 0) {
+            float* o = a.dbg + ((int64_t)blockIdx.x * WAVES + wave) * 8;
+            const float inv = 1.0f / (float)(KT > 0 ? KT : 1);
+            o[0] = (float)ph_sum[0] * inv;      // vmcnt wait
+            o[1] = (float)ph_sum[1] * inv;      // barrier
+            o[2] = (float)ph_sum[2] * inv;      // DMA issue
+            o[3] = (float)ph_sum[3] * inv;      // fragment reads + MFMA issue
+            o[4] = (float)(ph_end - ph_begin) * inv;      // whole loop per step (includes the stamps themselves)
+            o[5] = (float)KT;
+            o[6] = 0.f;
+            o[7] = 0.f;
+        }
     }
     // Cut the accumulators' live ranges here: without it hipcc keeps the MFMA results un-tied through the
     // branchy epilogue and re-copies all 64 AGPRs (v_accvgpr_mov + s_nop) in EVERY K step (-35 % throughput).
@@ -2588,6 +2619,9 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     if (abl == 0) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 0>), grid, dim3(NTHREADS), 0, st, a);
     else if (abl == 1) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 1>), grid, dim3(NTHREADS), 0, st, a);
     else if (abl == 3) hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 3>), grid, dim3(NTHREADS), 0, st, a);
+    else if (abl == 5) {          // the LDS-DMA 128 x 128 kernel with phase stamps; dbg = 8 floats per wave
+        hipLaunchKernelGGL((conv_igemm_dma_kernel<128, 0, 3, 3, 128, 64, true>), grid, dim3(NTHREADS), 0, st, a, a.x_bytes, a.w_bytes);
+    }
     else if (abl == 4) {
         a.dbg = nullptr;
         a.bnr_mean = d->pre_scale; a.bnr_invstd = d->pre_shift;       // per INPUT channel: the probe's scale / shift

@@ -113,6 +113,23 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
             by = 2.0 * M_ * (N + Cc * (1 + acc_ + res_ + bnr_)) + M_ * Cc / 8 * (res_ + bnr_)
             line += "%s %.1fus %.0fTF %.2fTB/s | " % (nm, t * 1e6, fl_ / t / 1e12, by / t / 1e12)
+    if which == "dmaphases":
+        # cycles per K step of the LDS-DMA 128 x 128 kernel by phase (s_memtime stamps, dml_debug_conv_ablate 5)
+        import ctypes
+        lib.dml_debug_conv_ablate.restype = ctypes.c_int
+        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]
+        nblk = ((M + 127) // 128) * ((N + 127) // 128)
+        dbg = torch.zeros(nblk * 4 * 8, device="cuda")
+        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, pre_scale=dbg.data_ptr(),
+                     pre_shift=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil,
+                     pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
+        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), int(os.environ.get("DMAPH_ABL", "5")), st))
+        torch.cuda.synchronize()
+        full = dbg.view(nblk * 4, 8).cpu()
+        names = ("vmcnt-wait", "barrier", "dma-issue", "frag-read+mfma-issue")
+        line += "%d tiles, %.1f us (with stamps); s_memtime ticks per K step, mean over %d waves: " % (nblk, t * 1e6, full.shape[0])
+        line += ", ".join("%s %.0f" % (n, v) for n, v in zip(names, full[:, :4].mean(0).tolist()))
+        line += " | whole step %.0f (p10 %.0f, p90 %.0f)" % (full[:, 4].mean(), full[:, 4].quantile(0.1), full[:, 4].quantile(0.9))
     if which in ("all", "wgrad"):
         dw = torch.zeros(N, k, k, Cc, device="cuda")
         for sk in (0, 4, 8, 16, 32, 64):
