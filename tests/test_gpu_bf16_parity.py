@@ -21,13 +21,13 @@ import helpers as H
 pytestmark = pytest.mark.gpu
 
 
-def _build_hip(dtype, seed, train=True):
+def _build_hip(dtype, seed, train=True, fp32_products=None):
     import network
     import utils
     m = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
     m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=seed))
     m.cuda()
-    m.set_compute_dtype(dtype)
+    m.set_compute_dtype(dtype, fp32_products=fp32_products)
     if train:
         m.train()
         m.classifier.aspp.project[3].eval()
@@ -305,15 +305,17 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed, stage32, monkeypatch
     assert n_acc32 == (5 if stage32 else 0), n_acc32       # d(out) + the four blocks with a downsample branch (low = layer2.0's)
 
 
-def test_fp32_768_bs2_against_oracle():
-    """fp32 mode at the benchmark's crop size against the fp32 oracle: logits / loss at 1e-3, every gradient checksum"""
+@pytest.mark.parametrize("products", ["exact", "bf16x3"])
+def test_fp32_768_bs2_against_oracle(products):
+    """fp32 mode at the benchmark's crop size against the fp32 oracle: logits / loss at 1e-3, every gradient checksum -- with the
+    exact fp32 MFMA and with the convolutions' products on the bf16 matrix cores (three-term split), same bars"""
     import utils
     from oracle import dmlnet_ref as O
     torch.set_num_threads(min(64, torch.get_num_threads() or 8))
     shape, seed = (2, 3, 768, 768), 77
     img = H.synth_tensor(seed, "bf16.768.img", shape)
     lab = H.synth_labels(seed, "bf16.768.lab", (2, 768, 768), 16, 255, ignore_frac=0.05)
-    m = _build_hip(torch.float32, seed)
+    m = _build_hip(torch.float32, seed, fp32_products=products)
     lg, _, ft = m(img.cuda())
     loss = utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab.cuda(), ft)
     loss.backward()
@@ -330,8 +332,8 @@ def test_fp32_768_bs2_against_oracle():
         a, b = H.checksum(p.grad), H.checksum(q.grad)
         if not np.allclose(a[1:], b[1:], rtol=5e-3):
             cs_bad.append((k, a, b))
-    print("fp32.768: logits %.2e features %.2e loss %.2e | grads max-norm median %.2e p95 %.2e max %.2e (%s); "
-          "checksum mismatches %d" % (e_lg, e_ft, e_loss, np.median(emax), np.percentile(emax, 95), emax.max(),
+    print("fp32.768 (%s): logits %.2e features %.2e loss %.2e | grads max-norm median %.2e p95 %.2e max %.2e (%s); "
+          "checksum mismatches %d" % (products, e_lg, e_ft, e_loss, np.median(emax), np.percentile(emax, 95), emax.max(),
                                        names[int(np.argmax(emax))], len(cs_bad)))
     assert e_lg <= 1e-3 and e_ft <= 1e-3 and e_loss <= 1e-3
     # 1.2 M pixels per image pair: fp32 summation order alone moves single gradient entries by a few 1e-3 of the tensor's
