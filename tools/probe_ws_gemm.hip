@@ -76,9 +76,84 @@ __device__ __forceinline__ void lds_st(uint32_t* p, uint32_t v) {
     __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
 }
 
+// one loader wave: pieces p = q * NLD + LW of every stage (compile-time ownership: no branches in the issue loop)
+template <int MT, int MW, int NW, int NST, int NLD, int D, int LW, int ABL>
+__device__ __forceinline__ void ws_loader(const Args& a, char* smem, uint32_t* ready, uint32_t* consumed, const int lane,
+                                          const int ntiles, const int KT) {
+    constexpr int NCW = MW * NW;
+    constexpr int BM = 16 * MT * MW, BN = 64 * NW;
+    constexpr int PA = BM / 16, PB = BN / 16, NP = PA + PB;
+    constexpr int SB = (BM + BN) * 64;
+    constexpr int MYP = (NP - LW + NLD - 1) / NLD;            // pieces of this wave per stage
+    constexpr uint32_t OOB = 0x80000000u;
+    const u32x4_t rs_a = make_rsrc(a.A, a.a_bytes), rs_b = make_rsrc(a.Bt, a.b_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
+    uint32_t g = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const int mt = tile % a.ntiles_m, nt = tile / a.ntiles_m;
+        const int m0 = mt * BM, n0 = nt * BN;
+        int arow[MYP];
+        uint32_t off[MYP];           // A pieces: byte offset of (row, chunk) at shift 0, c0 0; B pieces: byte offset at K step 0
+#pragma unroll
+        for (int q = 0; q < MYP; ++q) {
+            const int p = q * NLD + LW;
+            if (p < PA) {
+                arow[q] = m0 + p * 16 + prow;
+                off[q] = (uint32_t)((arow[q] * a.C + lchunk * 8) * 2);
+            } else {
+                const int row = (p - PA) * 16 + prow, n = n0 + row;
+                const int bchunk = swz(b_rho(row), lane & 3);
+                arow[q] = 0;
+                off[q] = n < a.N ? (uint32_t)((((int64_t)(n >> 6) * KT) * 2048 + (n & 63) * 32 + bchunk * 8) * 2) : OOB;
+            }
+        }
+        int tap = 0, c0 = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (g >= (uint32_t)NST) {
+                const uint32_t need = g - NST + 1;
+                for (;;) {
+                    uint32_t mn = lds_ld(consumed);
+#pragma unroll
+                    for (int w = 1; w < NCW; ++w) mn = min(mn, lds_ld(consumed + w));
+                    if (mn >= need) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+            const uint32_t sbase = lds0 + (g % NST) * SB;
+            const int shift = a.taps == 1 ? 0 : ((tap / 3) - 1) * a.W + (tap % 3) - 1;
+            const uint32_t soff_a = (uint32_t)((shift * a.C + c0) * 2);
+            if (ABL != 2) {
+#pragma unroll
+                for (int q = 0; q < MYP; ++q) {
+                    const int p = q * NLD + LW;
+                    if (p < PA) {
+                        const uint32_t voff = ((unsigned)(arow[q] + shift) < (unsigned)a.M) ? off[q] + soff_a : OOB;
+                        dma16(rs_a, sbase + p * 1024, voff, 0u);
+                    } else {
+                        dma16(rs_b, sbase + p * 1024, off[q], (uint32_t)kt * 4096u);
+                    }
+                }
+            }
+            c0 += 32;
+            if (c0 >= a.C) { c0 = 0; ++tap; }
+            ++g;
+            if (g > (uint32_t)D) {
+                wait_vmcnt<D * MYP>();
+                lds_st(ready + LW, g - D);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    lds_st(ready + LW, g);
+}
+
 // MT: 16-row fragments per wave tile (wave tile = 16 MT x 64); MW x NW consumer waves; NST ring stages of one 32-deep K step;
 // NLD loader waves, each keeps D stages in flight behind the one it publishes
-template <int MT, int MW, int NW, int NST, int NLD, int D>
+// ABL (ablations): 1 = consumers issue no MFMA, 2 = loaders issue no DMA (consumers run on whatever LDS holds)
+template <int MT, int MW, int NW, int NST, int NLD, int D, int ABL = 0>
 __global__ __launch_bounds__((MW * NW + NLD) * 64) void ws_gemm_kernel(const Args a) {
     constexpr int NCW = MW * NW;
     constexpr int BM = 16 * MT * MW, BN = 64 * NW;
@@ -99,72 +174,11 @@ __global__ __launch_bounds__((MW * NW + NLD) * 64) void ws_gemm_kernel(const Arg
     const int cpt = a.C / 32, KT = a.taps * cpt;
 
     if (wave >= NCW) {
-        // ------------------------------------------------------------------ loader
         const int lw = wave - NCW;
-        constexpr int MAXP = (NP + NLD - 1) / NLD;
-        const u32x4_t rs_a = make_rsrc(a.A, a.a_bytes), rs_b = make_rsrc(a.Bt, a.b_bytes);
-        const uint32_t lds0 = (uint32_t)(uintptr_t)smem;          // LDS byte address of the ring (low 32 bits of the generic pointer)
-        const int prow = lane >> 2;
-        const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
-        uint32_t g = 0;
-        for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-            const int mt = tile % a.ntiles_m, nt = tile / a.ntiles_m;
-            const int m0 = mt * BM, n0 = nt * BN;
-            int arow[MAXP];              // A pieces: row index of this lane; B pieces: unused
-            uint32_t boff[MAXP];         // B pieces: byte offset of this lane at K step 0
-#pragma unroll
-            for (int q = 0; q < MAXP; ++q) {
-                const int p = q * NLD + lw;
-                arow[q] = 0;
-                boff[q] = OOB;
-                if (p < PA) {
-                    arow[q] = m0 + p * 16 + prow;
-                } else if (p < NP) {
-                    const int row = (p - PA) * 16 + prow, n = n0 + row;
-                    const int bchunk = swz(b_rho(row), lane & 3);
-                    boff[q] = n < a.N ? (uint32_t)((((int64_t)(n >> 6) * KT) * 2048 + (n & 63) * 32 + bchunk * 8) * 2) : OOB;
-                }
-            }
-            int tap = 0, c0 = 0;
-            for (int kt = 0; kt < KT; ++kt) {
-                if (g >= (uint32_t)NST) {
-                    // the stage this K step overwrites must have been read by every consumer wave
-                    const uint32_t need = g - NST + 1;
-                    for (;;) {
-                        uint32_t mn = lds_ld(consumed);
-#pragma unroll
-                        for (int w = 1; w < NCW; ++w) mn = min(mn, lds_ld(consumed + w));
-                        if (mn >= need) break;
-                        __builtin_amdgcn_s_sleep(1);
-                    }
-                    asm volatile("" ::: "memory");
-                }
-                const uint32_t sbase = lds0 + (g % NST) * SB;
-                const int shift = a.taps == 1 ? 0 : ((tap / 3) - 1) * a.W + (tap % 3) - 1;
-#pragma unroll
-                for (int q = 0; q < MAXP; ++q) {
-                    const int p = q * NLD + lw;
-                    if (p < PA) {
-                        const int r = arow[q] + shift;
-                        const uint32_t voff = ((unsigned)r < (unsigned)a.M) ? (uint32_t)((r * a.C + c0 + lchunk * 8) * 2) : OOB;
-                        dma16(rs_a, sbase + p * 1024, voff, 0u);
-                    } else if (p < NP) {
-                        dma16(rs_b, sbase + p * 1024, boff[q], (uint32_t)kt * 4096u);
-                    }
-                }
-                c0 += 32;
-                if (c0 >= a.C) { c0 = 0; ++tap; }
-                ++g;
-                if (g > (uint32_t)D) {
-                    // at most D stages of this wave's pieces still in flight: stage g - 1 - D has landed
-                    if (NP % NLD == 0 || lw < NP % NLD) wait_vmcnt<D * MAXP>();
-                    else wait_vmcnt<D * (MAXP - 1 > 0 ? MAXP - 1 : 1)>();
-                    lds_st(ready + lw, g - D);
-                }
-            }
-        }
-        wait_vmcnt<0>();
-        lds_st(ready + lw, g);
+        if (NLD > 0 && lw == 0) ws_loader<MT, MW, NW, NST, NLD, D, 0, ABL>(a, smem, ready, consumed, lane, ntiles, KT);
+        if (NLD > 1 && lw == 1) ws_loader<MT, MW, NW, NST, NLD, D, (NLD > 1 ? 1 : 0), ABL>(a, smem, ready, consumed, lane, ntiles, KT);
+        if (NLD > 2 && lw == 2) ws_loader<MT, MW, NW, NST, NLD, D, (NLD > 2 ? 2 : 0), ABL>(a, smem, ready, consumed, lane, ntiles, KT);
+        if (NLD > 3 && lw == 3) ws_loader<MT, MW, NW, NST, NLD, D, (NLD > 3 ? 3 : 0), ABL>(a, smem, ready, consumed, lane, ntiles, KT);
         return;
     }
 
@@ -230,12 +244,18 @@ __global__ __launch_bounds__((MW * NW + NLD) * 64) void ws_gemm_kernel(const Arg
 #pragma unroll
             for (int j = 0; j < MT - 1; ++j) {
 #pragma unroll
-                for (int i = 0; i < 4; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], af[j], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < 4; ++i) {
+                    if (ABL == 1) asm volatile("" :: "v"(bc[i]), "v"(af[j]));
+                    else acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], af[j], acc[i][j], 0, 0, 0);
+                }
                 if (has_next) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[j]);
                 if (j == (MT - 1) / 2) rflag = read_ready();      // the next step's poll, answered under the MFMAs
             }
 #pragma unroll
-            for (int i = 0; i < 4; ++i) acc[i][MT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], alc, acc[i][MT - 1], 0, 0, 0);
+            for (int i = 0; i < 4; ++i) {
+                if (ABL == 1) asm volatile("" :: "v"(bc[i]), "v"(alc));
+                else acc[i][MT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], alc, acc[i][MT - 1], 0, 0, 0);
+            }
             ++g;
         };
         for (int kt = 0; kt < KT; kt += 2) {
@@ -298,7 +318,7 @@ static float bf2f(bf16_t b) {
 
 struct Shape { int M, N, C, taps, W; const char* name; };
 
-template <int MT, int MW, int NW, int NST, int NLD, int D>
+template <int MT, int MW, int NW, int NST, int NLD, int D, int ABL = 0>
 static void run_cfg(const char* cfg, const Shape& s, const bf16_t* dA, const bf16_t* dBt, const bf16_t* dB, bf16_t* dC, float* dRef,
                     int wg_per_cu, bool check) {
     constexpr int BM = 16 * MT * MW, BN = 64 * NW;
@@ -312,7 +332,7 @@ static void run_cfg(const char* cfg, const Shape& s, const bf16_t* dA, const bf1
     const int ntiles = a.ntiles_m * a.ntiles_n;
     const int grid = std::min(ntiles, 256 * wg_per_cu);
     const int threads = (MW * NW + NLD) * 64;
-#define KERN (ws_gemm_kernel<MT, MW, NW, NST, NLD, D>)
+#define KERN (ws_gemm_kernel<MT, MW, NW, NST, NLD, D, ABL>)
     CHECK(hipMemset(dC, 0, (size_t)s.M * s.N * 2));
     hipLaunchKernelGGL(KERN, dim3(grid), dim3(threads), 0, 0, a);
     CHECK(hipGetLastError());
@@ -392,16 +412,18 @@ int main(int argc, char** argv) {
         CHECK(hipMemcpy(dBt, hBt.data(), hBt.size() * 2, hipMemcpyHostToDevice));
         printf("%s: M %d N %d K %lld (%.1f GFLOP)\n", s.name, s.M, s.N, (long long)K, 2.0 * s.M * s.N * K / 1e9);
         //       MT MW NW NST NLD D
-        run_cfg<9, 1, 4, 6, 2, 4>("144x256 4c+2l ring6 D4", s, dA, dBt, dB, dC, dRef, 1, true);
-        run_cfg<9, 1, 4, 6, 2, 3>("144x256 4c+2l ring6 D3", s, dA, dBt, dB, dC, dRef, 1, false);
-        run_cfg<9, 1, 4, 6, 1, 2>("144x256 4c+1l ring6 D2", s, dA, dBt, dB, dC, dRef, 1, true);
-        run_cfg<8, 1, 4, 6, 2, 4>("128x256 4c+2l ring6 D4", s, dA, dBt, dB, dC, dRef, 1, true);
-        run_cfg<8, 2, 2, 6, 2, 4>("256x128 4c+2l ring6 D4", s, dA, dBt, dB, dC, dRef, 1, true);
-        run_cfg<4, 2, 4, 6, 2, 4>("128x256 8c(64x64)+2l ring6 D4", s, dA, dBt, dB, dC, dRef, 1, true);
-        run_cfg<9, 2, 4, 4, 2, 2>("288x256 8c+2l ring4 D2", s, dA, dBt, dB, dC, dRef, 1, true);
-        run_cfg<8, 2, 4, 4, 2, 2>("256x256 8c+2l ring4 D2", s, dA, dBt, dB, dC, dRef, 1, true);
+        run_cfg<9, 1, 4, 6, 2, 2>("144x256 4c+2l ring6 D2", s, dA, dBt, dB, dC, dRef, 1, true);
+        run_cfg<9, 1, 4, 6, 3, 2>("144x256 4c+3l ring6 D2", s, dA, dBt, dB, dC, dRef, 1, true);
+        run_cfg<9, 1, 4, 6, 4, 2>("144x256 4c+4l ring6 D2", s, dA, dBt, dB, dC, dRef, 1, true);
+        run_cfg<9, 1, 4, 6, 4, 3>("144x256 4c+4l ring6 D3", s, dA, dBt, dB, dC, dRef, 1, false);
+        run_cfg<9, 1, 4, 6, 4, 1>("144x256 4c+4l ring6 D1", s, dA, dBt, dB, dC, dRef, 1, false);
+        run_cfg<9, 1, 4, 4, 4, 2>("144x256 4c+4l ring4 D2", s, dA, dBt, dB, dC, dRef, 1, false);
+        run_cfg<9, 1, 4, 6, 4, 2, 1>("144x256 4c+4l D2 ABL no-MFMA", s, dA, dBt, dB, dC, dRef, 1, false);
+        run_cfg<9, 1, 4, 6, 4, 2, 2>("144x256 4c+4l D2 ABL no-DMA", s, dA, dBt, dB, dC, dRef, 1, false);
+        run_cfg<8, 1, 4, 6, 4, 2>("128x256 4c+4l ring6 D2", s, dA, dBt, dB, dC, dRef, 1, true);
+        run_cfg<8, 2, 2, 6, 4, 2>("256x128 4c+4l ring6 D2", s, dA, dBt, dB, dC, dRef, 1, true);
+        run_cfg<4, 2, 4, 6, 4, 2>("128x256 8c(64x64)+4l ring6 D2", s, dA, dBt, dB, dC, dRef, 1, true);
         run_cfg<4, 2, 2, 4, 2, 2>("128x128 4c+2l ring4 D2 x2/CU", s, dA, dBt, dB, dC, dRef, 2, true);
-        run_cfg<4, 2, 2, 3, 1, 1>("128x128 4c+1l ring3 D1 x3/CU", s, dA, dBt, dB, dC, dRef, 3, true);
         CHECK(hipFree(dA)); CHECK(hipFree(dB)); CHECK(hipFree(dBt)); CHECK(hipFree(dC)); CHECK(hipFree(dRef));
     }
     return 0;
