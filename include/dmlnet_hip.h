@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DML_ABI_VERSION 1
+#define DML_ABI_VERSION 2
 
 enum { DML_F32 = 0, DML_BF16 = 1 };
 enum { DML_EINVAL = -1, DML_EALIGN = -2, DML_EUNSUPPORTED = -3 };
@@ -48,7 +48,7 @@ typedef struct DmlConvDesc {
     const void* w;        /* fwd: w[N][R][S][C]; dgrad: transposed copy wt[N=Cin][R][S][C=Cout]         */
     void* y;              /* result [B,Ho,Wo,N], pitch ldy                                               */
     const float* bias;    /* optional [N] (only network/utils.py:23 has a bias)                          */
-    float* stats;         /* optional BN partials [ceil(M/DML_STAT_ROWS)][N][2] = (sum, M2 about the     */
+    float* stats;         /* optional BN partials [ceil(M/rows)][N][2], rows = dml_conv_stat_rows(): (sum, M2 about the */
                           /* group mean) taken from the fp32 accumulators (fused K9)         */
     const float* pre_scale;  /* optional fused BN+ReLU on the A operand: a = relu(x*scale[c]+shift[c]),  */
     const float* pre_shift;  /* applied before zero padding (fwd mode only)                              */
@@ -63,8 +63,8 @@ typedef struct DmlConvDesc {
     /* mode 1 only, optional (all NULL/0 otherwise): the result y is the output gradient dz of a BatchNorm
      * (+ReLU) whose pre-normalisation tensor is bnr_y [M][N] (pitch bnr_ldy) with the 1-bit ReLU mask of
      * dml_bn_apply; the epilogue then also writes that BN's backward partial sums, exactly what
-     * dml_bn_bwd_reduce would produce from the stored dz: bnr_partials[ceil(M/DML_STAT_ROWS)][N][2] =
-     * (sum g, sum g*(bnr_y - mean)*invstd), g = dz * [mask bit] -- pass it with nblocks = ceil(M/64) to
+     * dml_bn_bwd_reduce would produce from the stored dz: bnr_partials[ceil(M/rows)][N][2], rows = dml_conv_stat_rows() =
+     * (sum g, sum g*(bnr_y - mean)*invstd), g = dz * [mask bit] -- pass it with nblocks = ceil(M/rows) to
      * dml_bn_bwd_finalize.  bf16, N % 8 == 0, N > 32. */
     const void* bnr_y;
     const uint8_t* bnr_mask;
@@ -120,12 +120,20 @@ typedef struct DmlConvDesc {
      * weight half of every LDS-DMA instruction is one contiguous KB (whole 128-byte lines) instead of sixteen 64-byte row
      * segments.  bf16, C % 32 == 0, N % 64 == 0, LDS-DMA kernels only: DML_EUNSUPPORTED otherwise (never a silent re-layout). */
     int32_t w_tiled;
-    int32_t reserved0;
+    /* smallest tile count for which the wave-specialised kernel (one persistent workgroup per CU, dml_conv_stat_rows) takes an
+     * eligible launch: 0 = the library's default (192 tiles = three quarters of the CUs), 1 = whenever the shape allows
+     * (tests), INT32_MAX = never. */
+    int32_t ws_min_tiles;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
 
 int dml_conv_igemm(const DmlConvDesc* d, void* stream);
+/* Rows of the GEMM covered by one partial of `stats` / `bnr_partials` for THIS launch: 48 where the wave-specialised kernel
+ * (one persistent workgroup per CU on 144-row tiles: bf16, tile-major weights, N % 128 == 0, enough tiles to fill the chip)
+ * takes it, DML_STAT_ROWS otherwise.  Size the partial buffers as ceil(M / rows) * N * 2 floats, pass `rows` to
+ * dml_bn_finalize / dml_bn_moments and ceil(M / rows) as `nblocks` to dml_bn_bwd_finalize / dml_bn_bwd_sums. */
+int dml_conv_stat_rows(const DmlConvDesc* desc);
 
 typedef struct DmlWgradDesc {
     const void* x;        /* conv input [B,Hi,Wi,C], pitch ldx                                           */
@@ -189,7 +197,9 @@ int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W
  * not cancel); updates running stats with the unbiased variance and `momentum` exactly as
  * nn.BatchNorm2d does; saves invstd for the backward.  `partials` is scratch: the call may fold it in place
  * (large feature maps), so it is not valid input for a second call. */
-int dml_bn_finalize(float* partials, int64_t M, int N, const float* gamma, const float* beta,
+/* stat_rows: rows of the GEMM covered by one partial = dml_conv_stat_rows() of the launch that wrote them (DML_STAT_ROWS for
+ * dml_bn_stats). */
+int dml_bn_finalize(float* partials, int64_t M, int N, int stat_rows, const float* gamma, const float* beta,
                     float* running_mean, float* running_var, float momentum, float eps,
                     float* scale, float* shift, float* save_mean, float* save_invstd, void* stream);
 /* Synchronised BatchNorm (statistics over all ranks' samples; anomaly/lib/nn/modules/batchnorm.py:56-139 of the
@@ -199,7 +209,7 @@ int dml_bn_finalize(float* partials, int64_t M, int N, const float* gamma, const
  *             -> all_gather -> dml_bn_finalize_moments(moments[ranks][N][2], every rank holding M_each rows)
  *   backward: dml_bn_bwd_sums(partials -> sums[N][2] = (sum g, sum g*xhat); dgamma/dbeta += the LOCAL sums)
  *             -> all_reduce(sum) -> dml_bn_bwd_coef(sums, M_total) -> dml_bn_bwd_apply as usual. */
-int dml_bn_moments(float* partials, int64_t M, int N, double* moments, void* stream);
+int dml_bn_moments(float* partials, int64_t M, int N, int stat_rows, double* moments, void* stream);
 int dml_bn_finalize_moments(const double* moments, int ranks, int64_t M_each, int N, const float* gamma,
                             const float* beta, float* running_mean, float* running_var, float momentum,
                             float eps, float* scale, float* shift, float* save_mean, float* save_invstd,

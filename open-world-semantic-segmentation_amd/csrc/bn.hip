@@ -34,21 +34,21 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
 }
 template <int FIN_CH, int FIN_SL>      // channels x group-slices per 256-thread block
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
-    const float* __restrict__ partials, int64_t M, int N, const float* __restrict__ gamma,
+    const float* __restrict__ partials, int64_t M, int N, const int SR, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
     float* scale, float* shift, float* save_mean, float* save_invstd, double* moments_out) {
     static_assert(FIN_CH == 4 && FIN_SL == 64, "lane = 4 channels x 16 slices per wave");
     __shared__ double sh[3][4][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
-    const int64_t G = (M + DML_STAT_ROWS - 1) / DML_STAT_ROWS;
-    const int last_rows = (int)(M - (G - 1) * DML_STAT_ROWS);
+    const int64_t G = (M + SR - 1) / SR;              // SR: rows per statistics group (dml_conv_stat_rows)
+    const int last_rows = (int)(M - (G - 1) * SR);
     double S = 0.0, Q = 0.0, P = 0.0;
     if (n < N)
         #pragma unroll 8
         for (int64_t g = sl; g < G; g += FIN_SL) {
             const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
-            const double rows = g == G - 1 ? (double)last_rows : (double)DML_STAT_ROWS;
+            const double rows = g == G - 1 ? (double)last_rows : (double)SR;
             S += (double)p.x;
             Q += (double)p.y;
             P += (double)p.x * (double)p.x / rows;
@@ -460,7 +460,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
 // Stage 2: per channel, sum the chunks: M2 = Q + P - S^2 / M (fp64: the cancellation costs ~1e-16 * mean^2/var).
 constexpr int FIN2_MAXCHUNK = 128;
 __global__ __launch_bounds__(256) void bn_fold_partials_kernel(float* partials, int64_t G, int N, int R, int NC,
-                                                               int last_rows) {
+                                                               int last_rows, const int SR) {
     __shared__ double sh[3][4][64];
     const int c = threadIdx.x & 63, rl = threadIdx.x >> 6;
     const int n = blockIdx.x * 64 + c;
@@ -471,7 +471,7 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(float* partials, 
         #pragma unroll 8
         for (int64_t g = g0 + rl; g < g1; g += 4) {
             const float2 p = *reinterpret_cast<const float2*>(partials + (g * N + n) * 2);
-            const double rows = g == G - 1 ? (double)last_rows : (double)DML_STAT_ROWS;
+            const double rows = g == G - 1 ? (double)last_rows : (double)SR;
             S += (double)p.x;
             Q += (double)p.y;
             P += (double)p.x * (double)p.x / rows;
@@ -540,25 +540,25 @@ inline bool vec_ok(int dtype, int a) { return a % (dtype == DML_BF16 ? 8 : 4) ==
 
 }  // namespace
 
-extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, const float* gamma, const float* beta,
+extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, int stat_rows, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
-    if (!partials || !scale || !shift || !save_mean || M <= 0 || N <= 0) return DML_EINVAL;
-    const int64_t G = (M + DML_STAT_ROWS - 1) / DML_STAT_ROWS;
+    if (!partials || !scale || !shift || !save_mean || M <= 0 || N <= 0 || stat_rows <= 0) return DML_EINVAL;
+    const int64_t G = (M + stat_rows - 1) / stat_rows;
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (G >= 2048) {
         // large feature maps (the 192x192 layers have G = 9216 and as few as 64 channels): fold, then finish
         if ((reinterpret_cast<uintptr_t>(partials) & 7) != 0) return DML_EALIGN;
         const int R = (int)((G + FIN2_MAXCHUNK - 1) / FIN2_MAXCHUNK);      // >= 16 rows per chunk
         const int NC = (int)(G / R);                                         // the last chunk takes the remainder
-        const int last_rows = (int)(M - (G - 1) * DML_STAT_ROWS);
+        const int last_rows = (int)(M - (G - 1) * stat_rows);
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((N + 63) / 64, NC), dim3(256), 0, st, partials, G, N, R, NC,
-                           last_rows);
+                           last_rows, stat_rows);
         hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((N + 7) / 8), dim3(256), 0, st, partials, M, N, R, NC,
                            gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
     } else {
-        hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, st, partials, M, N, gamma,
-                           beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd,
+        hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, st, partials, M, N, stat_rows,
+                           gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd,
                            (double*)nullptr);
     }
     DML_LAUNCH_CHECK();
@@ -713,10 +713,10 @@ __global__ __launch_bounds__(256) void bn_bwd_coef_kernel(const double* __restri
 }
 }  // namespace
 
-extern "C" int dml_bn_moments(float* partials, int64_t M, int N, double* moments, void* stream) {
-    if (!partials || !moments || M <= 0 || N <= 0) return DML_EINVAL;
+extern "C" int dml_bn_moments(float* partials, int64_t M, int N, int stat_rows, double* moments, void* stream) {
+    if (!partials || !moments || M <= 0 || N <= 0 || stat_rows <= 0) return DML_EINVAL;
     hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, static_cast<hipStream_t>(stream),
-                       partials, M, N, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
+                       partials, M, N, stat_rows, (const float*)nullptr, (const float*)nullptr, (float*)nullptr, (float*)nullptr, 0.f,
                        0.f, (float*)nullptr, (float*)nullptr, (float*)nullptr, (float*)nullptr, moments);
     DML_LAUNCH_CHECK();
     return 0;

@@ -38,6 +38,7 @@ struct ConvArgs {
     float* dbg;      // tuning builds only (ABL == 3): per-wave phase timings
     uint32_t x_bytes, w_bytes;   // operand extents for the buffer descriptors (fast path: both < 2^31)
     int w_tiled;                 // weights in the tile-major layout (DmlConvDesc::w_tiled): LDS-DMA kernels only
+    int ws_min_tiles;            // DmlConvDesc::ws_min_tiles
     // data-gradient mode: BN-backward partial sums of the tensor being written (DmlConvDesc::bnr_*)
     const void* bnr_y;
     const uint8_t* bnr_mask;
@@ -1279,6 +1280,314 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
 }
 
 // ------------------------------------------------------------------------------------------------
+// bf16 forward / data-gradient kernel, WAVE-SPECIALISED version (round 4; tools/probe_ws_gemm.hip is its GEMM-only probe,
+// profiles/r04_ws_probe_*.txt the measurements behind every choice below).
+// What bounded the ring kernel above: every wave both issues its share of the K step's buffer_load ... lds instructions and
+// consumes the step -- a wave issues in order, so the 84-170 cycles the texture addresser takes to accept each of its four
+// DMA instructions are cycles in which it issues no MFMA, and three co-resident workgroups only partly fill the holes
+// (profiles/r03_dma_phases.txt).  Here the two jobs belong to different waves of one workgroup per CU:
+//   * NLD LOADER waves own the vector-memory path.  Loader l issues pieces l, l + NLD, ... (1 KB = 16 tile rows x 64 B each)
+//     of every K step into an NST-stage LDS ring, keeps D stages in flight behind the one it publishes (counted vmcnt) and
+//     announces "stage landed" through a counter in LDS.  A single wave gets one DMA instruction accepted per ~100 cycles,
+//     the addresser takes one per ~30 from several waves: three to four loaders saturate it (1 loader 455, 2: 906, 3: 997
+//     TFLOP/s on layer3's 3x3).  The DMA instruction is inline asm: hipcc must not see an LDS-DMA in flight, or it drains
+//     vmcnt(0) before each of the loader's own LDS accesses (the flag polls).
+//   * 4 CONSUMER waves (one per SIMD) never touch vector memory inside the K loop: poll the counter (the poll for step
+//     k + 1 is issued in the middle of step k's MFMAs), read fragments, issue MFMAs back to back.  The fragments of step
+//     k + 1 are fetched under the MFMAs of step k, register by register as they become free (A fragment j right after the
+//     four MFMAs that used it; the weight fragments and the last A fragment alternate between two register sets).
+//   * No s_barrier in the K loop; the ring decouples the two sides.  WAR: a consumer announces "every read of stage g has
+//     been ISSUED" (DS executes one wave's operations in order, so the flag write lands after them); a loader overwrites a
+//     stage only when all four consumers have announced it.
+//   * Tile = (144 MW) x (64 NW) pixels x channels on 144 x 64 WAVE tiles (36 MFMAs per wave and K step against 13 KB of
+//     fragment reads; the 64 x 64 wave tile of the ring kernel: 16 against 8 KB).  144 rows because the maps of this network
+//     at 16 images are 36 864 / 147 456 / 589 824 pixels: 256 CUs x 144 rows x {1, 4, 16} -- one 144 x 256 tile per CU fills the
+//     chip exactly where 128-row tiles leave a quarter of a round (layer3: 576 tiles on 768 slots) and 256 x 256 tiles 44 %
+//     of it.  One workgroup per CU; workgroups are persistent and walk the tile list (m fastest: the CUs work on the same
+//     weight rows at the same time), the loaders run ahead into the next tile while the consumers store the finished one.
+//   * BatchNorm partial statistics / BN-backward partial sums come per 48 rows (three groups per wave tile): the epilogue is
+//     conv_epilogue on 48-row sub-tiles, and the finalize kernels take the group height (dml_conv_stat_rows).
+// Weights must be the tile-major copy (w_tiled).  MODE as conv_igemm_dma_kernel.
+// ------------------------------------------------------------------------------------------------
+typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
+constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
+constexpr int WS_STAT_ROWS = 48;               // rows per statistics group of this kernel
+constexpr int WS_NST = 6, WS_D = 2;            // ring stages; stages in flight per loader behind the published one
+
+// LDS-DMA piece (16 B per lane, 1 KB per wave) from inline asm: m0 = LDS byte address of the piece (wave-uniform), voff per
+// lane, soff scalar; offsets beyond the descriptor write zeros.  Not counted by hipcc: completion by wait_vmcnt only.
+__device__ __forceinline__ void ws_dma16(const u32x4_ws rsrc, const uint32_t lds_addr, const uint32_t voff, const uint32_t soff) {
+    uint32_t keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tbuffer_load_dwordx4 %2, %3, %4 offen lds\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "s"(lds_addr), "v"(voff), "s"(rsrc), "s"(soff)
+                 : "memory");
+}
+__device__ __forceinline__ u32x4_ws ws_make_rsrc(const void* base, const uint32_t bytes) {
+    const uint64_t b = reinterpret_cast<uint64_t>(base);
+    u32x4_ws r;
+    r[0] = __builtin_amdgcn_readfirstlane((uint32_t)b);
+    r[1] = __builtin_amdgcn_readfirstlane((uint32_t)(b >> 32) & 0xffffu);
+    r[2] = __builtin_amdgcn_readfirstlane(bytes);
+    r[3] = 0x00020000u;
+    return r;
+}
+__device__ __forceinline__ uint32_t ws_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void ws_st(uint32_t* p, const uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// loader wave LW of NLD: compile-time piece ownership (no branches in the issue loop)
+template <int MW, int NW, int MODE, int NLD, int LW>
+__device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t x_bytes, const uint32_t w_bytes, char* smem,
+                                               uint32_t* ready, uint32_t* consumed, const int lane, const int ntiles,
+                                               const int first_tile) {
+    typedef bf16_t T;
+    constexpr int NCW = 4, NT = 4;
+    constexpr int BM = 16 * WS_MT * MW, BN = 64 * NW;
+    constexpr int PA = BM / 16, PB = BN / 16, NP = PA + PB;
+    constexpr int SB = (BM + BN) * BK * 2;
+    constexpr int MYP = (NP - LW + NLD - 1) / NLD;
+    constexpr int NST = WS_NST, D = WS_D;
+    constexpr uint32_t OOB = 0x80000000u;
+    static_assert(D * MYP <= 63, "vmcnt is a 6-bit counter");
+    const u32x4_ws rs_x = ws_make_rsrc(a.x, x_bytes), rs_w = ws_make_rsrc(a.w, w_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int prow = lane >> 2;
+    const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
+    const int sh2 = (MODE != 0 && a.stride == 2) ? 1 : 0;
+    const int KT = a.Ktot / BK;
+    uint32_t g = 0;
+    int base[MYP];
+    uint32_t mask[MYP];
+    int prev_blk_m = -1;
+    for (int tile = first_tile; tile < ntiles; tile += (int)gridDim.x) {
+        const int blk_m = tile % a.nblk_m, blk_n = tile / a.nblk_m;
+        const int m0 = blk_m * BM, n0 = blk_n * BN;
+        // per owned piece and lane: A -- signed byte offset of the row's tap-(0,0) pixel (+ swizzled chunk) and one validity
+        // bit per filter tap; B -- byte offset into the tile-major weights at K step 0 (see conv_igemm_dma_kernel).  The A part
+        // only depends on the row block: a workgroup whose tiles share it (grid = row blocks: N > 256) sets it up once.
+        const bool new_rows = blk_m != prev_blk_m;
+        prev_blk_m = blk_m;
+#pragma unroll
+        for (int q = 0; q < MYP; ++q) {
+            const int p = q * NLD + LW;
+            if (p < PA) {
+                if (!new_rows) continue;
+                base[q] = 0;
+                mask[q] = 0;
+                const int m = m0 + p * 16 + prow;
+                if (m < a.M) {
+                    const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+                    const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+                    const uint32_t yo = fdiv(rem, a.div_wo);
+                    const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+                    const int iy = MODE == 0 ? (int)yo * a.stride - a.pad : (int)yo + a.pad;
+                    const int ix = MODE == 0 ? (int)xo * a.stride - a.pad : (int)xo + a.pad;
+                    const int by = MODE == 0 ? iy : (iy >> sh2), bx = MODE == 0 ? ix : (ix >> sh2);
+                    base[q] = ((((int)b * a.Hi + by) * a.Wi + bx) * a.ldx + lchunk * 8) * 2;
+                    uint32_t mk = 0;
+                    for (int r = 0, t = 0; r < a.R; ++r)
+                        for (int s = 0; s < a.S; ++s, ++t) {
+                            bool ok;
+                            if (MODE == 0) {
+                                const int ys = iy + r * a.dil, xs = ix + s * a.dil;
+                                ok = ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
+                            } else {
+                                const int ty = iy - r * a.dil, tx = ix - s * a.dil;
+                                ok = (sh2 == 0 || (((ty | tx) & 1) == 0)) && ty >= 0 && tx >= 0 && ((ty >> sh2) < a.Hi) &&
+                                     ((tx >> sh2) < a.Wi);
+                            }
+                            mk |= ok ? (1u << t) : 0u;
+                        }
+                    mask[q] = mk;
+                }
+            } else {
+                const int row = (p - PA) * 16 + prow, n = n0 + row;
+                const int bchunk = swz_chunk<T>(b_rho<NT>(row & 63), lane & 3);
+                base[q] = n < a.N ? (int)((((int64_t)(n >> 6) * KT) * 2048 + (n & 63) * 32 + bchunk * 8) * 2) : (int)OOB;
+            }
+        }
+        int ir = 0, is = 0, ic0 = 0;
+        for (int kt = 0; kt < KT; ++kt) {
+            if (g >= (uint32_t)NST) {
+                // the stage this K step overwrites must have been read by every consumer wave
+                const uint32_t need = g - NST + 1;
+                for (;;) {
+                    uint32_t mn = ws_ld(consumed);
+#pragma unroll
+                    for (int w = 1; w < NCW; ++w) mn = min(mn, ws_ld(consumed + w));
+                    if (mn >= need) break;
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+            const uint32_t sbase = lds0 + (g % NST) * SB;
+            const uint32_t tapbit = 1u << (ir * a.S + is);
+            const int soff = (MODE == 0 ? ((ir * a.dil) * a.Wi + is * a.dil) * a.ldx
+                                        : -((((ir * a.dil) >> sh2) * a.Wi + ((is * a.dil) >> sh2)) * a.ldx)) * 2 + ic0 * 2;
+#pragma unroll
+            for (int q = 0; q < MYP; ++q) {
+                const int p = q * NLD + LW;
+                if (p < PA) {
+                    const uint32_t voff = (mask[q] & tapbit) ? (uint32_t)(base[q] + soff) : OOB;
+                    ws_dma16(rs_x, sbase + p * 1024, voff, 0u);
+                } else {
+                    ws_dma16(rs_w, sbase + p * 1024, (uint32_t)base[q], (uint32_t)kt * 4096u);
+                }
+            }
+            ic0 += BK;
+            if (ic0 >= a.C) {
+                ic0 = 0;
+                if (++is == a.S) { is = 0; ++ir; }
+            }
+            ++g;
+            if (g > (uint32_t)D) {
+                wait_vmcnt<D * MYP>();             // at most D stages of this wave's pieces in flight: stage g - 1 - D has landed
+                ws_st(ready + LW, g - D);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    ws_st(ready + LW, g);
+}
+
+template <int MW, int NW, int MODE, int NLD>
+__global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs a, const uint32_t x_bytes, const uint32_t w_bytes) {
+    typedef bf16_t T;
+    static_assert(MW * NW == 4, "four consumer waves, one per SIMD");
+    constexpr int NCW = 4, NT = 4, MT = WS_MT, NST = WS_NST;
+    constexpr int BM = 16 * MT * MW, BN = 64 * NW;
+    constexpr int SB = (BM + BN) * BK * 2;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64];
+    uint32_t* const ready = reinterpret_cast<uint32_t*>(smem + NST * SB);          // [NLD] stages landed, per loader
+    uint32_t* const consumed = ready + 4;                                          // [4] stages whose reads were issued
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 16) reinterpret_cast<uint32_t*>(smem + NST * SB)[tid] = 0;
+    __syncthreads();
+
+    const int ntiles = a.nblk_m * a.nblk_n;
+    const int first_tile = xcd_remap(blockIdx.x, gridDim.x);      // this workgroup walks first_tile, + grid, + 2 grid, ...
+    const int KT = a.Ktot / BK;
+
+    if (wave >= NCW) {
+        const int lw = wave - NCW;
+        if (lw == 0) conv_ws_loader<MW, NW, MODE, NLD, 0>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 1 && lw == 1) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 1 ? 1 : 0)>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 2 && lw == 2) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 2 ? 2 : 0)>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 3 && lw == 3) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 3 ? 3 : 0)>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        return;
+    }
+
+    // ---------------------------------------------------------------------- consumer
+    const int wm = wave / NW, wn = wave % NW;
+    const int lr = lane & 15, lq = lane >> 4;
+    uint32_t g = 0, rflag = 0;
+    auto read_ready = [&]() -> uint32_t {
+        uint32_t v = ws_ld(ready);
+#pragma unroll
+        for (int w = 1; w < NLD; ++w) v = min(v, ws_ld(ready + w));
+        return v;
+    };
+    auto wait_ready = [&](const uint32_t need) {
+        while (rflag < need) {
+            __builtin_amdgcn_s_sleep(1);
+            rflag = read_ready();
+        }
+        asm volatile("" ::: "memory");
+    };
+    int a_off[MT], b_off[NT];          // fragment byte offsets inside a stage
+#pragma unroll
+    for (int j = 0; j < MT; ++j) a_off[j] = (wm * (16 * MT) + j * 16 + lr) * (BK * 2) + swz_chunk<T>(j * 16 + lr, lq) * 16;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) b_off[i] = BM * BK * 2 + (wn * 64 + b_row<NT>(i, lr)) * (BK * 2) + swz_chunk<T>(lr, lq) * 16;
+
+    for (int tile = first_tile; tile < ntiles; tile += (int)gridDim.x) {
+        const int blk_m = tile % a.nblk_m, blk_n = tile / a.nblk_m;
+        f32x4 acc[NT][MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+        mfma_bf16x8 bfA[NT], bfB[NT], af[MT], alA, alB;       // af[MT - 1] unused: the last A fragment alternates alA / alB
+        wait_ready(g + 1);                                      // first K step of the tile: exposed once per tile
+        {
+            const char* sb = smem + (g % NST) * SB;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) bfA[i] = *reinterpret_cast<const mfma_bf16x8*>(sb + b_off[i]);
+#pragma unroll
+            for (int j = 0; j < MT - 1; ++j) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sb + a_off[j]);
+            alA = *reinterpret_cast<const mfma_bf16x8*>(sb + a_off[MT - 1]);
+        }
+        // one K step: MFMAs of step g from (bc, af, alc); the fragments of step g + 1 into (bn, af, aln) as registers free up
+        auto step = [&](mfma_bf16x8 (&bc)[NT], mfma_bf16x8 (&bn)[NT], mfma_bf16x8& alc, mfma_bf16x8& aln, const bool has_next) {
+            asm volatile("" ::: "memory");
+            ws_st(consumed + wave, g + 1);         // every read of stage g has been issued (DS runs a wave's operations in order)
+            const char* sn = smem + ((g + 1) % NST) * SB;
+            if (has_next) {
+                wait_ready(g + 2);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) bn[i] = *reinterpret_cast<const mfma_bf16x8*>(sn + b_off[i]);
+                aln = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[MT - 1]);
+            }
+#pragma unroll
+            for (int j = 0; j < MT - 1; ++j) {
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], af[j], acc[i][j], 0, 0, 0);
+                if (has_next) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[j]);
+                if (j == (MT - 1) / 2) rflag = read_ready();      // the next step's poll, answered under the MFMAs
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) acc[i][MT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], alc, acc[i][MT - 1], 0, 0, 0);
+            ++g;
+        };
+        int kt = 0;
+        for (; kt + 1 < KT; kt += 2) {
+            step(bfA, bfB, alA, alB, true);
+            step(bfB, bfA, alB, alA, kt + 2 < KT);
+        }
+        if (kt < KT) step(bfA, bfB, alA, alB, false);
+        // cut the accumulators' live ranges (see conv_igemm_kernel), then the shared epilogue per 48-row group
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+        // (three explicit copies: hipcc does not unroll a loop around the inlined epilogue, and a run-time index into acc
+        // sends all 36 accumulator fragments through scratch memory -- 37 MB written and read back per launch, +25 us)
+        auto epi = [&](auto hc) {
+            constexpr int h = decltype(hc)::value;
+            f32x4 sub[NT][3];
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < 3; ++j) sub[i][j] = acc[i][h * 3 + j];
+            conv_epilogue<T, NT, 3, MODE, false>(sub, a, blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, blk_n * BN + wn * 64, lr, lq);
+        };
+        static_assert(MT == 9, "three 48-row groups per wave tile");
+        epi(std::integral_constant<int, 0>{});
+        epi(std::integral_constant<int, 1>{});
+        epi(std::integral_constant<int, 2>{});
+    }
+}
+
+// may this launch run on conv_ws_kernel?  (shared by launch_conv and dml_conv_stat_rows)
+static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t wb) {
+    static const int ws_on = getenv("DML_CONV_WS") ? atoi(getenv("DML_CONV_WS")) : 1;
+    if (!ws_on || !a.w_tiled || (a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 128) != 0) return false;
+    if (xb >= (1ll << 31) || wb >= (1ll << 31)) return false;
+    // long K loops only: a consumer wave runs its tile's epilogue itself, with nothing of the same workgroup to cover it, and
+    // below ~32 K steps per tile that costs more than the K loop gains (tools/bench_ws.py, profiles/r04_bench_ws_2.txt: K = 256
+    // with four tiles per workgroup 42.5 vs 31.6 us, K = 512 120 vs 89; K = 1024 28.6 vs 32.0, K = 2304 52.9 vs 60.5, K = 4608
+    // 158 vs 207, K = 18432 284 vs 372).  ws_min_tiles > 0 (tests) lifts the rule.
+    if (a.ws_min_tiles <= 0 && a.R * a.S * a.C < 1024) return false;
+    // a persistent workgroup per CU: the tile list must fill most of the chip
+    const int bn = (a.N % 256) == 0 ? 256 : 128, bm = (a.N % 256) == 0 ? 144 : 288;
+    const int64_t ntiles = ((int64_t)a.M + bm - 1) / bm * (a.N / bn);
+    return ntiles >= (a.ws_min_tiles > 0 ? a.ws_min_tiles : 192);
+}
+
+// ------------------------------------------------------------------------------------------------
 // Persistent form of the LDS-DMA ring for SHORT K loops (1x1 convolutions over <= 512 channels, the 64-channel 3x3):
 // there a tile is 2-18 K steps, and the first loads' latency plus the epilogue (its loads, and the stores the wave must
 // see acknowledged before s_endpgm frees its LDS and registers) is 40-78 % of a tile's lifetime
@@ -2324,6 +2633,27 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
         const int64_t xb = ((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx * 2 + (int64_t)a.C * 2;
         const int64_t wb = (int64_t)a.N * a.Ktot * 2;
         if (!use_v1 && aligned && a.N > 32 && xb < (1ll << 31) && wb < (1ll << 31)) {
+            // wave-specialised kernel (conv_ws_kernel): one persistent workgroup per CU on 144-row tiles, tile-major weights,
+            // N a multiple of 128, enough tiles to fill the chip.  Same-box microbenchmarks against the ring kernel below
+            // (profiles/r04_ws_probe_3.txt vs r04_ws_probe_1_shipped.txt): layer3 3x3 67.5 -> 43.6 us, 1x1 1024 -> 256
+            // 37.6 -> 24.2, 1x1 256 -> 1024 38.4 -> 31.0, ASPP 3x3 385 -> 325-357, decoder 3x3 886 -> 825-870.
+            if (conv_ws_eligible(a, xb, wb)) {
+                constexpr int CUS = 256, NLD = 3;
+                const bool wide = (a.N % 256) == 0;
+                const int bm = wide ? 144 : 288;
+                a.nblk_m = (a.M + bm - 1) / bm;
+                a.nblk_n = a.N / (wide ? 256 : 128);
+                const int ntiles = a.nblk_m * a.nblk_n;
+                const int grid = ntiles < CUS ? ntiles : CUS;
+                if (wide)
+                    hipLaunchKernelGGL((conv_ws_kernel<1, 4, MODE, NLD>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, (uint32_t)xb,
+                                       (uint32_t)wb);
+                else
+                    hipLaunchKernelGGL((conv_ws_kernel<2, 2, MODE, NLD>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, (uint32_t)xb,
+                                       (uint32_t)wb);
+                DML_LAUNCH_CHECK();
+                return 0;
+            }
             // grids that leave most of the chip idle (batch-1 inference, the anomaly model's down-scaled inputs): halve the
             // tile width to double the workgroup count; per-FLOP the 128 x 64 tile is 15-25 % slower, so only below 200
             // workgroups (1024 x 2048 bs 1: 235 -> 250 images/s, 5-scale open-set evaluation 92 -> 97.5 frames/s; the
@@ -2497,6 +2827,20 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
 
 }  // namespace
 
+// Rows of the GEMM covered by one statistics partial (DmlConvDesc.stats / bnr_partials) of THIS launch: 48 where the
+// wave-specialised kernel takes it, DML_STAT_ROWS otherwise.  The caller sizes the partial buffers with it and passes it on to
+// dml_bn_finalize_rows / dml_bn_moments_rows (the BN-backward finalize only needs the group count).
+extern "C" int dml_conv_stat_rows(const DmlConvDesc* d) {
+    if (!d || d->dtype != DML_BF16 || !d->w_tiled) return DML_STAT_ROWS;
+    ConvArgs a;
+    a.w_tiled = 1; a.C = d->C; a.R = d->R; a.S = d->S; a.N = d->N; a.ws_min_tiles = d->ws_min_tiles;
+    a.M = d->B * d->Ho * d->Wo;
+    const int64_t xb = ((int64_t)(d->B * d->Hi) * d->Wi - 1) * d->ldx * 2 + (int64_t)d->C * 2;
+    const int64_t wb = (int64_t)d->N * d->R * d->S * d->C * 2;
+    static const bool use_v1 = getenv("DML_CONV_V1") != nullptr;
+    return (!use_v1 && conv_ws_eligible(a, xb, wb)) ? WS_STAT_ROWS : DML_STAT_ROWS;
+}
+
 extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if (!d || !d->x || !d->w || !d->y) return DML_EINVAL;
     if (d->dtype != DML_F32 && d->dtype != DML_BF16) return DML_EINVAL;
@@ -2518,6 +2862,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
     a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = (d->dtype == DML_F32 && d->f32_split) ? 1 : 0;
     a.w_tiled = 0;
+    a.ws_min_tiles = d->ws_min_tiles;
     if (d->w_tiled) {
         if (d->dtype != DML_BF16 || d->C % BK || d->N % 64) return DML_EUNSUPPORTED;
         a.w_tiled = 1;
@@ -2611,7 +2956,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = 0;
-    a.w_tiled = 0;
+    a.w_tiled = 0; a.ws_min_tiles = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);

@@ -41,7 +41,7 @@ class ConvDesc(C.Structure):
                 ("res_dz", C.c_void_p), ("res_mask", C.c_void_p), ("res_ld", C.c_int32), ("res_reserved", C.c_int32),
                 # fp32 staging of a gradient with several producers, rounded once by the last one (see the header)
                 ("acc32", C.c_void_p), ("acc32_ld", C.c_int32), ("f32_split", C.c_int32),
-                ("w_tiled", C.c_int32), ("reserved0", C.c_int32)]
+                ("w_tiled", C.c_int32), ("ws_min_tiles", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 22
@@ -81,6 +81,7 @@ _PROTOS = {
     "dml_abi_version": (c_i, []),
     "dml_target_arch": (C.c_char_p, []),
     "dml_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_p]),
+    "dml_conv_stat_rows": (c_i, [C.POINTER(ConvDesc)]),
     "dml_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
     "dml_prep_weight": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_prep_weights": (c_i, [c_p, c_i, c_i, c_p]),
@@ -88,8 +89,8 @@ _PROTOS = {
     "dml_bias_grad": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_bias_grad_ws": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_p]),
     "dml_pack_input": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
-    "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
-    "dml_bn_moments": (c_i, [c_p, c_i64, c_i, c_p, c_p]),
+    "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
+    "dml_bn_moments": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
     "dml_bn_finalize_moments": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_bwd_sums": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_p]),
     "dml_bn_bwd_coef": (c_i, [c_p, c_i64, c_i, c_p, c_p, c_p, c_p, c_p]),
@@ -168,7 +169,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.dml_abi_version() != 1:
+    if lib.dml_abi_version() != 2:
         raise DmlError("libdmlnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -339,9 +339,12 @@ class Plan:
         # instruction becomes one contiguous KB (whole cache lines) instead of sixteen 64-byte row segments.  DML_W_TILED=0: off
         self.tiled_weights = os.environ.get("DML_W_TILED", "1") != "0" and os.environ.get("DML_CONV_V1") is None
         self.fork_branches = os.environ.get("DML_FORK_BRANCHES", "1") != "0"
-        # shared scratch for BN partial statistics (forward: ceil(M/64)*N*2 <= B*H*W/2 floats for every layer
-        # of this network; backward: <= ~1100*N*2)
-        self.scratch = torch.empty(max(B * H * W // 2 + 16384, 1100 * 2048 * 2 + 65536), dtype=torch.float32,
+        # DmlConvDesc.ws_min_tiles for every conv of the plan: 0 = the library's rule for its wave-specialised kernel, 1 = take it
+        # whenever the shape allows (the GPU tests run the small fixtures through it), 2147483647 = never
+        self.ws_min_tiles = int(os.environ.get("DML_WS_MIN_TILES", "0"))
+        # shared scratch for BN partial statistics (forward: ceil(M/rows)*N*2 floats, rows = 64 or 48 (dml_conv_stat_rows):
+        # <= 2/3 B*H*W for every layer of this network; backward: <= ~1100*N*2)
+        self.scratch = torch.empty(max(B * H * W * 3 // 4 + 16384, 1100 * 2048 * 2 + 65536), dtype=torch.float32,
                                    device=self.device)
         self.sp = self.scratch.data_ptr()
         # split-K partials of the weight gradients (one launch at a time uses it: all of them run on one stream)
@@ -440,19 +443,23 @@ class Plan:
         Wo = (x.W + 2 * p - d * (kw - 1) - 1) // s + 1
         return kh, kw, s, d, p, Ho, Wo
 
-    def prep_weight(self, conv: nn.Conv2d, Cp: int, need_wt: bool, src_ptr=None, N=None):
+    def prep_weight(self, conv: nn.Conv2d, Cp: int, need_wt: bool, src_ptr=None, N=None, x_bytes=0, dy_bytes=0):
         """compute copies w[N][RS][Cp] (and wt[Cp][RS][N] for the data gradient) of a master weight; `src_ptr` / `N`
-        override the source and the row count (the final conv's rows are padded to a multiple of 8, see build())."""
+        override the source and the row count (the final conv's rows are padded to a multiple of 8, see build()).
+        `x_bytes` / `dy_bytes`: extents of the forward / data-gradient operand tensors of this conv."""
         N, Cm = N or conv.out_channels, conv.in_channels
         kh, kw = conv.kernel_size
         w = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device)
         wt = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device) if need_wt else None
         # tile-major copies for the LDS-DMA kernels (DmlConvDesc.w_tiled): bf16, the GEMM's K a multiple of 32 per filter tap and
-        # its row count a multiple of 64 -- the shapes those kernels take; conv_fwd / conv_dgrad pass the flag on
-        dma = self.tiled_weights and self.dtype == torch.bfloat16 and kh * kw <= 32
-        w.tiled = bool(dma and Cp % 32 == 0 and N % 64 == 0)
+        # its row count a multiple of 64 -- the shapes those kernels take; conv_fwd / conv_dgrad pass the flag on.  Those kernels
+        # address their operands with 31-bit byte offsets (launch_conv's `small` test): a conv whose activation or weight tensor
+        # reaches 2 GiB falls back to the register-staged kernel, which reads the plain layout only -- no tile-major copy then.
+        lim = 1 << 31
+        dma = (self.tiled_weights and self.dtype == torch.bfloat16 and kh * kw <= 32 and N * kh * kw * Cp * 2 < lim)
+        w.tiled = bool(dma and Cp % 32 == 0 and N % 64 == 0 and x_bytes < lim)
         if wt is not None:
-            wt.tiled = bool(dma and N % 32 == 0 and Cp % 64 == 0)
+            wt.tiled = bool(dma and N % 32 == 0 and Cp % 64 == 0 and dy_bytes < lim)
         self.keep += [w, wt]
         self.prep.append((src_ptr or conv.weight.data_ptr(), w.data_ptr(), wt.data_ptr() if wt is not None else 0, N,
                           kh * kw, Cm, Cp, self.dt, 1 if w.tiled else 0, 1 if (wt is not None and wt.tiled) else 0))
@@ -467,6 +474,7 @@ class Plan:
                        y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
         dsc.f32_split = self.f32_split
         dsc.w_tiled = 1 if getattr(w, "tiled", False) else 0
+        dsc.ws_min_tiles = self.ws_min_tiles
         if self.training:
             dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
             dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
@@ -477,6 +485,7 @@ class Plan:
             dsc.post_relu = 1 if relu else 0
         self.keep.append(dsc)
         self.call(self.fwd, self.lib.dml_conv_igemm, C.byref(dsc))
+        return dsc
 
     def conv_dgrad(self, dy: Act, conv: nn.Conv2d, wt, x: Act, final=True):
         """d(loss)/dx (+)= conv^T(dy); x.grad is created on demand.  `final`: no producer of this gradient comes after
@@ -489,6 +498,7 @@ class Plan:
                        accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
         dsc.f32_split = self.f32_split
         dsc.w_tiled = 1 if getattr(wt, "tiled", False) else 0
+        dsc.ws_min_tiles = self.ws_min_tiles
         g32 = x.g32 if x is x.root else None
         convert = False
         if g32 is not None and not (final and not x.root.grad_init):
@@ -587,7 +597,8 @@ class Plan:
         u.Cp = x.C                       # x already carries any channel padding
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         N = conv.out_channels
-        u.w, u.wt = self.prep_weight(conv, u.Cp, self.training and need_dgrad)
+        u.w, u.wt = self.prep_weight(conv, u.Cp, self.training and need_dgrad, x_bytes=x.M * x.ld * x.es,
+                                     dy_bytes=x.B * Ho * Wo * N * x.es)
         u.z = out if out is not None else self.new(x.B, Ho, Wo, N)
         u.y = self.new(x.B, Ho, Wo, N) if self.training else None      # inference never materialises it
         M = u.z.M
@@ -608,15 +619,17 @@ class Plan:
                                                 dummy.data_ptr(), N, float(bn.eps)))
             self.conv_fwd(x, conv, u.y, u.w, None)
         elif self.training:
-            groups = (M + STAT_ROWS - 1) // STAT_ROWS
-            assert groups * N * 2 <= self.scratch.numel(), "BN statistics scratch too small"
             u.mean, u.invstd = self.fbuf(N), self.fbuf(N)
             mean_ptr = u.mean.data_ptr()
-            self.conv_fwd(x, conv, u.y, u.w, self.sp)
+            dsc = self.conv_fwd(x, conv, u.y, u.w, self.sp)
+            # rows per statistics partial of THIS launch (48 on the wave-specialised kernel, STAT_ROWS otherwise)
+            rows = lib.dml_conv_stat_rows(C.byref(dsc))
+            groups = (M + rows - 1) // rows
+            assert groups * N * 2 <= self.scratch.numel(), "BN statistics scratch too small"
             if self.sync:
                 # statistics over every rank's samples (equal shards): local (mean, M2) -> all_gather -> Chan merge
                 mom, allmom = self.dbuf(N * 2), self.dbuf(self.world * N * 2)
-                self.call(self.fwd, lib.dml_bn_moments, self.sp, M, N, mom.data_ptr())
+                self.call(self.fwd, lib.dml_bn_moments, self.sp, M, N, rows, mom.data_ptr())
                 grp = self.e.sync_group
                 self.py_op(self.fwd, lambda a=allmom, b=mom, g=grp: dist.all_gather_into_tensor(a, b, group=g))
                 args = self.call(self.fwd, lib.dml_bn_finalize_moments, allmom.data_ptr(), self.world, M, N, g_ptr, b_ptr,
@@ -624,10 +637,10 @@ class Plan:
                                  u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr())
                 self.momentum_slots.append((args, 8, bn))
             else:
-                args = self.call(self.fwd, lib.dml_bn_finalize, self.sp, M, N, g_ptr, b_ptr,
+                args = self.call(self.fwd, lib.dml_bn_finalize, self.sp, M, N, rows, g_ptr, b_ptr,
                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
                                  u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr())
-                self.momentum_slots.append((args, 7, bn))
+                self.momentum_slots.append((args, 8, bn))
         else:
             # inference: scale / shift of every BN come from ONE table launch at the head of the plan, and BN +
             # residual + ReLU run in the conv epilogue -- one launch per unit instead of three, no y tensor
@@ -671,8 +684,9 @@ class Plan:
         # no dropout scale, at most 4096 row groups (on the 192 x 192 layers the finalize would fold 9216 groups in two
         # stages, which works, but the fused sums then cost the data gradients more than the stand-alone reduce:
         # 363.5 vs 364.5 images/s).
-        G = (M + STAT_ROWS - 1) // STAT_ROWS
         prod = self.last_dgrad.get(dz.ptr) if (self.fuse_bn_reduce and u.z is u.z.root) else None
+        prows = lib.dml_conv_stat_rows(C.byref(prod)) if prod is not None else STAT_ROWS      # rows per partial of that launch
+        G = (M + prows - 1) // prows
         fused = (prod is not None and self.dtype == torch.bfloat16 and (u.mask is not None or not u.relu)
                  and u.drop is None and N % 8 == 0 and N > 32 and G <= 4096 and prod.N == N and prod.ldy == N
                  and dz.ld == N and prod.y == dz.ptr)

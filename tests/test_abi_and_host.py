@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
         assert hasattr(lib, s), "missing export " + s
     assert sorted(_lib.EXPORTS) == syms, "binding and header disagree"
     lib2 = _lib.load()
-    assert lib2.dml_abi_version() == 1
+    assert lib2.dml_abi_version() == 2
     assert lib2.dml_target_arch() == b"gfx950"
 
 

@@ -111,7 +111,7 @@ def test_conv_fwd_dgrad_wgrad(lib, case, dname):
     # fused BN statistics: finalize and compare with the batch statistics of the fp32 result
     sc, sh, mu, inv = (torch.empty(Cout, device="cuda") for _ in range(4))
     rm, rv = torch.zeros(Cout, device="cuda"), torch.ones(Cout, device="cuda")
-    chk(lib.dml_bn_finalize(stats.data_ptr(), M, Cout, None, None, rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5,
+    chk(lib.dml_bn_finalize(stats.data_ptr(), M, Cout, 64, None, None, rm.data_ptr(), rv.data_ptr(), 0.1, 1e-5,
                             sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
     yr = y_ref.detach().double()
     mean_ref, var_ref = yr.mean(dim=(0, 2, 3)), yr.var(dim=(0, 2, 3), unbiased=False)
@@ -302,12 +302,12 @@ def test_sync_bn_building_blocks(lib):
     # whole batch, ordinary path
     ref = [torch.empty(N, device="cuda") for _ in range(4)]
     rm_ref, rv_ref = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
-    chk(lib.dml_bn_finalize(stats(y).data_ptr(), 2 * Mh, N, gam.data_ptr(), bet.data_ptr(), rm_ref.data_ptr(), rv_ref.data_ptr(),
+    chk(lib.dml_bn_finalize(stats(y).data_ptr(), 2 * Mh, N, 64, gam.data_ptr(), bet.data_ptr(), rm_ref.data_ptr(), rv_ref.data_ptr(),
                             0.1, 1e-5, *[t.data_ptr() for t in ref], st()))
     # two "ranks"
     mom = torch.empty(2, N, 2, device="cuda", dtype=torch.float64)
     for r in range(2):
-        chk(lib.dml_bn_moments(stats(y[r * Mh:(r + 1) * Mh]).data_ptr(), Mh, N, mom[r].data_ptr(), st()))
+        chk(lib.dml_bn_moments(stats(y[r * Mh:(r + 1) * Mh]).data_ptr(), Mh, N, 64, mom[r].data_ptr(), st()))
     got = [torch.empty(N, device="cuda") for _ in range(4)]
     rm, rv = torch.zeros(N, device="cuda"), torch.ones(N, device="cuda")
     chk(lib.dml_bn_finalize_moments(mom.data_ptr(), 2, Mh, N, gam.data_ptr(), bet.data_ptr(), rm.data_ptr(), rv.data_ptr(), 0.1,
@@ -416,7 +416,7 @@ def test_bn_finalize_many_groups(lib, Cc):
     sc, sh, mu, inv = (torch.empty(Cc, device="cuda") for _ in range(4))
     rm, rv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
     gam = (torch.rand(Cc, generator=g) + 0.5).cuda()
-    chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, gam.data_ptr(), None, rm.data_ptr(), rv.data_ptr(),
+    chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, 64, gam.data_ptr(), None, rm.data_ptr(), rv.data_ptr(),
                             0.1, 1e-5, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
     torch.cuda.synchronize()
     y64 = y.double()
@@ -485,7 +485,7 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     chk(lib.dml_bn_stats(yd.data_ptr(), part.data_ptr(), M, Cc, Cc, dt, st()))
     sc, sh, mu, inv = (torch.empty(Cc, device="cuda") for _ in range(4))
     rm, rv, g_d, b_d = rm0.cuda(), rv0.cuda(), gamma.detach().cuda(), beta.detach().cuda()
-    chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, g_d.data_ptr(), b_d.data_ptr(), rm.data_ptr(), rv.data_ptr(),
+    chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, 64, g_d.data_ptr(), b_d.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                             0.01, 1e-5, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
     bitmask = torch.zeros(M * Cc // 8, device="cuda", dtype=torch.uint8) if dname == "bf16" else None
     mk = bitmask.data_ptr() if bitmask is not None else None
@@ -973,73 +973,92 @@ def test_conv_tail_split_k(lib, case):
     assert int(cnt.abs().sum()) == 0
 
 
-PERSIST_CASES = [
-    # name, mode, B, H, W, C (K side), N (output side), k, stride (of the forward conv), bnr, accum
-    ("fwd_1x1_k256_n1024", 0, 16, 48, 48, 256, 1024, 1, 1, 0, 0),          # layer3 conv3: 2304 tiles, 8 K steps
-    ("fwd_1x1_k64_n256", 0, 2, 192, 192, 64, 256, 1, 1, 0, 0),            # layer1 conv3: 2 K steps, 2 rounds of 576
-    ("fwd_3x3_k576_n64_ragged", 0, 4, 191, 190, 64, 64, 3, 1, 0, 0),      # 64-wide tiles, ragged last tile, 18 K steps
-    ("fwd_1x1_n320", 0, 8, 96, 96, 128, 320, 1, 1, 0, 0),                 # partial third column of tiles
-    ("dgrad_1x1_bnr_accum", 1, 16, 48, 48, 256, 1024, 1, 1, 1, 1),        # layer3 conv1 data gradient + bn3 sums
-    ("dgrad_1x1_bnr", 1, 8, 96, 96, 128, 512, 1, 1, 1, 0),
-    ("dgrad_1x1_stride2", 1, 16, 48, 48, 512, 256, 1, 2, 0, 0),           # downsample conv: writes 96 x 96
-    ("dgrad_3x3_k576_n64", 1, 4, 192, 192, 64, 64, 3, 1, 1, 0),
+WS_CASES = [
+    # name, mode, B, H, W, C (K side), N (output side), k, stride (of the forward conv), dil, bnr, accum, res
+    ("fwd_1x1_k256_n1024", 0, 4, 48, 48, 256, 1024, 1, 1, 1, 0, 0, 0),          # layer3 conv3: 8 K steps, 4 n-blocks
+    ("fwd_3x3_n256", 0, 2, 48, 48, 256, 256, 3, 1, 1, 0, 0, 0),                 # layer3 conv2
+    ("fwd_3x3_d2_ragged", 0, 2, 37, 29, 128, 256, 3, 1, 2, 0, 0, 0),            # rows not a multiple of 16 / 48 / 144
+    ("fwd_1x1_odd_ksteps", 0, 3, 24, 40, 96, 256, 1, 1, 1, 0, 0, 0),            # 3 K steps (odd: the unrolled pair + a tail step)
+    ("fwd_3x3_s2_n128", 0, 2, 96, 96, 128, 128, 3, 2, 1, 0, 0, 0),              # stride 2, the 288 x 128 tile
+    ("fwd_1x1_n384", 0, 2, 48, 48, 512, 384, 1, 1, 1, 0, 0, 0),                 # N % 256 != 0: 128-wide tiles, three of them
+    ("dgrad_1x1_bnr_res", 1, 4, 48, 48, 256, 1024, 1, 1, 1, 1, 0, 1),           # layer3 conv1 data gradient + bn3 sums + identity add
+    ("dgrad_1x1_bnr_accum", 1, 2, 96, 96, 128, 512, 1, 1, 1, 1, 1, 0),
+    ("dgrad_1x1_stride2", 1, 4, 48, 48, 512, 256, 1, 2, 1, 0, 0, 0),            # downsample conv: writes 96 x 96
+    ("dgrad_3x3_d2_bnr", 1, 2, 48, 48, 512, 512, 3, 1, 2, 1, 0, 0),
+    ("dgrad_3x3_s2", 1, 2, 48, 48, 256, 256, 3, 2, 1, 0, 0, 0),
 ]
 
 
-@pytest.mark.parametrize("case", PERSIST_CASES, ids=[c[0] for c in PERSIST_CASES])
-def test_conv_persistent_short_k_is_bit_identical(lib, case):
-    """conv_igemm_dma_persist_kernel (workgroups that walk a tile list, ring kept full across tile boundaries) against
-    the one-tile-per-workgroup kernel on the same launch: outputs, BN statistics partials and BN-backward partials must
-    be bit-identical (same tile, same MFMA order, same epilogue); the one-tile kernel is what the other tests check
-    against torch."""
-    name, mode, B, Hh, Ww, Cc, N, k, stride, bnr, accum = case
-    lib.dml_debug_conv_persist.restype = C.c_int
-    lib.dml_debug_conv_persist.argtypes = [C.c_int]
+@pytest.mark.parametrize("case", WS_CASES, ids=[c[0] for c in WS_CASES])
+def test_wave_specialised_conv_equals_ring_kernel(lib, case):
+    """conv_ws_kernel (one persistent workgroup per CU: loader waves feed an LDS ring, consumer waves only read fragments and
+    issue MFMAs, 144-row tiles, statistics per 48 rows) against the ring kernel (conv_igemm_dma_kernel, 128-row tiles, 64-row
+    statistics groups) on the same launch: same products in the same K order, so the OUTPUT must be bit-identical; the partial
+    statistics / BN-backward partials are grouped differently and must agree after the merge.  The ring kernel is what the other
+    tests check against torch.  DmlConvDesc.ws_min_tiles selects the kernel in-process."""
+    from dmlnet._lib import PrepDesc
+    name, mode, B, Hh, Ww, Cc, N, k, stride, dil, bnr, accum, res = case
     g = torch.Generator(device="cuda").manual_seed(5)
-    pad = k // 2
+    pad = dil * (k // 2)
     if mode == 0:
-        Hi, Wi, Ho, Wo = Hh, Ww, Hh, Ww
+        Hi, Wi = Hh, Ww
+        Ho, Wo = (Hh + 2 * pad - dil * (k - 1) - 1) // stride + 1, (Ww + 2 * pad - dil * (k - 1) - 1) // stride + 1
     else:                          # data gradient: "input" is dy on the forward output grid, output on the input grid
         Hi, Wi, Ho, Wo = Hh, Ww, Hh * stride, Ww * stride
     x = (torch.randn(B, Hi, Wi, Cc, device="cuda", generator=g)).to(torch.bfloat16)
-    w = (torch.randn(N, k, k, Cc, device="cuda", generator=g) * 0.05).to(torch.bfloat16)
+    master = (torch.randn(N, k, k, Cc, device="cuda", generator=g) * 0.05).contiguous()
+    w = torch.empty(N * k * k * Cc, device="cuda", dtype=torch.bfloat16)
+    arr = (PrepDesc * 1)(PrepDesc(master.data_ptr(), w.data_ptr(), None, N, k * k, Cc, Cc, 1, 0))
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    chk(lib.dml_prep_weights(tab.data_ptr(), 1, 1, st()))
     M = B * Ho * Wo
     y0 = (torch.randn(B, Ho, Wo, N, device="cuda", generator=g) * 0.3).to(torch.bfloat16)
-    G = (M + 63) // 64
     ybn = (torch.randn(M, N, device="cuda", generator=g) * 1.5 + 0.3).to(torch.bfloat16)
     bits = torch.randint(0, 256, (M * N // 8,), device="cuda", dtype=torch.uint8, generator=g)
+    rdz = (torch.randn(M, N, device="cuda", generator=g)).to(torch.bfloat16)
+    rbits = torch.randint(0, 256, (M * N // 8,), device="cuda", dtype=torch.uint8, generator=g)
     mean, invstd = torch.randn(N, device="cuda", generator=g) * 0.2, torch.rand(N, device="cuda", generator=g) + 0.5
 
-    def run(persist):
-        prev = lib.dml_debug_conv_persist(24 if persist else 0)
-        try:
-            y = y0.clone()
-            stats = torch.full((G * N * 2,), 3.0, device="cuda")
-            part = torch.full((G * N * 2,), 7.0, device="cuda")
-            d = make_desc(lib, x, w, y, B, Hi, Wi, Cc, Ho, Wo, N, k, stride, 1, pad, 1, mode=mode,
-                          stats=stats if mode == 0 else None, accum=accum)
-            if bnr:
-                d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr()
-                d.bnr_partials, d.bnr_ldy, d.bnr_relu = part.data_ptr(), N, 1
-            for _ in range(2 if not accum else 1):           # a second launch over a warm cache changes the interleaving
-                chk(lib.dml_conv_igemm(C.byref(d), st()))
+    def run(ws):
+        y = y0.clone()
+        d = make_desc(lib, x, w, y, B, Hi, Wi, Cc, Ho, Wo, N, k, stride, dil, pad, 1, mode=mode, accum=accum)
+        d.w_tiled, d.ws_min_tiles = 1, (1 if ws else 2 ** 31 - 1)
+        rows = lib.dml_conv_stat_rows(C.byref(d))
+        assert rows == (48 if ws else 64)
+        G = (M + rows - 1) // rows
+        stats = torch.full((G * N * 2,), 3.0, device="cuda")
+        part = torch.full((G * N * 2,), 7.0, device="cuda")
+        if mode == 0:
+            d.stats = stats.data_ptr()
+        if bnr:
+            d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+            d.bnr_partials, d.bnr_ldy, d.bnr_relu = part.data_ptr(), N, 1
+        if res:
+            d.res_dz, d.res_mask, d.res_ld = rdz.data_ptr(), rbits.data_ptr(), N
+        for _ in range(2 if not accum else 1):           # a second launch over a warm cache changes the interleaving
+            chk(lib.dml_conv_igemm(C.byref(d), st()))
+        torch.cuda.synchronize()
+        fin = None
+        if mode == 0:
+            sc, sh, mu, inv = (torch.empty(N, device="cuda") for _ in range(4))
+            chk(lib.dml_bn_finalize(stats.data_ptr(), M, N, rows, None, None, None, None, 0.1, 1e-5, sc.data_ptr(), sh.data_ptr(),
+                                    mu.data_ptr(), inv.data_ptr(), st()))
             torch.cuda.synchronize()
-            return y, stats, part
-        finally:
-            lib.dml_debug_conv_persist(prev)
+            fin = (mu, inv)
+        return y, fin, part.view(G, N, 2).double().sum(0)
 
-    y1, s1, p1 = run(True)
-    y2, s2, p2 = run(False)
+    y1, f1, p1 = run(True)
+    y2, f2, p2 = run(False)
     assert torch.isfinite(y1.float()).all()
     assert (y1.float() - y0.float()).abs().max().item() > 0.1, "nothing was written"
-    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)), "%s: outputs differ at %d elements" % (
-        name, (y1.view(torch.int16) != y2.view(torch.int16)).sum().item())
-    assert torch.equal(s1.view(torch.int32), s2.view(torch.int32)), name + ": BN statistics partials differ"
-    assert torch.equal(p1.view(torch.int32), p2.view(torch.int32)), name + ": BN-backward partials differ"
+    assert torch.equal(y1.view(torch.int16), y2.view(torch.int16)), "%s: outputs differ at %d of %d elements" % (
+        name, (y1.view(torch.int16) != y2.view(torch.int16)).sum().item(), y1.numel())
     if mode == 0:
-        assert (s1 != 3.0).any()
+        relclose(f1[0], f2[0], 1e-5, name + ": batch mean from the 48-row partials")
+        relclose(f1[1], f2[1], 1e-5, name + ": 1/sigma from the 48-row partials")
     if bnr:
-        assert (p1 != 7.0).any()
+        relclose(p1, p2, 1e-5, name + ": BN-backward sums")
+        assert (p1 != 7.0 * ((M + 47) // 48)).any()
 
 
 @pytest.mark.parametrize("case", [("3x3_odd_steps", 3, 50, 46, 256, 256, 3, 1), ("1x1_ragged", 2, 37, 41, 512, 256, 1, 1),
