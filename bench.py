@@ -30,7 +30,7 @@ import torch.distributed as dist  # noqa: E402
 
 # dense MFMA peaks, MI355X_MICROARCH.md; "f32x3" = fp32 storage with the convolutions' products on the bf16 matrix cores through
 # a three-term split (six bf16 MFMAs per fp32-accurate block): its ceiling in fp32-equivalent FLOPs is the bf16 peak / 6
-PEAK = {"bf16": 2.5e15, "f32": 157.3e12, "f32x3": 2.5e15 / 6}
+PEAK = {"bf16": 2.5e15, "f32": 157.3e12, "f32x3": 2.5e15 / 6, "f16x2": 2.5e15 / 3}
 HBM_PEAK = 8.0e12
 ROUND = "r03"
 
@@ -609,7 +609,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x3"],
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f32x3", "f16x2"],
                     help="bf16 (headline), f32 = exact fp32 MFMA (the reference's arithmetic), f32x3 = fp32 storage, conv products "
                          "through the three-term bf16 split (fp32-level error)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
@@ -718,7 +718,7 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
     model = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
     model.to(device)
     model.set_compute_dtype(torch.bfloat16 if dtype == "bf16" else torch.float32,
-                            fp32_products="bf16x3" if dtype == "f32x3" else "exact")
+                            fp32_products={"f32x3": "bf16x3", "f16x2": "f16x2"}.get(dtype, "exact"))
     model.train()
     utils.set_bn_momentum(model.backbone, momentum=0.01)                     # main_embedding.py:379
     lr = 0.01

@@ -111,7 +111,7 @@ typedef struct DmlConvDesc {
      * LAST producer adds it to its accumulators and rounds the total once into the bf16 tensor y. */
     const float* acc32;
     int32_t acc32_ld;
-    /* dtype DML_F32 only: 1 = compute the products on the bf16 matrix cores through a three-term split of both operands
+    /* dtype DML_F32 only (2: see x_planes below): 1 = compute the products on the bf16 matrix cores through a three-term split of both operands
      * (x = hi + mid + lo, six bf16 MFMAs per block: fp32-level error, 2.7x fewer matrix cycles than v_mfma_f32_16x16x4_f32);
      * 0 = the exact fp32 MFMA, the reference's arithmetic (network/utils.py:84-118 computes in fp32).  Shapes the split kernel
      * does not take (C % 32 != 0, N <= 32) run exact either way. */
@@ -124,6 +124,19 @@ typedef struct DmlConvDesc {
      * eligible launch: 0 = the library's default (192 tiles = three quarters of the CUs), 1 = whenever the shape allows
      * (tests), INT32_MAX = never. */
     int32_t ws_min_tiles;
+    /* dtype DML_F32, f32_split == 2: the products on the fp16 matrix cores through a TWO-term split of the power-of-two-scaled
+     * operands -- x s = xh + xl, w t = wh + wl (fp16 hi / lo planes written by dml_h2_split), per block wl xh + wh xl + wh xh, fp32
+     * accumulation, result unscaled by the exact 1 / (s t): relative error ~2^-21 per element, the reference's own fp32-vs-fp64
+     * level on the parity fixtures (tests/tools/emu_split_terms.py) at three MFMAs per block instead of the six of
+     * f32_split == 1.  x_planes / w_planes: [2][...] fp16, the hi plane then the lo plane `*_plane_stride` elements further, the
+     * activation planes with the geometry (pitch ldx) of `x`, the weight planes tile-major ([N / 64][K / 32][64][32] per plane);
+     * x_unscale / w_unscale: device scalars 1 / s and 1 / t (dml_h2_split).  Shapes the planes kernel does not take (C % 32,
+     * N % 128, more than 32 taps) run the three-term split on x / w, which must therefore be valid as well. */
+    const void* x_planes;
+    const void* w_planes;
+    const float* x_unscale;
+    const float* w_unscale;
+    int64_t x_plane_stride, w_plane_stride;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
@@ -134,6 +147,19 @@ int dml_conv_igemm(const DmlConvDesc* d, void* stream);
  * takes it, DML_STAT_ROWS otherwise.  Size the partial buffers as ceil(M / rows) * N * 2 floats, pass `rows` to
  * dml_bn_finalize / dml_bn_moments and ceil(M / rows) as `nblocks` to dml_bn_bwd_finalize / dml_bn_bwd_sums. */
 int dml_conv_stat_rows(const DmlConvDesc* desc);
+
+/* fp32 tensor x[rows][ld] (C used columns) -> two fp16 planes of s * x, s the power of two that puts max|x| into [2^14, 2^15):
+ * hi = fp16(s x), lo = fp16(s x - hi), both round-to-nearest-even, s x = hi + lo up to 2^-22 relative.  planes[0 .. ] = hi,
+ * planes[plane_stride ..] = lo (fp16 elements); layout 0: row pitch ldp, element (r, c) at r * ldp + c; layout 1: tile-major
+ * [rows / 64][C / 32][64][32] (rows % 64 == 0, C % 32 == 0: the weight operand of the LDS-DMA kernels).  `work`: >= 1025 floats of
+ * scratch owned by this tensor; work[1024] receives 1 / s (DmlConvDesc.x_unscale / w_unscale).  Two launches (per-workgroup
+ * maxima, then the split: no atomics, no memset, deterministic) -- or one, with amax_known = 1: the maximum over work[0 .. 1024)
+ * then already is max |x| (any upper bound within a few binades works: fp16 keeps 11 bits down to 2^-14 of the scaled range),
+ * collected by the tensor's producer (dml_bn_apply / dml_bn_bwd_apply, `amax` = work: order-independent atomic maxima spread over
+ * those 1024 words, which the caller zeroed).
+ * Non-finite values propagate (s becomes 0 or NaN). */
+int dml_h2_split(const float* x, int64_t rows, int32_t C, int32_t ld, void* planes, int64_t plane_stride, int32_t ldp,
+                 int32_t layout, float* work, int32_t amax_known, void* stream);
 
 typedef struct DmlWgradDesc {
     const void* x;        /* conv input [B,Hi,Wi,C], pitch ldx                                           */
@@ -149,6 +175,14 @@ typedef struct DmlWgradDesc {
     int64_t ws_elems;     /* and a second kernel folds them into dw (no fp32 atomics); capacity in floats     */
     int32_t f32_split;    /* dtype DML_F32 only: products through the three-term bf16 split (DmlConvDesc.f32_split) */
     int32_t reserved;
+    /* f32_split == 2 (dtype DML_F32): both operands as two fp16 planes of the scaled tensors (dml_h2_split, layout 0, the pitches
+     * of x / dy), three MFMAs per block on the fp16 matrix cores (DmlConvDesc.x_planes has the arithmetic); NULL planes or
+     * misaligned shapes: the three-term split on x / dy. */
+    const void* x_planes;
+    const void* dy_planes;
+    const float* x_unscale;
+    const float* dy_unscale;
+    int64_t x_plane_stride, dy_plane_stride;
 } DmlWgradDesc;
 
 int dml_conv_wgrad(const DmlWgradDesc* d, void* stream);
@@ -232,11 +266,13 @@ typedef struct DmlBnEvalDesc {
 } DmlBnEvalDesc;
 int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, void* stream);
 /* z = act((y - mean)*scale + shift [+ res]) with optional inverted dropout (network/utils.py:354).
- * y, res, z have independent pitches.  `mask` (optional, DML_BF16 only): one bit per element, z > 0, packed as
- * mask[m*(N/8) + c/8] bit c%8 -- the backward passes then read 1 byte instead of 16 bytes of z. */
+ * y, res, z have independent pitches.  `mask` (optional): one bit per element, z > 0, one BYTE per 16-byte vector of z --
+ * DML_BF16: mask[m*(N/8) + c/8] bit c%8; DML_F32: mask[m*(N/4) + c/4] bit c%4 -- the backward passes then read 1 byte
+ * instead of 16 bytes of z.  `amax` (optional): 1024 floats the caller zeroed; their maximum afterwards is max |z| (one
+ * order-independent atomic maximum per workgroup, spread over the words: dml_h2_split, amax_known). */
 int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
                  const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
-                 int dtype, float drop_p, uint64_t drop_seed, void* stream);
+                 int dtype, float drop_p, uint64_t drop_seed, float* amax, void* stream);
 /* backward, pass 1: per-channel sums of g = dz*[z>0]*gscale and g*xhat -> partials[blocks][N][2]
  * ([z>0] from `mask` when given, else from z).
  * returns the number of partial rows through *nblocks (host int). */
@@ -252,10 +288,11 @@ int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const uint8_
 int dml_bn_bwd_finalize(float* partials, int nblocks, int64_t M, int N, const float* gamma,
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                         float* coef, void* stream);
-/* backward, pass 2: dy = coef0*g + coef1*(y - coef3) + coef2; optionally dres (+)= g for the identity branch. */
+/* backward, pass 2: dy = coef0*g + coef1*(y - coef3) + coef2; optionally dres (+)= g for the identity branch.  `amax`
+ * (optional): max |dy|, as in dml_bn_apply. */
 int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* coef, void* dy,
                      void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
-                     int relu, float gscale, int dres_accum, int dtype, void* stream);
+                     int relu, float gscale, int dres_accum, int dtype, float* amax, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling (network/backbone/resnet.py:143; network/utils.py:320,326-329).

@@ -142,24 +142,43 @@ __device__ __forceinline__ bool drop_keep(uint64_t seed, uint64_t idx, uint32_t 
 // Column-stationary variant: a thread keeps one 16-byte channel vector (its scale / shift / mean live in registers,
 // no per-element division) and walks rows, U rows per trip with all loads issued before the first use, so that a CU
 // has U x 32 KB of HBM reads in flight instead of 32 KB.
+// max |x| of a tensor as a side output of the kernel that writes it (dml_h2_split, amax_known): ONE atomic maximum per
+// workgroup, spread over the 1024 words of the tensor's `work` buffer by workgroup index -- tens of thousands of short-lived
+// workgroups raising a single word serialise in one L2 channel (measured: the apply kernels 56 -> 329 us); the split kernel
+// takes the maximum over all 1024 words.  Order-independent, so the step stays bitwise reproducible.
+__device__ __forceinline__ void amax_publish(uint32_t amx, uint32_t* __restrict__ words) {
+    __shared__ uint32_t sh_amax[4];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) amx = max(amx, (uint32_t)__shfl_xor((int)amx, o, 64));
+    if ((threadIdx.x & 63) == 0) sh_amax[threadIdx.x >> 6] = amx;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t m = max(max(sh_amax[0], sh_amax[1]), max(sh_amax[2], sh_amax[3]));
+        if (m != 0) atomicMax(words + ((blockIdx.x + blockIdx.y * gridDim.x) & 1023u), m);
+    }
+}
+
 template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
     const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, uint8_t* __restrict__ mask, int64_t M, int N,
-    int ldy, int ldres, int ldz, int relu, float drop_p, uint64_t drop_seed, int CB, int RB, int rows_per_block) {
+    int ldy, int ldres, int ldz, int relu, float drop_p, uint64_t drop_seed, int CB, int RB, int rows_per_block,
+    uint32_t* __restrict__ amax) {
     constexpr int V = Vec16<T>::N;
     const int NV = N / V;
     const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
     const int vcol = blockIdx.y * CB + col;
-    if (rl >= RB || vcol >= NV) return;
-    const int c = vcol * V;
+    const bool act = rl < RB && vcol < NV;      // (idle threads stay for the wave reduction of amax at the end)
+    if (!act && amax == nullptr) return;
+    const int c = act ? vcol * V : 0;
+    uint32_t amx = 0;                  // largest |z| this thread stores, as its bit pattern (dml_h2_split with amax_known)
     float sc[V], sh[V], mu[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) { sc[q] = scale[c + q]; sh[q] = shift[c + q]; mu[q] = mean[c + q]; }
     const uint32_t thresh = drop_p > 0.f ? (uint32_t)min(4294967295.0, (double)drop_p * 4294967296.0) : 0u;
     const float keep_scale = drop_p > 0.f ? 1.0f / (1.0f - drop_p) : 1.0f;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = min(M, r0 + rows_per_block);
+    const int64_t r1 = act ? min(M, r0 + rows_per_block) : 0;
     for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)RB * U) {
         float v[U][V], r[U][V];
 #pragma unroll
@@ -190,14 +209,19 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
                     v[u][q] = drop_keep(drop_seed, (uint64_t)m * N + c + q, thresh) ? v[u][q] * keep_scale : 0.f;
             }
             Vec16<T>::store(z + m * ldz + c, v[u]);
-            if (V == 8 && mask != nullptr) {
+            if (mask != nullptr) {           // one byte per 16-byte vector: 8 bits (bf16) / 4 bits (fp32)
                 uint32_t bits = 0;
 #pragma unroll
                 for (int q = 0; q < V; ++q) bits |= (v[u][q] > 0.f ? 1u : 0u) << q;
                 mask[m * NV + vcol] = (uint8_t)bits;
             }
+            if (amax != nullptr) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) amx = max(amx, __float_as_uint(v[u][q]) & 0x7fffffffu);
+            }
         }
     }
+    if (amax != nullptr) amax_publish(amx, amax);
 }
 
 // geometry shared by the column-stationary kernels: CB vector columns x RB row lanes per 256-thread block
@@ -252,7 +276,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
         const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
         const int64_t r1 = min(M, r0 + rows_per_block);
         constexpr int U = 2;                  // rows in flight per thread
-        const bool use_mask = V == 8 && mask != nullptr;
+        const bool use_mask = mask != nullptr;
         for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)rt * U) {
             float g[U][V], yy[U][V], zz[U][V];
             uint32_t bits[U];
@@ -395,13 +419,15 @@ template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
     const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const uint8_t* __restrict__ mask,
     const float* __restrict__ coef, T* __restrict__ dy, T* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy,
-    int lddres, int relu, float gscale, int dres_accum, int CB, int RB, int rows_per_block) {
+    int lddres, int relu, float gscale, int dres_accum, int CB, int RB, int rows_per_block, uint32_t* __restrict__ amax) {
     constexpr int V = Vec16<T>::N;
     const int NV = N / V;
     const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
     const int vcol = blockIdx.y * CB + col;
-    if (rl >= RB || vcol >= NV) return;
-    const int c = vcol * V;
+    const bool act = rl < RB && vcol < NV;      // (idle threads stay for the wave reduction of amax at the end)
+    if (!act && amax == nullptr) return;
+    const int c = act ? vcol * V : 0;
+    uint32_t amx = 0;                  // largest |dy| this thread stores (dml_h2_split with amax_known)
     float cA[V], cB[V], cC[V], cM[V];
 #pragma unroll
     for (int q = 0; q < V; ++q) {
@@ -410,9 +436,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
         cC[q] = coef[2 * N + c + q];
         cM[q] = coef[3 * N + c + q];
     }
-    const bool use_mask = V == 8 && mask != nullptr;
+    const bool use_mask = mask != nullptr;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
-    const int64_t r1 = min(M, r0 + rows_per_block);
+    const int64_t r1 = act ? min(M, r0 + rows_per_block) : 0;
     for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)RB * U) {
         float g[U][V], yy[U][V], zz[U][V], rr[U][V];
         uint32_t bits[U];
@@ -444,6 +470,10 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
 #pragma unroll
             for (int q = 0; q < V; ++q) o[q] = cA[q] * g[u][q] + cB[q] * (yy[u][q] - cM[q]) + cC[q];
             Vec16<T>::store(dy + m * lddy + c, o);
+            if (amax != nullptr) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) amx = max(amx, __float_as_uint(o[q]) & 0x7fffffffu);
+            }
             if (dres != nullptr) {
 #pragma unroll
                 for (int q = 0; q < V; ++q) g[u][q] = g[u][q] * gscale + (dres_accum ? rr[u][q] : 0.f);
@@ -451,6 +481,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
             }
         }
     }
+    if (amax != nullptr) amax_publish(amx, amax);
 }
 
 // Large feature maps (G >= 2048 row groups): two coalesced stages instead of one strided walk per channel.
@@ -597,7 +628,7 @@ extern "C" int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, v
 
 extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
                             const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
-                            int dtype, float drop_p, uint64_t drop_seed, void* stream) {
+                            int dtype, float drop_p, uint64_t drop_seed, float* amax, void* stream) {
     if (!y || !z || !scale || !shift || !mean || M <= 0 || N <= 0) return DML_EINVAL;
     if (!vec_ok(dtype, N) || !vec_ok(dtype, ldy) || !vec_ok(dtype, ldz) || (res && !vec_ok(dtype, ldres)))
         return DML_EALIGN;
@@ -609,11 +640,11 @@ extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float
     if (dtype == DML_BF16)
         hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)y, (const bf16_t*)res,
                            (bf16_t*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
-                           g.rows_per_block);
+                           g.rows_per_block, reinterpret_cast<uint32_t*>(amax));
     else
         hipLaunchKernelGGL((bn_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)y, (const float*)res,
-                           (float*)z, scale, shift, mean, nullptr, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
-                           g.rows_per_block);
+                           (float*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
+                           g.rows_per_block, reinterpret_cast<uint32_t*>(amax));
     DML_LAUNCH_CHECK();
     return 0;
 }
@@ -622,7 +653,6 @@ extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
                                  const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
                                  int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream) {
     if (!dz || !y || !save_mean || !save_invstd || !partials || !nblocks || M <= 0 || N <= 0) return DML_EINVAL;
-    if (dtype != DML_BF16) mask = nullptr;
     if (relu && !z && !mask) return DML_EINVAL;
     if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || (relu && !mask && !vec_ok(dtype, ldz)))
         return DML_EALIGN;
@@ -644,7 +674,7 @@ extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
                            ldz, relu, gscale, (int)rpb, chv, rt);
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz,
-                           (const float*)y, (const float*)z, nullptr, save_mean, save_invstd, partials, M, N, lddz, ldy,
+                           (const float*)y, (const float*)z, mask, save_mean, save_invstd, partials, M, N, lddz, ldy,
                            ldz, relu, gscale, (int)rpb, chv, rt);
     DML_LAUNCH_CHECK();
     return 0;
@@ -757,9 +787,8 @@ extern "C" int dml_bn_bwd_coef(const double* sums, int64_t M_total, int N, const
 
 extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* coef, void* dy,
                                 void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
-                                int relu, float gscale, int dres_accum, int dtype, void* stream) {
+                                int relu, float gscale, int dres_accum, int dtype, float* amax, void* stream) {
     if (!dz || !y || !coef || !dy || M <= 0 || N <= 0) return DML_EINVAL;
-    if (dtype != DML_BF16) mask = nullptr;
     if (relu && !z && !mask) return DML_EINVAL;
     if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || !vec_ok(dtype, lddy) ||
         (relu && !mask && !vec_ok(dtype, ldz)) || (dres && !vec_ok(dtype, lddres)))
@@ -772,11 +801,12 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     if (dtype == DML_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)dz,
                            (const bf16_t*)y, (const bf16_t*)z, mask, coef, (bf16_t*)dy, (bf16_t*)dres, M, N, lddz, ldy,
-                           ldz, lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block);
+                           ldz, lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block,
+                           reinterpret_cast<uint32_t*>(amax));
     else
         hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)dz,
-                           (const float*)y, (const float*)z, nullptr, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
-                           lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block);
+                           (const float*)y, (const float*)z, mask, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
+                           lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block, reinterpret_cast<uint32_t*>(amax));
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -39,6 +39,12 @@ struct ConvArgs {
     uint32_t x_bytes, w_bytes;   // operand extents for the buffer descriptors (fast path: both < 2^31)
     int w_tiled;                 // weights in the tile-major layout (DmlConvDesc::w_tiled): LDS-DMA kernels only
     int ws_min_tiles;            // DmlConvDesc::ws_min_tiles
+    // f32_split == 2: operands as two fp16 planes of the power-of-two-scaled fp32 tensors (DmlConvDesc::x_planes ...)
+    const void* x_planes;
+    const void* w_planes;
+    const float* x_unscale;      // device scalars: 1 / scale of the operand (dml_h2_split)
+    const float* w_unscale;
+    uint32_t x_plane_bytes, w_plane_bytes;      // distance from the hi plane to the lo plane
     // data-gradient mode: BN-backward partial sums of the tensor being written (DmlConvDesc::bnr_*)
     const void* bnr_y;
     const uint8_t* bnr_mask;
@@ -1336,20 +1342,23 @@ __device__ __forceinline__ uint32_t ws_ld(const uint32_t* p) { return __hip_atom
 __device__ __forceinline__ void ws_st(uint32_t* p, const uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 
 // loader wave LW of NLD: compile-time piece ownership (no branches in the issue loop)
-template <int MW, int NW, int MODE, int NLD, int LW>
+// PL = 2: every operand tile is two planes (hi, lo fp16 of the scaled fp32 tensor); a stage = [A hi | A lo | B hi | B lo]
+template <int MW, int NW, int MODE, int NLD, int LW, int PL>
 __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t x_bytes, const uint32_t w_bytes, char* smem,
                                                uint32_t* ready, uint32_t* consumed, const int lane, const int ntiles,
                                                const int first_tile) {
     typedef bf16_t T;
     constexpr int NCW = 4, NT = 4;
     constexpr int BM = 16 * WS_MT * MW, BN = 64 * NW;
-    constexpr int PA = BM / 16, PB = BN / 16, NP = PA + PB;
-    constexpr int SB = (BM + BN) * BK * 2;
+    constexpr int PA = BM / 16, PB = BN / 16, NP = PL * (PA + PB);
+    constexpr int SB = PL * (BM + BN) * BK * 2;
     constexpr int MYP = (NP - LW + NLD - 1) / NLD;
-    constexpr int NST = WS_NST, D = WS_D;
+    constexpr int NST = PL == 1 ? WS_NST : 3, D = PL == 1 ? WS_D : 1;
     constexpr uint32_t OOB = 0x80000000u;
     static_assert(D * MYP <= 63, "vmcnt is a 6-bit counter");
-    const u32x4_ws rs_x = ws_make_rsrc(a.x, x_bytes), rs_w = ws_make_rsrc(a.w, w_bytes);
+    // (PL = 2: the descriptors span both planes; the lo plane is reached through the scalar offset)
+    const u32x4_ws rs_x = ws_make_rsrc(PL == 1 ? a.x : a.x_planes, PL == 1 ? x_bytes : x_bytes + a.x_plane_bytes),
+                   rs_w = ws_make_rsrc(PL == 1 ? a.w : a.w_planes, PL == 1 ? w_bytes : w_bytes + a.w_plane_bytes);
     const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
     const int prow = lane >> 2;
     const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
@@ -1369,12 +1378,12 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
         prev_blk_m = blk_m;
 #pragma unroll
         for (int q = 0; q < MYP; ++q) {
-            const int p = q * NLD + LW;
-            if (p < PA) {
+            const int p = q * NLD + LW;             // piece of the stage: [PL x PA activation pieces | PL x PB weight pieces]
+            if (p < PL * PA) {
                 if (!new_rows) continue;
                 base[q] = 0;
                 mask[q] = 0;
-                const int m = m0 + p * 16 + prow;
+                const int m = m0 + (p % PA) * 16 + prow;
                 if (m < a.M) {
                     const uint32_t b = fdiv((uint32_t)m, a.div_howo);
                     const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
@@ -1401,7 +1410,7 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
                     mask[q] = mk;
                 }
             } else {
-                const int row = (p - PA) * 16 + prow, n = n0 + row;
+                const int row = ((p - PL * PA) % PB) * 16 + prow, n = n0 + row;
                 const int bchunk = swz_chunk<T>(b_rho<NT>(row & 63), lane & 3);
                 base[q] = n < a.N ? (int)((((int64_t)(n >> 6) * KT) * 2048 + (n & 63) * 32 + bchunk * 8) * 2) : (int)OOB;
             }
@@ -1427,11 +1436,12 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
 #pragma unroll
             for (int q = 0; q < MYP; ++q) {
                 const int p = q * NLD + LW;
-                if (p < PA) {
+                if (p < PL * PA) {
                     const uint32_t voff = (mask[q] & tapbit) ? (uint32_t)(base[q] + soff) : OOB;
-                    ws_dma16(rs_x, sbase + p * 1024, voff, 0u);
+                    ws_dma16(rs_x, sbase + p * 1024, voff, p < PA ? 0u : a.x_plane_bytes);
                 } else {
-                    ws_dma16(rs_w, sbase + p * 1024, (uint32_t)base[q], (uint32_t)kt * 4096u);
+                    ws_dma16(rs_w, sbase + p * 1024, (uint32_t)base[q],
+                             (uint32_t)kt * 4096u + ((p - PL * PA) < PB ? 0u : a.w_plane_bytes));
                 }
             }
             ic0 += BK;
@@ -1450,13 +1460,15 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
     ws_st(ready + LW, g);
 }
 
-template <int MW, int NW, int MODE, int NLD>
+typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
+
+template <int MW, int NW, int MODE, int NLD, int PL = 1>
 __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs a, const uint32_t x_bytes, const uint32_t w_bytes) {
     typedef bf16_t T;
     static_assert(MW * NW == 4, "four consumer waves, one per SIMD");
-    constexpr int NCW = 4, NT = 4, MT = WS_MT, NST = WS_NST;
+    constexpr int NCW = 4, NT = 4, MT = WS_MT, NST = PL == 1 ? WS_NST : 3;
     constexpr int BM = 16 * MT * MW, BN = 64 * NW;
-    constexpr int SB = (BM + BN) * BK * 2;
+    constexpr int SB = PL * (BM + BN) * BK * 2;
     __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64];
     uint32_t* const ready = reinterpret_cast<uint32_t*>(smem + NST * SB);          // [NLD] stages landed, per loader
     uint32_t* const consumed = ready + 4;                                          // [4] stages whose reads were issued
@@ -1472,10 +1484,10 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 
     if (wave >= NCW) {
         const int lw = wave - NCW;
-        if (lw == 0) conv_ws_loader<MW, NW, MODE, NLD, 0>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
-        if (NLD > 1 && lw == 1) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 1 ? 1 : 0)>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
-        if (NLD > 2 && lw == 2) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 2 ? 2 : 0)>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
-        if (NLD > 3 && lw == 3) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 3 ? 3 : 0)>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (lw == 0) conv_ws_loader<MW, NW, MODE, NLD, 0, PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 1 && lw == 1) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 1 ? 1 : 0), PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 2 && lw == 2) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 2 ? 2 : 0), PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 3 && lw == 3) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 3 ? 3 : 0), PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
         return;
     }
 
@@ -1496,11 +1508,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         }
         asm volatile("" ::: "memory");
     };
-    int a_off[MT], b_off[NT];          // fragment byte offsets inside a stage
+    int a_off[MT], b_off[NT];          // fragment byte offsets inside a stage (hi plane; the lo plane is BM / BN rows further)
 #pragma unroll
     for (int j = 0; j < MT; ++j) a_off[j] = (wm * (16 * MT) + j * 16 + lr) * (BK * 2) + swz_chunk<T>(j * 16 + lr, lq) * 16;
 #pragma unroll
-    for (int i = 0; i < NT; ++i) b_off[i] = BM * BK * 2 + (wn * 64 + b_row<NT>(i, lr)) * (BK * 2) + swz_chunk<T>(lr, lq) * 16;
+    for (int i = 0; i < NT; ++i) b_off[i] = PL * BM * BK * 2 + (wn * 64 + b_row<NT>(i, lr)) * (BK * 2) + swz_chunk<T>(lr, lq) * 16;
+    constexpr int A_PLANE = BM * BK * 2, B_PLANE = BN * BK * 2;      // bytes from the hi plane to the lo plane inside a stage
 
     for (int tile = first_tile; tile < ntiles; tile += (int)gridDim.x) {
         const int blk_m = tile % a.nblk_m, blk_n = tile / a.nblk_m;
@@ -1510,49 +1523,93 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 #pragma unroll
             for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-        mfma_bf16x8 bfA[NT], bfB[NT], af[MT], alA, alB;       // af[MT - 1] unused: the last A fragment alternates alA / alB
-        wait_ready(g + 1);                                      // first K step of the tile: exposed once per tile
-        {
-            const char* sb = smem + (g % NST) * SB;
+        if constexpr (PL == 1) {
+            mfma_bf16x8 bfA[NT], bfB[NT], af[MT], alA, alB;       // af[MT - 1] unused: the last A fragment alternates alA / alB
+            wait_ready(g + 1);                                      // first K step of the tile: exposed once per tile
+            {
+                const char* sb = smem + (g % NST) * SB;
 #pragma unroll
-            for (int i = 0; i < NT; ++i) bfA[i] = *reinterpret_cast<const mfma_bf16x8*>(sb + b_off[i]);
+                for (int i = 0; i < NT; ++i) bfA[i] = *reinterpret_cast<const mfma_bf16x8*>(sb + b_off[i]);
 #pragma unroll
-            for (int j = 0; j < MT - 1; ++j) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sb + a_off[j]);
-            alA = *reinterpret_cast<const mfma_bf16x8*>(sb + a_off[MT - 1]);
-        }
-        // one K step: MFMAs of step g from (bc, af, alc); the fragments of step g + 1 into (bn, af, aln) as registers free up
-        auto step = [&](mfma_bf16x8 (&bc)[NT], mfma_bf16x8 (&bn)[NT], mfma_bf16x8& alc, mfma_bf16x8& aln, const bool has_next) {
-            asm volatile("" ::: "memory");
-            ws_st(consumed + wave, g + 1);         // every read of stage g has been issued (DS runs a wave's operations in order)
-            const char* sn = smem + ((g + 1) % NST) * SB;
-            if (has_next) {
-                wait_ready(g + 2);
-#pragma unroll
-                for (int i = 0; i < NT; ++i) bn[i] = *reinterpret_cast<const mfma_bf16x8*>(sn + b_off[i]);
-                aln = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[MT - 1]);
+                for (int j = 0; j < MT - 1; ++j) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sb + a_off[j]);
+                alA = *reinterpret_cast<const mfma_bf16x8*>(sb + a_off[MT - 1]);
             }
+            // one K step: MFMAs of step g from (bc, af, alc); the fragments of step g + 1 into (bn, af, aln) as registers free up
+            auto step = [&](mfma_bf16x8 (&bc)[NT], mfma_bf16x8 (&bn)[NT], mfma_bf16x8& alc, mfma_bf16x8& aln, const bool has_next) {
+                asm volatile("" ::: "memory");
+                ws_st(consumed + wave, g + 1);         // every read of stage g has been issued (DS runs a wave's operations in order)
+                const char* sn = smem + ((g + 1) % NST) * SB;
+                if (has_next) {
+                    wait_ready(g + 2);
 #pragma unroll
-            for (int j = 0; j < MT - 1; ++j) {
+                    for (int i = 0; i < NT; ++i) bn[i] = *reinterpret_cast<const mfma_bf16x8*>(sn + b_off[i]);
+                    aln = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[MT - 1]);
+                }
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], af[j], acc[i][j], 0, 0, 0);
-                if (has_next) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[j]);
-                if (j == (MT - 1) / 2) rflag = read_ready();      // the next step's poll, answered under the MFMAs
+                for (int j = 0; j < MT - 1; ++j) {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], af[j], acc[i][j], 0, 0, 0);
+                    if (has_next) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[j]);
+                    if (j == (MT - 1) / 2) rflag = read_ready();      // the next step's poll, answered under the MFMAs
+                }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][MT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], alc, acc[i][MT - 1], 0, 0, 0);
+                ++g;
+            };
+            int kt = 0;
+            for (; kt + 1 < KT; kt += 2) {
+                step(bfA, bfB, alA, alB, true);
+                step(bfB, bfA, alB, alA, kt + 2 < KT);
             }
+            if (kt < KT) step(bfA, bfB, alA, alB, false);
+        } else {
+            // two fp16 planes per operand: x s = xh + xl, w t = wh + wl; per 16 x 16 x 32 block the three products wl xh, wh xl,
+            // wh xh (the dropped wl xl is below 2^-22 of the block) -- 108 MFMAs per K step against 26 fragment reads.  The
+            // weight fragments of a step are read at its start (exposed: ~8 % of the step), the activation fragments of row
+            // group j + 1 under the twelve MFMAs of group j.
+            for (int kt = 0; kt < KT; ++kt) {
+                wait_ready(g + 1);
+                const char* sb = smem + (g % NST) * SB;
+                mfma_f16x8 bh[NT], bl[NT], ah[2], al[2];
 #pragma unroll
-            for (int i = 0; i < NT; ++i) acc[i][MT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], alc, acc[i][MT - 1], 0, 0, 0);
-            ++g;
-        };
-        int kt = 0;
-        for (; kt + 1 < KT; kt += 2) {
-            step(bfA, bfB, alA, alB, true);
-            step(bfB, bfA, alB, alA, kt + 2 < KT);
+                for (int i = 0; i < NT; ++i) {
+                    bh[i] = *reinterpret_cast<const mfma_f16x8*>(sb + b_off[i]);
+                    bl[i] = *reinterpret_cast<const mfma_f16x8*>(sb + b_off[i] + B_PLANE);
+                }
+                ah[0] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[0]);
+                al[0] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[0] + A_PLANE);
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    if (j + 1 < MT) {
+                        ah[(j + 1) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1]);
+                        al[(j + 1) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1] + A_PLANE);
+                    } else {
+                        asm volatile("" ::: "memory");
+                        ws_st(consumed + wave, g + 1);      // every read of stage g has been issued
+                    }
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[i], ah[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[i], al[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[i], ah[j & 1], acc[i][j], 0, 0, 0);
+                    if (j == MT / 2) rflag = read_ready();      // the next step's poll, answered under the MFMAs
+                }
+                ++g;
+            }
         }
-        if (kt < KT) step(bfA, bfB, alA, alB, false);
         // cut the accumulators' live ranges (see conv_igemm_kernel), then the shared epilogue per 48-row group
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
             for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+        if constexpr (PL == 2) {
+            const float un = a.x_unscale[0] * a.w_unscale[0];      // exact powers of two
+#pragma unroll
+            for (int i = 0; i < NT; ++i)
+#pragma unroll
+                for (int j = 0; j < MT; ++j) acc[i][j] *= un;
+        }
         // (three explicit copies: hipcc does not unroll a loop around the inlined epilogue, and a run-time index into acc
         // sends all 36 accumulator fragments through scratch memory -- 37 MB written and read back per launch, +25 us)
         auto epi = [&](auto hc) {
@@ -1562,7 +1619,9 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             for (int i = 0; i < NT; ++i)
 #pragma unroll
                 for (int j = 0; j < 3; ++j) sub[i][j] = acc[i][h * 3 + j];
-            conv_epilogue<T, NT, 3, MODE, false>(sub, a, blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, blk_n * BN + wn * 64, lr, lq);
+            const int mw0 = blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, nw0 = blk_n * BN + wn * 64;
+            if constexpr (PL == 1) conv_epilogue<bf16_t, NT, 3, MODE, false>(sub, a, mw0, nw0, lr, lq);
+            else conv_epilogue<float, NT, 3, MODE, false>(sub, a, mw0, nw0, lr, lq);
         };
         static_assert(MT == 9, "three 48-row groups per wave tile");
         epi(std::integral_constant<int, 0>{});
@@ -1585,6 +1644,14 @@ static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t 
     const int bn = (a.N % 256) == 0 ? 256 : 128, bm = (a.N % 256) == 0 ? 144 : 288;
     const int64_t ntiles = ((int64_t)a.M + bm - 1) / bm * (a.N / bn);
     return ntiles >= (a.ws_min_tiles > 0 ? a.ws_min_tiles : 192);
+}
+// the same kernel on two fp16 planes per operand (fp32 tensors, f32_split == 2): every shape it can address -- the alternative
+// is the three-term split kernel at a third of its rate
+static bool conv_ws_planes_eligible(const ConvArgs& a) {
+    if (a.f32_split != 2 || !a.x_planes || !a.w_planes || !a.x_unscale || !a.w_unscale) return false;
+    if ((a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 64) != 0 || a.N < 128) return false;      // (N = 320: the decoder's data gradient)
+    const int64_t xb = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2, wb = (int64_t)a.N * a.Ktot * 2;
+    return xb + a.x_plane_bytes < (1ll << 31) && wb + a.w_plane_bytes < (1ll << 31);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -1797,6 +1864,12 @@ struct WgradArgs {
     int slab_tiles;   // K tiles (of 32 pixels) per split
     float* ws;        // optional split-K workspace [splits][N][Ktot]: plain stores instead of atomics
     FastDiv div_wo, div_howo, div_c;
+    // f32_split == 2: fp16 hi / lo planes of both operands (DmlWgradDesc::x_planes ...)
+    const void* x_planes;
+    const void* dy_planes;
+    const float* x_unscale;
+    const float* dy_unscale;
+    uint32_t x_plane_bytes, dy_plane_bytes;
 };
 
 template <typename T> struct WgLds;
@@ -2146,6 +2219,163 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
                         a.ws[((int64_t)split * a.N + n) * a.Ktot + k] = acc[i][j][q];
                     else
                         atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q]);
+                }
+            }
+        }
+}
+
+// ------------------------------------------------------------------------------------------------
+// fp32 weight gradient with the products on the fp16 matrix cores: both operands as two fp16 planes of the scaled tensors
+// (dml_h2_split; DmlWgradDesc.x_planes / dy_planes).  conv_wgrad_kernel<bf16_t>'s 128 x 128 tile, sub-tiled LDS image and
+// ds_read_b64_tr_b16 fragments, with four operand planes per stage and three MFMA groups per 32-pixel K step
+// (dy_l x_h, dy_h x_l, dy_h x_h): 48 MFMAs per wave against 16 bytes x 8 loads per thread -- no VALU split in the loop, the
+// planes were written once by the producer of the tensor.  Double-buffered LDS (68 KB: two workgroups per CU), loads of step
+// t + 1 in registers while step t computes.  Same split-K / workspace scheme as the other weight-gradient kernels.
+// ------------------------------------------------------------------------------------------------
+template <bool LIN>      // LIN: 1x1, stride 1, no padding -- pixel row m of x is output row m
+__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_h2_kernel(
+    const WgradArgs a, const uint32_t x_bytes, const uint32_t dy_bytes) {
+    constexpr int TILE = 128, CV = TILE / 8, RPP = NTHREADS / CV, LD = BK / RPP;       // 16 vectors per row, 16 rows per pass, 2 loads
+    constexpr int SUB = 528, PLN = (TILE / 16) * SUB;                                  // fp16 elements per operand plane and stage
+    constexpr int MT = 4, NT = 4;
+    constexpr uint32_t OOB = 0x80000000u;
+    typedef _Float16 f16_t;
+    __shared__ __attribute__((aligned(16))) f16_t smem[2 * 4 * PLN];                   // [buf][dy hi, dy lo, x hi, x lo]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave >> 1, wk = wave & 1;
+    const int ntile = a.nblk_n * a.nblk_k;
+    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    const int split = logical / ntile, tile_id = logical - split * ntile;
+    const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
+    const int n0 = blk_n * TILE, kc0 = blk_k * TILE;
+    // descriptors span both planes; the lo plane is reached through the scalar offset
+    const __amdgpu_buffer_rsrc_t rs_x =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x_planes), 0, (int)(x_bytes + a.x_plane_bytes), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_y =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.dy_planes), 0, (int)(dy_bytes + a.dy_plane_bytes), 0x00020000);
+    const int vcol = tid % CV, prow = tid / CV;
+    const int kc = kc0 + vcol * 8;
+    const bool kc_ok = kc < a.Ktot;
+    const uint32_t tap = fdiv((uint32_t)(kc_ok ? kc : 0), a.div_c);
+    const int xc = (kc_ok ? kc : 0) - (int)tap * a.C;
+    const int tr = (int)tap / a.S, ts = (int)tap - tr * a.S;
+    const int dyo = tr * a.dil - a.pad, dxo = ts * a.dil - a.pad;
+    const int yn = n0 + vcol * 8;
+    const bool yn_ok = yn < a.N;
+    const int tile_beg = split * a.slab_tiles;
+    const int tiles_total = (a.M + BK - 1) / BK;
+    const int tile_end = min(tiles_total, tile_beg + a.slab_tiles);
+
+    typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+    u32x4_t yh_r[LD], yl_r[LD], xh_r[LD], xl_r[LD];
+    auto load_row = [&](int t, int j) {
+        const int m = t * BK + prow + j * RPP;
+        const bool mv = t < tile_end && m < a.M;
+        uint32_t xo_b;
+        bool xv = mv && kc_ok;
+        if (LIN) {
+            xo_b = ((uint32_t)m * (uint32_t)a.ldx + (uint32_t)xc) * 2u;
+        } else {
+            const uint32_t b = fdiv((uint32_t)m, a.div_howo);
+            const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
+            const uint32_t yo = fdiv(rem, a.div_wo);
+            const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+            const int ys = (int)yo * a.stride + dyo, xs = (int)xo * a.stride + dxo;
+            xv = xv && (unsigned)ys < (unsigned)a.Hi && (unsigned)xs < (unsigned)a.Wi;
+            xo_b = ((uint32_t)(((int)b * a.Hi + ys) * a.Wi + xs) * (uint32_t)a.ldx + (uint32_t)xc) * 2u;
+        }
+        const uint32_t yo_b = ((uint32_t)m * (uint32_t)a.ldy + (uint32_t)yn) * 2u;
+        const int yoff = (int)((mv && yn_ok) ? yo_b : OOB), xoff = (int)(xv ? xo_b : OOB);
+        yh_r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, yoff, 0, 0);
+        yl_r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_y, yoff, (int)a.dy_plane_bytes, 0);
+        xh_r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, 0, 0);
+        xl_r[j] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, xoff, (int)a.x_plane_bytes, 0);
+    };
+    // conv_wgrad_kernel<bf16_t>'s image: 16-column sub-tiles [col / 16][k'][16], k rows with bits 2 / 3 swapped
+    auto store_tiles = [&](int buf) {
+        f16_t* base = smem + buf * 4 * PLN;
+#pragma unroll
+        for (int j = 0; j < LD; ++j) {
+            const int row = prow + j * RPP;
+            const int prow_ = (row & 0x13) | (((row >> 3) & 1) << 2) | (((row >> 2) & 1) << 3);
+            const int off = (vcol >> 1) * SUB + prow_ * 16 + (vcol & 1) * 8;
+            *reinterpret_cast<u32x4_t*>(base + off) = yh_r[j];
+            *reinterpret_cast<u32x4_t*>(base + PLN + off) = yl_r[j];
+            *reinterpret_cast<u32x4_t*>(base + 2 * PLN + off) = xh_r[j];
+            *reinterpret_cast<u32x4_t*>(base + 3 * PLN + off) = xl_r[j];
+        }
+    };
+    f32x4 acc[NT][MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (tile_beg < tile_end) {
+#pragma unroll
+        for (int j = 0; j < LD; ++j) load_row(tile_beg, j);
+        store_tiles(0);
+    }
+    __syncthreads();
+    const int lr = lane & 15, lq = lane >> 4;
+    const int p_lo = ((lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4)) * 16 + (lr & 3) * 4;
+    const int p_hi = p_lo + 8 * 16;
+    auto frag = [&](const f16_t* p) -> mfma_f16x8 {
+        const bf16x4 lo = lds_tr16_b64(reinterpret_cast<const bf16_t*>(p + p_lo));
+        const bf16x4 hi = lds_tr16_b64(reinterpret_cast<const bf16_t*>(p + p_hi));
+        const bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(mfma_f16x8, v);
+    };
+    int cur = 0;
+    for (int t = tile_beg; t < tile_end; ++t) {
+        const bool has_next = t + 1 < tile_end;
+        if (has_next) {
+#pragma unroll
+            for (int j = 0; j < LD; ++j) load_row(t + 1, j);
+        }
+        const f16_t* sb = smem + cur * 4 * PLN;
+        mfma_f16x8 yh[NT], yl[NT], xh[MT], xl[MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i) {
+            yh[i] = frag(sb + (wn * 4 + i) * SUB);
+            yl[i] = frag(sb + PLN + (wn * 4 + i) * SUB);
+        }
+#pragma unroll
+        for (int j = 0; j < MT; ++j) {
+            xh[j] = frag(sb + 2 * PLN + (wk * 4 + j) * SUB);
+            xl[j] = frag(sb + 3 * PLN + (wk * 4 + j) * SUB);
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl[i], xh[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh[i], xl[j], acc[i][j], 0, 0, 0);
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh[i], xh[j], acc[i][j], 0, 0, 0);
+        if (has_next) store_tiles(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+    }
+    const float un = a.x_unscale[0] * a.dy_unscale[0];      // exact powers of two
+    // acc[i][j][q] = dw[n = n0 + wn*64 + i*16 + lq*4 + q][kc = kc0 + wk*64 + j*16 + lr]
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int n = n0 + wn * 64 + i * 16 + lq * 4 + q;
+            if (n >= a.N) continue;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                const int k = kc0 + wk * 64 + j * 16 + lr;
+                if (k < a.Ktot) {
+                    if (a.ws != nullptr)
+                        a.ws[((int64_t)split * a.N + n) * a.Ktot + k] = acc[i][j][q] * un;
+                    else
+                        atomicAdd(a.dw + (int64_t)n * a.Ktot + k, acc[i][j][q] * un);
                 }
             }
         }
@@ -2784,7 +3014,24 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
     }
     if (a.w_tiled) return DML_EUNSUPPORTED;      // tile-major weights: only the LDS-DMA kernels above read them
     if constexpr (sizeof(T) == 4 && MODE != 2) {
-        if (a.f32_split && aligned && a.N > 32) {
+        if (conv_ws_planes_eligible(a)) {
+            // fp32 tensors, products of two fp16 planes per operand on the matrix cores (DmlConvDesc.x_planes ...)
+            constexpr int CUS = 256, NLD = 3;
+            const bool wide = (a.N % 256) == 0;
+            const int bm = wide ? 144 : 288;
+            a.nblk_m = (a.M + bm - 1) / bm;
+            a.nblk_n = wide ? a.N / 256 : (a.N + 127) / 128;      // (a last 128-wide block may be half empty: zero rows, no stores)
+            const int ntiles = a.nblk_m * a.nblk_n;
+            const int grid = ntiles < CUS ? ntiles : CUS;
+            const uint32_t xpb = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2), wpb = (uint32_t)((int64_t)a.N * a.Ktot * 2);
+            if (wide)
+                hipLaunchKernelGGL((conv_ws_kernel<1, 4, MODE, NLD, 2>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+            else
+                hipLaunchKernelGGL((conv_ws_kernel<2, 2, MODE, NLD, 2>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+            DML_LAUNCH_CHECK();
+            return 0;
+        }
+        if (a.f32_split && aligned && a.N > 32) {      // (f32_split == 2 launches the planes kernel did not take: three-term split)
             static const int x3bn = getenv("DML_X3_BN") ? atoi(getenv("DML_X3_BN")) : 128;
             if (a.N > 64 && x3bn != 64) {
                 a.nblk_n = (a.N + 127) / 128;
@@ -2831,10 +3078,20 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
 // wave-specialised kernel takes it, DML_STAT_ROWS otherwise.  The caller sizes the partial buffers with it and passes it on to
 // dml_bn_finalize_rows / dml_bn_moments_rows (the BN-backward finalize only needs the group count).
 extern "C" int dml_conv_stat_rows(const DmlConvDesc* d) {
-    if (!d || d->dtype != DML_BF16 || !d->w_tiled) return DML_STAT_ROWS;
+    if (!d) return DML_STAT_ROWS;
     ConvArgs a;
-    a.w_tiled = 1; a.C = d->C; a.R = d->R; a.S = d->S; a.N = d->N; a.ws_min_tiles = d->ws_min_tiles;
+    a.w_tiled = d->w_tiled; a.C = d->C; a.R = d->R; a.S = d->S; a.N = d->N; a.ws_min_tiles = d->ws_min_tiles;
+    a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.ldx = d->ldx;
     a.M = d->B * d->Ho * d->Wo;
+    a.Ktot = d->R * d->S * d->C;
+    if (d->dtype == DML_F32) {
+        a.f32_split = d->f32_split; a.x_planes = d->x_planes; a.w_planes = d->w_planes;
+        a.x_unscale = d->x_unscale; a.w_unscale = d->w_unscale;
+        a.x_plane_bytes = (uint32_t)(d->x_plane_stride * 2); a.w_plane_bytes = (uint32_t)(d->w_plane_stride * 2);
+        return (d->x_plane_stride < (1ll << 30) && d->w_plane_stride < (1ll << 30) && conv_ws_planes_eligible(a)) ? WS_STAT_ROWS
+                                                                                                                   : DML_STAT_ROWS;
+    }
+    if (d->dtype != DML_BF16 || !d->w_tiled) return DML_STAT_ROWS;
     const int64_t xb = ((int64_t)(d->B * d->Hi) * d->Wi - 1) * d->ldx * 2 + (int64_t)d->C * 2;
     const int64_t wb = (int64_t)d->N * d->R * d->S * d->C * 2;
     static const bool use_v1 = getenv("DML_CONV_V1") != nullptr;
@@ -2860,7 +3117,19 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
-    a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = (d->dtype == DML_F32 && d->f32_split) ? 1 : 0;
+    a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = d->dtype == DML_F32 ? d->f32_split : 0;
+    if (a.f32_split < 0 || a.f32_split > 2) return DML_EINVAL;
+    a.x_planes = nullptr; a.w_planes = nullptr; a.x_unscale = nullptr; a.w_unscale = nullptr; a.x_plane_bytes = a.w_plane_bytes = 0;
+    if (a.f32_split == 2 && d->x_planes && d->w_planes) {
+        if (!d->x_unscale || !d->w_unscale || d->x_plane_stride <= 0 || d->w_plane_stride <= 0 ||
+            d->x_plane_stride >= (1ll << 30) || d->w_plane_stride >= (1ll << 30))
+            return DML_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(d->x_planes) & 15) || (reinterpret_cast<uintptr_t>(d->w_planes) & 15) ||
+            (d->x_plane_stride & 7) || (d->w_plane_stride & 7))
+            return DML_EALIGN;
+        a.x_planes = d->x_planes; a.w_planes = d->w_planes; a.x_unscale = d->x_unscale; a.w_unscale = d->w_unscale;
+        a.x_plane_bytes = (uint32_t)(d->x_plane_stride * 2); a.w_plane_bytes = (uint32_t)(d->w_plane_stride * 2);
+    }
     a.w_tiled = 0;
     a.ws_min_tiles = d->ws_min_tiles;
     if (d->w_tiled) {
@@ -2957,6 +3226,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
     a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = 0;
     a.w_tiled = 0; a.ws_min_tiles = 0;
+    a.x_planes = nullptr; a.w_planes = nullptr; a.x_unscale = nullptr; a.w_unscale = nullptr; a.x_plane_bytes = a.w_plane_bytes = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);
     a.w_bytes = (uint32_t)((int64_t)a.N * a.Ktot * 2);
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -2996,6 +3266,22 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     a.div_wo = make_fastdiv((uint32_t)d->Wo);
     a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
+    a.x_planes = nullptr; a.dy_planes = nullptr; a.x_unscale = nullptr; a.dy_unscale = nullptr; a.x_plane_bytes = a.dy_plane_bytes = 0;
+    bool planes = false;
+    if (d->dtype == DML_F32 && d->f32_split == 2 && d->x_planes && d->dy_planes) {
+        if (!d->x_unscale || !d->dy_unscale || d->x_plane_stride <= 0 || d->dy_plane_stride <= 0) return DML_EINVAL;
+        if ((reinterpret_cast<uintptr_t>(d->x_planes) & 15) || (reinterpret_cast<uintptr_t>(d->dy_planes) & 15) ||
+            (d->x_plane_stride & 7) || (d->dy_plane_stride & 7))
+            return DML_EALIGN;
+        const int64_t xpb = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2, ypb = (((int64_t)a.M - 1) * a.ldy + a.N) * 2;
+        // fp16 vectors of 8: C, N, pitches multiples of 8; both planes within 31-bit offsets
+        planes = d->C % 8 == 0 && d->N % 8 == 0 && d->ldx % 8 == 0 && d->ldy % 8 == 0 && xpb + d->x_plane_stride * 2 < 0x7fffffffll &&
+                 ypb + d->dy_plane_stride * 2 < 0x7fffffffll;
+        if (planes) {
+            a.x_planes = d->x_planes; a.dy_planes = d->dy_planes; a.x_unscale = d->x_unscale; a.dy_unscale = d->dy_unscale;
+            a.x_plane_bytes = (uint32_t)(d->x_plane_stride * 2); a.dy_plane_bytes = (uint32_t)(d->dy_plane_stride * 2);
+        }
+    }
     const int tiles = (a.M + BK - 1) / BK;
     const int cm = d->Cm > 0 ? d->Cm : d->C;
     if (cm > d->C) return DML_EINVAL;
@@ -3101,7 +3387,13 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     // split-product kernel: operands through buffer descriptors (32-bit byte offsets)
     const int64_t x3_xb = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 4, x3_yb = (((int64_t)a.M - 1) * a.ldy + a.N) * 4;
     const bool x3_ok = x3_xb < (int64_t)0x7fffffff && x3_yb < (int64_t)0x7fffffff;
-    if (n64)
+    if (planes) {
+        const uint32_t xpb = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2), ypb = (uint32_t)((((int64_t)a.M - 1) * a.ldy + a.N) * 2);
+        if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0)
+            hipLaunchKernelGGL(conv_wgrad_h2_kernel<true>, grid, dim3(NTHREADS), 0, st, a, xpb, ypb);
+        else
+            hipLaunchKernelGGL(conv_wgrad_h2_kernel<false>, grid, dim3(NTHREADS), 0, st, a, xpb, ypb);
+    } else if (n64)
         hipLaunchKernelGGL(conv_wgrad_n64_kernel, grid, dim3(NTHREADS), 0, st, a);
     else if (d->dtype == DML_BF16)
         hipLaunchKernelGGL(conv_wgrad_kernel<bf16_t>, grid, dim3(NTHREADS), 0, st, a);

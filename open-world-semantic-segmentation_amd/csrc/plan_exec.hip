@@ -106,6 +106,7 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_confusion_update),
     DML_ENTRY(dml_class_feature_sum),
     DML_ENTRY(dml_label_encode),
+    DML_ENTRY(dml_h2_split),
 };
 constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 

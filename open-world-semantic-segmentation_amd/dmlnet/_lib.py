@@ -41,7 +41,10 @@ class ConvDesc(C.Structure):
                 ("res_dz", C.c_void_p), ("res_mask", C.c_void_p), ("res_ld", C.c_int32), ("res_reserved", C.c_int32),
                 # fp32 staging of a gradient with several producers, rounded once by the last one (see the header)
                 ("acc32", C.c_void_p), ("acc32_ld", C.c_int32), ("f32_split", C.c_int32),
-                ("w_tiled", C.c_int32), ("ws_min_tiles", C.c_int32)]
+                ("w_tiled", C.c_int32), ("ws_min_tiles", C.c_int32),
+                # f32_split == 2: fp16 hi / lo planes of the scaled operands (dml_h2_split; see the header)
+                ("x_planes", c_p), ("w_planes", c_p), ("x_unscale", c_p), ("w_unscale", c_p),
+                ("x_plane_stride", C.c_int64), ("w_plane_stride", C.c_int64)]
 
 
 PLAN_MAX_ARGS = 22
@@ -64,7 +67,9 @@ class WgradDesc(C.Structure):
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
                 ("pad", C.c_int32), ("dtype", C.c_int32), ("splitk", C.c_int32), ("Cm", C.c_int32),
-                ("ws", c_p), ("ws_elems", C.c_int64), ("f32_split", C.c_int32), ("reserved", C.c_int32)]
+                ("ws", c_p), ("ws_elems", C.c_int64), ("f32_split", C.c_int32), ("reserved", C.c_int32),
+                ("x_planes", c_p), ("dy_planes", c_p), ("x_unscale", c_p), ("dy_unscale", c_p),
+                ("x_plane_stride", C.c_int64), ("dy_plane_stride", C.c_int64)]
 
 
 class PrepDesc(C.Structure):
@@ -82,6 +87,7 @@ _PROTOS = {
     "dml_target_arch": (C.c_char_p, []),
     "dml_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_p]),
     "dml_conv_stat_rows": (c_i, [C.POINTER(ConvDesc)]),
+    "dml_h2_split": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_i64, c_i, c_i, c_p, c_i, c_p]),
     "dml_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
     "dml_prep_weight": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_prep_weights": (c_i, [c_p, c_i, c_i, c_p]),
@@ -97,12 +103,12 @@ _PROTOS = {
     "dml_bn_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
     "dml_bn_eval_coeffs_table": (c_i, [c_p, c_i, c_p]),
-    "dml_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.c_uint64, c_p]),
+    "dml_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.c_uint64, c_p, c_p]),
     "dml_bn_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_f, c_i,
                                 C.POINTER(c_i), c_p]),
     "dml_bn_bwd_finalize": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
-                               c_i, c_i, c_p]),
+                               c_i, c_i, c_p, c_p]),
     "dml_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_global_avgpool_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -264,7 +264,7 @@ class ParamStore:
 # ---------------------------------------------------------------------------------------------------
 class Act:
     """An NHWC activation (or gradient) living in a plan-owned buffer; may be a channel slice."""
-    __slots__ = ("t", "ptr", "B", "H", "W", "C", "ld", "f32", "es", "grad", "grad_init", "root", "g32")
+    __slots__ = ("t", "ptr", "B", "H", "W", "C", "ld", "f32", "es", "grad", "grad_init", "root", "g32", "h2", "amax")
 
     def __init__(self, t, ptr, B, H, W, C, ld, f32, es):
         self.t, self.ptr, self.B, self.H, self.W, self.C, self.ld, self.f32, self.es = t, ptr, B, H, W, C, ld, f32, es
@@ -272,6 +272,8 @@ class Act:
         self.grad_init = False      # has any producer written the gradient yet?
         self.root = self            # concat buffer this is a slice of
         self.g32 = None             # fp32 staging of the gradient while it still has producers to come (Plan.stage_grad32)
+        self.h2 = None              # (fp16 hi / lo planes, work) of this fp32 tensor once a conv has asked for them (Plan.h2_of)
+        self.amax = None            # its `work` buffer when the producers of the tensor collect max |x| into work[0] (Plan.amax_of)
 
     @property
     def M(self):
@@ -324,7 +326,13 @@ class Plan:
         #                                that conv1's data gradient adds in its epilogue (DmlConvDesc.res_*)
         # fp32 plans: products of the forward / data-gradient convolutions on the bf16 matrix cores through a three-term
         # split of both operands (DmlConvDesc.f32_split; fp32-level error, not the exact fp32 MFMA): Engine.f32_split
-        self.f32_split = 1 if (engine.f32_split and dtype == torch.float32) else 0
+        # (2: two fp16 planes per operand, written by dml_h2_split before the first conv that reads a tensor: Plan.h2_of)
+        self.f32_split = int(engine.f32_split) if dtype == torch.float32 else 0
+        self.prep_h2 = []              # dml_h2_split argument lists of the weight copies, run after every dml_prep_weights
+        # `work` buffers of dml_h2_split (1025 floats per tensor), carved from one allocation so that ONE fill at the head of
+        # the forward zeroes every amax word the step's producers will raise (dml_bn_apply / dml_bn_bwd_apply, `amax`)
+        self.h2_slots = torch.zeros(1025 * 1024, dtype=torch.float32, device=self.device) if self.f32_split == 2 else None
+        self.h2_used = 0
         self.fuse_res_grad = os.environ.get("DML_FUSE_RES_GRAD", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
@@ -435,6 +443,63 @@ class Plan:
         ops.append((fn, lst))
         return lst
 
+    # ---- fp32 plans with fp32_products = "f16x2": fp16 hi / lo planes of a conv operand (DmlConvDesc.x_planes)
+    def h2_ok(self, C, N, taps):
+        """shapes the planes kernel takes (conv_ws_planes_eligible); the others run the three-term split on the fp32 tensors"""
+        return self.f32_split == 2 and self.dtype == torch.float32 and C % 32 == 0 and N % 64 == 0 and N >= 128 and taps <= 32
+
+    def h2_work(self):
+        assert self.h2_used < 1024, "out of dml_h2_split work buffers"
+        w = self.h2_slots[self.h2_used * 1025:(self.h2_used + 1) * 1025]
+        self.h2_used += 1
+        return w
+
+    def amax_of(self, a: Act):
+        """pointer for the `amax` argument of the kernel that writes activation `a` (None outside f16x2 plans): every
+        producer of a root tensor raises the same word, and the split then needs no maximum pass of its own"""
+        if self.f32_split != 2 or self.dtype != torch.float32 or not a.f32 or a is not a.root:
+            return None         # (a slice of a concat buffer: its other producers -- resize, broadcast -- do not report a maximum)
+        root = a.root
+        if root.amax is None:
+            root.amax = self.h2_work()
+        return root.amax.data_ptr()
+
+    def h2_of(self, a: Act, ops):
+        """(planes pointer, plane stride in elements, pointer to 1 / scale) of activation `a`; the split of its ROOT tensor is
+        appended to `ops` the first time a conv asks -- every tensor of a plan is complete before its first consumer and never
+        rewritten within a step, so one split per tensor and step serves all its consumers (forward conv, weight gradient)."""
+        root = a.root
+        if root.h2 is None:
+            planes = torch.empty(2 * root.M * root.ld, dtype=torch.float16, device=self.device)
+            known = root.amax is not None           # its producers collected max |x| (amax_of)
+            work = root.amax if known else self.h2_work()
+            self.keep.append(planes)
+            self.call(ops, self.lib.dml_h2_split, root.ptr, root.M, root.C, root.ld, planes.data_ptr(), root.M * root.ld, root.ld,
+                      0, work.data_ptr(), 1 if known else 0)
+            root.h2 = (planes, work)
+        planes, work = root.h2
+        return planes.data_ptr() + (a.ptr - root.ptr) // 2, root.M * root.ld, work.data_ptr() + 4096
+
+    def h2_weight(self, w, rows, K):
+        """planes of a prepared fp32 weight copy [rows][K] (tile-major), refreshed with the copies (refresh_weights)"""
+        if getattr(w, "h2", None) is None:
+            planes = torch.empty(2 * rows * K, dtype=torch.float16, device=self.device)
+            work = torch.zeros(1025, dtype=torch.float32, device=self.device)
+            self.keep += [planes, work]
+            self.prep_h2.append((w.data_ptr(), rows, K, K, planes.data_ptr(), rows * K, K, 1, work.data_ptr(), 0))
+            self.prepped_version = None
+            w.h2 = (planes, work)
+        planes, work = w.h2
+        return planes.data_ptr(), rows * K, work.data_ptr() + 4096
+
+    def set_planes(self, dsc, x: Act, w, rows, K, ops):
+        """DmlConvDesc.f32_split / x_planes / w_planes of a conv of this plan reading activation x and weight copy w[rows][K]"""
+        dsc.f32_split = min(self.f32_split, 1)
+        if self.h2_ok(x.C, rows, dsc.R * dsc.S):
+            dsc.f32_split = 2
+            dsc.x_planes, dsc.x_plane_stride, dsc.x_unscale = self.h2_of(x, ops)
+            dsc.w_planes, dsc.w_plane_stride, dsc.w_unscale = self.h2_weight(w, rows, K)
+
     # ---- graph pieces ------------------------------------------------------------------------
     def conv_geom(self, conv: nn.Conv2d, x: Act):
         kh, kw = conv.kernel_size
@@ -472,7 +537,7 @@ class Plan:
                        pre_shift=None, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
                        N=N or conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
                        y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
-        dsc.f32_split = self.f32_split
+        self.set_planes(dsc, x, w, dsc.N, kh * kw * x.C, self.fwd)
         dsc.w_tiled = 1 if getattr(w, "tiled", False) else 0
         dsc.ws_min_tiles = self.ws_min_tiles
         if self.training:
@@ -496,7 +561,7 @@ class Plan:
                        pre_shift=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld, Ho=x.H, Wo=x.W, N=x.C,
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
                        accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
-        dsc.f32_split = self.f32_split
+        self.set_planes(dsc, dy, wt, x.C, kh * kw * dy.C, self.bwd)
         dsc.w_tiled = 1 if getattr(wt, "tiled", False) else 0
         dsc.ws_min_tiles = self.ws_min_tiles
         g32 = x.g32 if x is x.root else None
@@ -539,6 +604,11 @@ class Plan:
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         Cm = conv.in_channels
         gptr = self.e.store.grad_ptr_of(conv.weight)
+        h2 = None
+        if self.f32_split == 2 and self.dtype == torch.float32 and x.C % 8 == 0 and (pad_rows or conv.out_channels) % 8 == 0:
+            # both operands as fp16 planes (the forward already split x; dy is split once for this and the data gradient).  The
+            # splits are appended HERE, before `first`: they belong to the main stream, whose data gradient reads dy's planes too
+            h2 = self.h2_of(x, self.bwd) + self.h2_of(dy, self.bwd)
         first = len(self.bwd)
         Nw, tmp = conv.out_channels, None
         if pad_rows and pad_rows != conv.out_channels:
@@ -549,7 +619,10 @@ class Plan:
                         ldx=x.ld, Ho=Ho, Wo=Wo,
                         N=Nw, ldy=dy.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, splitk=0,
                         Cm=Cm, ws=self.wgrad_ws.data_ptr(), ws_elems=self.wgrad_ws.numel(),
-                        f32_split=self.f32_split if self.dtype == torch.float32 else 0)
+                        f32_split=min(self.f32_split, 1) if self.dtype == torch.float32 else 0)
+        if h2 is not None:
+            dsc.f32_split = 2
+            (dsc.x_planes, dsc.x_plane_stride, dsc.x_unscale, dsc.dy_planes, dsc.dy_plane_stride, dsc.dy_unscale) = h2
         self.keep.append(dsc)
         if tmp is None and self.group_wgrad and self.lib.dml_conv_wgrad_group_eligible(C.byref(dsc)):
             # joins the next grouped launch (dml_conv_wgrad_group): the weight gradients of a few consecutive layers
@@ -653,13 +726,15 @@ class Plan:
         u.gscale_slots = []
         # ReLU bitmask (bf16 training): the two BN backward passes read 1 byte per 8 elements instead of z
         u.mask = None
-        if self.training and relu and self.dtype == torch.bfloat16:
-            u.mask = torch.empty(M * (N // 8), dtype=torch.uint8, device=self.device)
+        if self.training and relu and N % self.vec == 0:
+            # one byte per 16-byte vector of z: 8 bits in bf16 plans, 4 in fp32 plans (the BN backward reads it instead of z)
+            u.mask = torch.empty(M * (N // self.vec), dtype=torch.uint8, device=self.device)
             self.keep.append(u.mask)
         mask_ptr = u.mask.data_ptr() if u.mask is not None else None
         u.apply_args = self.call(self.fwd, lib.dml_bn_apply, u.y.ptr, res.ptr if res is not None else None,
                                  u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), mean_ptr, mask_ptr, M, N, u.y.ld,
-                                 res.ld if res is not None else 0, u.z.ld, 1 if relu else 0, self.dt, 0.0, 0)
+                                 res.ld if res is not None else 0, u.z.ld, 1 if relu else 0, self.dt, 0.0, 0,
+                                 self.amax_of(u.z) if self.training else None)
         if drop is not None and self.training:
             self.drop_units.append(u)
         self.units.append(u)
@@ -721,7 +796,7 @@ class Plan:
         a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, mk, coef.data_ptr(), dy.ptr,
                        dres.ptr if dres is not None else None, M, N, dz.ld, u.y.ld, u.z.ld, dy.ld,
                        dres.ld if dres is not None else 0, 1 if u.relu else 0, 1.0,
-                       1 if dres_accum else 0, self.dt)
+                       1 if dres_accum else 0, self.dt, self.amax_of(dy))
         u.gscale_slots += ([(a1, 13)] if a1 is not None else []) + [(a3, 15)]
         if dres is not None:
             self.last_dgrad.pop(dres.ptr, None)   # written by the BN kernel, not by a data gradient
@@ -782,6 +857,9 @@ class Plan:
                 n_fixed += 0 if mod.training else 1
 
         self.bn_eval = []
+        if self.h2_slots is not None and self.training:
+            # every amax word of the step starts from zero (Plan.amax_of; the backward's words are raised after the forward)
+            self.call(self.fwd, lib.dml_fill_f32, self.h2_slots.data_ptr(), self.h2_slots.numel(), 0.0)
         if n_fixed:
             self.bn_eval_args = self.call(self.fwd, lib.dml_bn_eval_coeffs_table, 0, 0)      # filled in below
         # input packing NCHW fp32 -> NHWC (8 ch)
@@ -1053,6 +1131,8 @@ class Plan:
                 self.prep_table.append((raw.to(self.device), len(ent), dt))
         for tab, n, dt in self.prep_table:
             _lib.check(self.lib.dml_prep_weights(tab.data_ptr(), n, dt, stream), "dml_prep_weights")
+        for args in self.prep_h2:
+            _lib.check(self.lib.dml_h2_split(*args, stream), "dml_h2_split")
         self.prepped_version = key
 
     # ---- replay: one C call per contiguous run of ops (dml_plan_run) unless the engine is told to stay in Python
@@ -1224,7 +1304,8 @@ class Engine:
         self.native = os.environ.get("DML_NATIVE_PLAN", "1") != "0"      # replay launch lists through dml_plan_run
         self.sync_bn, self.sync_group = False, None     # synchronised BatchNorm statistics over the process group
         # fp32 compute dtype only: "bf16x3" products (model.set_compute_dtype(torch.float32, fp32_products="bf16x3"))
-        self.f32_split = os.environ.get("DML_F32_PRODUCTS", "exact").lower() == "bf16x3"
+        # or "f16x2" (fp32_products="f16x2"): two fp16 planes per operand, three MFMAs per block (DmlConvDesc.x_planes)
+        self.f32_split = {"exact": 0, "bf16x3": 1, "f16x2": 2}[os.environ.get("DML_F32_PRODUCTS", "exact").lower()]
         self._side = {}
         self._branch = {}
         self.step_count = 0
@@ -1290,7 +1371,7 @@ class Engine:
             self.plans.clear()
             self._protos.clear()
         B, Cin, H, W = x.shape
-        key = (B, H, W, dtype, training, bool(self.sync_bn), self.bn_modes() if training else 0, bool(self.f32_split))
+        key = (B, H, W, dtype, training, bool(self.sync_bn), self.bn_modes() if training else 0, int(self.f32_split))
         plan = self.plans.get(key)
         if plan is None:
             plan = self.plan_cls(self, B, H, W, dtype, training)

@@ -147,15 +147,18 @@ class DeepLabV3_embedding(nn.Module):
     def set_compute_dtype(self, dtype, fp32_products=None):
         """torch.float32: the reference's arithmetic (network/utils.py:84-118 computes in fp32) -- exact fp32 MFMAs by default;
         `fp32_products="bf16x3"` keeps fp32 storage everywhere and computes the convolutions' products on the bf16 matrix
-        cores through a three-term split of both operands (fp32-level error, DmlConvDesc.f32_split).  torch.bfloat16: bf16
-        storage of activations / compute weights, fp32 accumulation (the throughput mode)."""
+        cores through a three-term split of both operands (fp32-level error, DmlConvDesc.f32_split); `fp32_products="f16x2"`
+        computes them on the fp16 matrix cores through a two-term split of the power-of-two-scaled operands (22 significand
+        bits, the reference's own fp32-vs-fp64 level on the parity fixtures; three MFMAs per block instead of six; the
+        weight gradients and the shapes its kernel does not take stay on the three-term split).  torch.bfloat16: bf16 storage
+        of activations / compute weights, fp32 accumulation (the throughput mode)."""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype must be float32 or bfloat16")
-        if fp32_products not in (None, "exact", "bf16x3"):
-            raise ValueError("fp32_products must be 'exact' or 'bf16x3'")
+        if fp32_products not in (None, "exact", "bf16x3", "f16x2"):
+            raise ValueError("fp32_products must be 'exact', 'bf16x3' or 'f16x2'")
         self.compute_dtype = dtype
         if fp32_products is not None:
-            self._engine.f32_split = fp32_products == "bf16x3"
+            self._engine.f32_split = {"exact": 0, "bf16x3": 1, "f16x2": 2}[fp32_products]
         return self
 
     def set_sync_batchnorm(self, enabled=True, group=None):

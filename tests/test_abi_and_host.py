@@ -35,14 +35,15 @@ def test_struct_layout_matches_header():
     from dmlnet._lib import ConvDesc, WgradDesc
     # 7 ptr + 19 int32 (+4 pad) | bnr: 5 ptr + 2 int32 | post: 4 ptr + 2 int32 | tail: ptr, int64, ptr, 2 int32 |
     # res: 2 ptr + 2 int32
-    assert ctypes.sizeof(ConvDesc) == 7 * 8 + 19 * 4 + 4 + 5 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 2 * 4 + 2 * 4
+    assert ctypes.sizeof(ConvDesc) == 7 * 8 + 19 * 4 + 4 + 5 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 2 * 4 + 2 * 4 + 6 * 8
+    assert ConvDesc.ws_min_tiles.offset == 300 and ConvDesc.x_planes.offset == 304 and ConvDesc.w_plane_stride.offset == 344
     assert ConvDesc.tail_ws.offset == 224 and ConvDesc.tail_counters_len.offset == 248
     assert ConvDesc.res_dz.offset == 256 and ConvDesc.res_ld.offset == 272
     assert ConvDesc.acc32.offset == 280 and ConvDesc.acc32_ld.offset == 288 and ConvDesc.f32_split.offset == 292 and ConvDesc.w_tiled.offset == 296
     assert ConvDesc.bnr_y.offset == 136 and ConvDesc.bnr_ldy.offset == 176 and ConvDesc.post_scale.offset == 184
     from dmlnet._lib import BnEvalDesc
     assert ctypes.sizeof(BnEvalDesc) == 48
-    assert ctypes.sizeof(WgradDesc) == 3 * 8 + 17 * 4 + 4 + 8 + 8 + 2 * 4 and WgradDesc.f32_split.offset == 112
+    assert ctypes.sizeof(WgradDesc) == 3 * 8 + 17 * 4 + 4 + 8 + 8 + 2 * 4 + 6 * 8 and WgradDesc.f32_split.offset == 112 and WgradDesc.x_planes.offset == 120
     assert ConvDesc.B.offset == 56 and ConvDesc.pre_relu.offset == 56 + 18 * 4
     from dmlnet._lib import PrepDesc
     assert ctypes.sizeof(PrepDesc) == 48 and PrepDesc.w_tiled.offset == 40 and PrepDesc.wt_tiled.offset == 44

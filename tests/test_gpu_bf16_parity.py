@@ -305,10 +305,11 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed, stage32, monkeypatch
     assert n_acc32 == (5 if stage32 else 0), n_acc32       # d(out) + the four blocks with a downsample branch (low = layer2.0's)
 
 
-@pytest.mark.parametrize("products", ["exact", "bf16x3"])
+@pytest.mark.parametrize("products", ["exact", "bf16x3", "f16x2"])
 def test_fp32_768_bs2_against_oracle(products):
     """fp32 mode at the benchmark's crop size against the fp32 oracle: logits / loss at 1e-3, every gradient checksum -- with the
-    exact fp32 MFMA and with the convolutions' products on the bf16 matrix cores (three-term split), same bars"""
+    exact fp32 MFMA, with the convolutions' products on the bf16 matrix cores (three-term split) and on the fp16 matrix cores
+    (two-term split of the scaled operands), same bars"""
     import utils
     from oracle import dmlnet_ref as O
     torch.set_num_threads(min(64, torch.get_num_threads() or 8))

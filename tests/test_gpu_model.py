@@ -50,10 +50,11 @@ def g8_inputs():
     return img, lab
 
 
-@pytest.mark.parametrize("products", ["exact", "bf16x3"])
+@pytest.mark.parametrize("products", ["exact", "bf16x3", "f16x2"])
 def test_g5_full_train_step_matches_reference(products):
-    """fp32 compute dtype against the reference-minted fixture, with the exact fp32 MFMA and with the convolutions' products
-    on the bf16 matrix cores through the three-term split (same 1e-3 / 2e-3 bars: the split is fp32-accurate)."""
+    """fp32 compute dtype against the reference-minted fixture, with the exact fp32 MFMA, with the convolutions' products
+    on the bf16 matrix cores through the three-term split, and on the fp16 matrix cores through the two-term split of the
+    scaled operands (same 1e-3 / 2e-3 bars for all three: the splits are fp32-accurate)."""
     import utils
     g = H.load_golden("g5_full_train")
     m = build(fp32_products=products)
@@ -122,7 +123,7 @@ def test_train_steps_are_bitwise_reproducible(dtype):
     assert not diff, "%d of %d tensors differ between two identical runs, e.g. %s" % (len(diff), len(runs[0][1]), diff[:5])
 
 
-@pytest.mark.parametrize("products", ["exact", "bf16x3"])
+@pytest.mark.parametrize("products", ["exact", "bf16x3", "f16x2"])
 def test_g8_sgd_polylr_trajectory(products):
     import utils
     from dmlnet.optim import FusedSGD

@@ -487,11 +487,16 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     rm, rv, g_d, b_d = rm0.cuda(), rv0.cuda(), gamma.detach().cuda(), beta.detach().cuda()
     chk(lib.dml_bn_finalize(part.data_ptr(), M, Cc, 64, g_d.data_ptr(), b_d.data_ptr(), rm.data_ptr(), rv.data_ptr(),
                             0.01, 1e-5, sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), inv.data_ptr(), st()))
-    bitmask = torch.zeros(M * Cc // 8, device="cuda", dtype=torch.uint8) if dname == "bf16" else None
+    # 1-bit ReLU mask, one byte per 16-byte vector (8 elements in bf16, 4 in fp32); every other fp32 case keeps reading z
+    use_mask = dname == "bf16" or (res and relu)
+    bitmask = torch.zeros(M * Cc // (8 if dname == "bf16" else 4), device="cuda", dtype=torch.uint8) if use_mask else None
     mk = bitmask.data_ptr() if bitmask is not None else None
+    amax = torch.zeros(1024, device="cuda")
     chk(lib.dml_bn_apply(yd.data_ptr(), rd.data_ptr() if res else None, zd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                         mu.data_ptr(), mk, M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, st()))
+                         mu.data_ptr(), mk, M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, amax.data_ptr(), st()))
     torch.cuda.synchronize()
+    # (taken from the fp32 value before a bf16 store rounds it)
+    assert abs(amax.max().item() - zd.float().abs().max().item()) <= 2.0 ** -7 * amax.max().item(), "amax side output of dml_bn_apply"
     relclose(rm.cpu(), rm_ref, 1e-4, "running_mean")
     relclose(rv.cpu(), rv_ref, 1e-4, "running_var")
     z = nchw(zd)
@@ -521,10 +526,12 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
                                 dg.data_ptr(), db.data_ptr(), coef.data_ptr(), st()))
     dyd = torch.empty_like(yd)
     dres = torch.empty_like(yd) if res else None
+    amax_dy = torch.zeros(1024, device="cuda")
     chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zarg, mk, coef.data_ptr(), dyd.data_ptr(),
                              dres.data_ptr() if res else None, M, Cc, Cc, Cc, Cc, Cc, Cc,
-                             1 if (relu or drop > 0) else 0, gs, 0, dt, st()))
+                             1 if (relu or drop > 0) else 0, gs, 0, dt, amax_dy.data_ptr(), st()))
     torch.cuda.synchronize()
+    assert abs(amax_dy.max().item() - dyd.float().abs().max().item()) <= 2.0 ** -7 * amax_dy.max().item()
     btol = 1e-4 if dname == "f32" else 2e-2
     relclose(dg.cpu(), gamma.grad, btol, "dgamma")
     relclose(db.cpu(), beta.grad, btol, "dbeta")
@@ -760,7 +767,7 @@ def test_rejects_bad_arguments(lib):
     assert lib.dml_conv_igemm(C.byref(d), None) == -1
     x = torch.zeros(64, device="cuda")
     assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 6, 6, 6,
-                            6, 1, 0, 0.0, 0, st()) == -2
+                            6, 1, 0, 0.0, 0, None, st()) == -2
     assert lib.dml_proto_dist_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 64, 16, 1, 1, st()) == -3
 
 
@@ -1253,6 +1260,130 @@ def test_conv_f32_three_term_split_is_fp32_accurate(lib, case):
     print("%s: fwd / dgrad / stats / wgrad error vs fp64: exact fp32 MFMA %.2e %.2e %.2e %.2e | three-term split %.2e %.2e %.2e %.2e"
           % ((name,) + errs[0] + errs[1]))
     for a_, b_ in zip(errs[1], errs[0]):
+        assert a_ <= max(4.0 * b_, 2e-6), errs
+
+
+def h2_planes(lib, t2d, layout=0, amax=None):
+    """dml_h2_split of an fp32 [rows][C] cuda tensor -> (planes fp16 [2][rows * C], work) ; work[1024] = 1 / scale"""
+    rows, Cc = t2d.shape
+    planes = torch.empty((2, rows * Cc), device="cuda", dtype=torch.float16)
+    work = torch.zeros(1025, device="cuda")
+    if amax is not None:
+        work[77] = amax                 # anywhere in the first 1024 words
+    chk(lib.dml_h2_split(t2d.data_ptr(), rows, Cc, Cc, planes.data_ptr(), rows * Cc, Cc, layout, work.data_ptr(),
+                         0 if amax is None else 1, st()))
+    return planes, work
+
+
+@pytest.mark.parametrize("scale", [1.0, 3e-5, 7e4, 0.0])
+def test_h2_split_reconstructs_the_tensor(lib, scale):
+    """dml_h2_split: (hi + lo) / s reproduces x to 2^-21 of its magnitude (elements far below the maximum: to 2^-36 of the
+    maximum), s is the power of two that puts max|x| into [2^14, 2^15), both layouts hold the same values, zero tensors work."""
+    g = torch.Generator(device="cuda").manual_seed(3)
+    x = (torch.randn(192, 96, device="cuda", generator=g) * scale).contiguous()
+    x[5, 7] *= 1e-6                                      # a tiny element next to large ones
+    pl, work = h2_planes(lib, x, 0)
+    torch.cuda.synchronize()
+    un = work[1024].item()
+    amax = x.abs().max().item()
+    if amax > 0:
+        assert 2.0 ** 14 <= amax / un < 2.0 ** 15 and np.log2(un) == np.floor(np.log2(un))
+    else:
+        assert un == 1.0
+    rec = (pl[0].double() + pl[1].double()).view(192, 96) * un
+    err = (rec - x.double()).abs()
+    assert (err <= x.double().abs() * 2.0 ** -21 + amax * 2.0 ** -36).all(), err.max().item()
+    assert torch.equal(pl[0].view(192, 96).float(), (x / un).half().float())        # hi = fp16(s x), round to nearest even
+    plt, workt = h2_planes(lib, x, 1)
+    torch.cuda.synchronize()
+    for p_ in (0, 1):
+        assert torch.equal(plt[p_].view(-1), _tile_major(pl[p_].view(192, 96)).view(-1))
+    assert workt[1024].item() == un
+    plk, workk = h2_planes(lib, x, 0, amax=amax)            # the producer already knows max |x|: one pass, same planes
+    torch.cuda.synchronize()
+    assert torch.equal(plk, pl) and workk[1024].item() == un
+    # an Inf poisons the scale instead of being clipped silently
+    x[1, 1] = float("inf")
+    _, w2 = h2_planes(lib, x, 0)
+    torch.cuda.synchronize()
+    v = w2[1024].item()
+    assert v == 0.0 or not np.isfinite(v)
+
+
+H2_CASES = [("h2_1x1", 2, 24, 20, 64, 128, 1, 1, 1), ("h2_3x3", 2, 19, 23, 64, 256, 3, 1, 1), ("h2_3x3_d2", 2, 16, 16, 128, 256, 3, 1, 2),
+            ("h2_3x3_s2", 2, 22, 18, 128, 128, 3, 2, 1), ("h2_rows", 3, 40, 40, 256, 256, 3, 1, 1), ("h2_1x1_n384", 2, 13, 29, 96, 384, 1, 1, 1)]
+
+
+@pytest.mark.parametrize("case", H2_CASES, ids=lambda c: c[0])
+def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
+    """DmlConvDesc.f32_split = 2 with x_planes / w_planes (dml_h2_split): forward (with BN statistics) and data gradient of fp32
+    tensors with the products of two fp16 planes per operand on the matrix cores (conv_ws_kernel<.., 2>).  Against fp64 the
+    error must stay within 4x the exact fp32 MFMA kernel's own (the two-term split carries 22 bits, the accumulation is fp32
+    either way); operands of very different magnitude (activations ~1e3, weights ~1e-3) check the two scales."""
+    name, B, Hh, Ww, Cin, Cout, k, stride, dil = case
+    x = (rnd(name + ".x", (B, Cin, Hh, Ww)).double() * 1e3).requires_grad_(True)
+    w = (rnd(name + ".w", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5).double() * 1e-3).requires_grad_(True)
+    y_ref, pad = conv_ref(x, w, k, stride, dil)
+    Ho, Wo = y_ref.shape[2:]
+    gy = rnd(name + ".gy", tuple(y_ref.shape)).double() * 1e-4
+    y_ref.backward(gy)
+    xd = nhwc(x.detach().float(), torch.float32)
+    wd = w.detach().float().permute(0, 2, 3, 1).contiguous().cuda()            # N R S C
+    wtd = w.detach().float().permute(1, 2, 3, 0).contiguous().cuda()           # C R S N
+    gyd = nhwc(gy.float(), torch.float32)
+    M = B * Ho * Wo
+    errs = {}
+    for split in (0, 2):
+        yd = torch.empty((B, Ho, Wo, Cout), device="cuda")
+        d = make_desc(lib, xd, wd, yd, B, Hh, Ww, Cin, Ho, Wo, Cout, k, stride, dil, pad, 0)
+        dxd = torch.empty((B, Hh, Ww, Cin), device="cuda")
+        dd = make_desc(lib, gyd, wtd, dxd, B, Ho, Wo, Cout, Hh, Ww, Cin, k, stride, dil, pad, 0, mode=1)
+        keep = []
+        if split:
+            for desc, act, wmat, rows_w in ((d, xd, wd, Cout), (dd, gyd, wtd, Cin)):
+                if rows_w % 128:                     # not a shape of the planes kernel: the three-term split takes it
+                    desc.f32_split = 1
+                    continue
+                ap, aw = h2_planes(lib, act.view(-1, act.shape[-1]), 0)
+                wp, ww = h2_planes(lib, wmat.view(rows_w, -1), 1)
+                keep += [ap, aw, wp, ww]
+                desc.f32_split = 2
+                desc.x_planes, desc.x_unscale, desc.x_plane_stride = ap.data_ptr(), aw.data_ptr() + 4096, ap.shape[1]
+                desc.w_planes, desc.w_unscale, desc.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
+        rows = lib.dml_conv_stat_rows(C.byref(d))
+        assert rows == (48 if (split and Cout % 128 == 0) else 64)
+        stats = torch.zeros((M + rows - 1) // rows * Cout * 2, device="cuda")
+        d.stats = stats.data_ptr()
+        chk(lib.dml_conv_igemm(C.byref(d), st()))
+        chk(lib.dml_conv_igemm(C.byref(dd), st()))
+        sc, sh, mu, inv = (torch.empty(Cout, device="cuda") for _ in range(4))
+        chk(lib.dml_bn_finalize(stats.data_ptr(), M, Cout, rows, None, None, None, None, 0.1, 1e-5, sc.data_ptr(), sh.data_ptr(),
+                                mu.data_ptr(), inv.data_ptr(), st()))
+        torch.cuda.synchronize()
+        yr = y_ref.detach()
+        ef = (nchw(yd).double() - yr).abs().max().item() / yr.abs().max().item()
+        eg = (nchw(dxd).double() - x.grad).abs().max().item() / x.grad.abs().max().item()
+        em = (mu.cpu().double() - yr.mean(dim=(0, 2, 3))).abs().max().item() / yr.abs().max().item()
+        # weight gradient (workspace path): both operands as planes
+        from dmlnet._lib import WgradDesc
+        ws = torch.empty(8 * Cout * k * k * Cin, device="cuda")
+        dw = torch.zeros((Cout, k, k, Cin), device="cuda")
+        wg = WgradDesc(x=xd.data_ptr(), dy=gyd.data_ptr(), dw=dw.data_ptr(), B=B, Hi=Hh, Wi=Ww, C=Cin, ldx=Cin, Ho=Ho, Wo=Wo,
+                       N=Cout, ldy=Cout, R=k, S=k, stride=stride, dil=dil, pad=pad, dtype=0, splitk=5, f32_split=split,
+                       ws=ws.data_ptr(), ws_elems=ws.numel())
+        if split:
+            xp, xw = h2_planes(lib, xd.view(-1, Cin), 0)
+            yp, yw = h2_planes(lib, gyd.view(-1, Cout), 0)
+            keep += [xp, xw, yp, yw]
+            wg.x_planes, wg.x_unscale, wg.x_plane_stride = xp.data_ptr(), xw.data_ptr() + 4096, xp.shape[1]
+            wg.dy_planes, wg.dy_unscale, wg.dy_plane_stride = yp.data_ptr(), yw.data_ptr() + 4096, yp.shape[1]
+        chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+        torch.cuda.synchronize()
+        ew = (dw.cpu().permute(0, 3, 1, 2).double() - w.grad).abs().max().item() / w.grad.abs().max().item()
+        errs[split] = (ef, eg, em, ew)
+    print("%s: fwd / dgrad / batch-mean / wgrad error vs fp64: exact fp32 MFMA %.2e %.2e %.2e %.2e | two fp16 planes %.2e %.2e %.2e %.2e"
+          % ((name,) + errs[0] + errs[2]))
+    for a_, b_ in zip(errs[2], errs[0]):
         assert a_ <= max(4.0 * b_, 2e-6), errs
 
 
