@@ -50,8 +50,6 @@ typedef struct DmlConvDesc {
     const float* bias;    /* optional [N] (only network/utils.py:23 has a bias)                          */
     float* stats;         /* optional BN partials [ceil(M/rows)][N][2], rows = dml_conv_stat_rows(): (sum, M2 about the */
                           /* group mean) taken from the fp32 accumulators (fused K9)         */
-    const float* pre_scale;  /* optional fused BN+ReLU on the A operand: a = relu(x*scale[c]+shift[c]),  */
-    const float* pre_shift;  /* applied before zero padding (fwd mode only)                              */
     int32_t B, Hi, Wi, C, ldx;
     int32_t Ho, Wo, N, ldy;
     int32_t R, S, stride, dil, pad;
@@ -59,7 +57,9 @@ typedef struct DmlConvDesc {
     int32_t y_f32;        /* 1: write y as float regardless of dtype                                     */
     int32_t accum;        /* 1: y += result                                                              */
     int32_t mode;         /* 0 = forward gather, 1 = data-gradient gather (transposed conv)              */
-    int32_t pre_relu;     /* with pre_scale: apply ReLU after the affine                                 */
+    /* (ABI 2: the pre_scale / pre_shift / pre_relu fields of ABI 1 -- the producer's BatchNorm + ReLU applied on the operand
+     * load -- are gone: measured on the register-staged kernel in round 1 and on the loader-wave structure in round 4, the
+     * transform costs the convolution more than the BatchNorm apply pass it would remove) */
     /* mode 1 only, optional (all NULL/0 otherwise): the result y is the output gradient dz of a BatchNorm
      * (+ReLU) whose pre-normalisation tensor is bnr_y [M][N] (pitch bnr_ldy) with the 1-bit ReLU mask of
      * dml_bn_apply; the epilogue then also writes that BN's backward partial sums, exactly what

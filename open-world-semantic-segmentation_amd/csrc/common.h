@@ -113,9 +113,9 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 }
 
 // Workgroups for a grid-stride streaming kernel.  Caps of 2048 and above are "enough to fill the chip" choices, not
-// buffer sizes; DML_GRID_CAP overrides them (tools: short-lived workgroups stream faster than persistent ones, see bn.hip).
+// buffer sizes (short-lived workgroups stream faster than persistent ones, see bn.hip).
 static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
-    static const int cap_override = getenv("DML_GRID_CAP") ? atoi(getenv("DML_GRID_CAP")) : DML_GRID_CAP_DEFAULT;
+    constexpr int cap_override = DML_GRID_CAP_DEFAULT;      // (tuning builds: -DDML_GRID_CAP_DEFAULT=n)
     if (cap_override > 0 && max_blocks >= 2048) max_blocks = cap_override;
     int64_t g = (work_items + block - 1) / block;
     if (g < 1) g = 1;

@@ -76,13 +76,7 @@ struct ConvArgs {
     int nt_out;
 };
 
-int g_persist_kt = -1;      // largest K-step count the persistent kernel takes (launch_conv); -1: read DML_CONV_PERSIST
-
-int g_wgrad_depth = -1;     // K steps per barrier of the 256 x 256 weight-gradient kernel (1 | 2); -1: read DML_WGRAD_DEPTH
-inline int wgrad_depth() {
-    if (g_wgrad_depth < 0) g_wgrad_depth = getenv("DML_WGRAD_DEPTH") ? atoi(getenv("DML_WGRAD_DEPTH")) : 2;
-    return g_wgrad_depth;
-}
+constexpr int WGRAD_DEPTH = 2;      // K steps per barrier of the 256 x 256 weight-gradient kernel (one: 3-12 % slower)
 
 // bijective XCD-aware remap: consecutive logical tiles land on the same XCD (private L2)
 __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
@@ -1632,8 +1626,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 
 // may this launch run on conv_ws_kernel?  (shared by launch_conv and dml_conv_stat_rows)
 static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t wb) {
-    static const int ws_on = getenv("DML_CONV_WS") ? atoi(getenv("DML_CONV_WS")) : 1;
-    if (!ws_on || !a.w_tiled || (a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 128) != 0) return false;
+    // bf16 plans: OPT-IN (DML_CONV_WS=1).  Per launch it wins where K is long (rule below), but in the train step the persistent
+    // 150 KB-of-LDS workgroups keep the side stream's weight-gradient workgroups off the CUs they hold and static tile lists
+    // cannot rebalance around them: whole step 391.5 / 392.2 images/s with it, 395.3 / 394.9 without (two interleaved pairs,
+    // profiles/r04_ab_ws.txt).  The two-plane fp32 mode (conv_ws_planes_eligible) always runs on it.
+    static const int ws_on = getenv("DML_CONV_WS") ? atoi(getenv("DML_CONV_WS")) : 0;
+    if ((!ws_on && a.ws_min_tiles <= 0) || !a.w_tiled || (a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 128) != 0) return false;
     if (xb >= (1ll << 31) || wb >= (1ll << 31)) return false;
     // long K loops only: a consumer wave runs its tile's epilogue itself, with nothing of the same workgroup to cover it, and
     // below ~32 K steps per tile that costs more than the K loop gains (tools/bench_ws.py, profiles/r04_bench_ws_2.txt: K = 256
@@ -1652,198 +1650,6 @@ static bool conv_ws_planes_eligible(const ConvArgs& a) {
     if ((a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 64) != 0 || a.N < 128) return false;      // (N = 320: the decoder's data gradient)
     const int64_t xb = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2, wb = (int64_t)a.N * a.Ktot * 2;
     return xb + a.x_plane_bytes < (1ll << 31) && wb + a.w_plane_bytes < (1ll << 31);
-}
-
-// ------------------------------------------------------------------------------------------------
-// Persistent form of the LDS-DMA ring for SHORT K loops (1x1 convolutions over <= 512 channels, the 64-channel 3x3):
-// there a tile is 2-18 K steps, and the first loads' latency plus the epilogue (its loads, and the stores the wave must
-// see acknowledged before s_endpgm frees its LDS and registers) is 40-78 % of a tile's lifetime
-// (profiles/r01_conv_phase_cycles.txt: 3.5k + 6.2k cycles beside a 13.3k-cycle loop at K = 256; 5.3k + 7.2k beside 3.5k
-// at K = 64).  A workgroup here walks a list of tiles: the ring does not drain at a tile boundary -- the first two
-// stages of the NEXT tile are issued during the last two K steps of the current one, so its K loop starts on landed
-// data, the epilogue's stores are never waited for (only the kernel's end is), and the next tile's address setup runs
-// under loads in flight.  Same tile, ring, fragment reads, MFMA order and epilogue as conv_igemm_dma_kernel<BN, MODE, 3>:
-// results are bit-identical.
-// vmcnt bookkeeping: the counter is in-order over loads AND stores on gfx9; at the first K step after an epilogue the
-// operations younger than the stage being waited for are the next stage's NI loads plus the epilogue's stores, so
-// vmcnt(NI) still implies "landed" (it over-waits for all but the last NI of the stores, never under-waits).
-// ------------------------------------------------------------------------------------------------
-template <int BN, int MODE>
-__global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(3))) void conv_igemm_dma_persist_kernel(
-    const ConvArgs a_karg, const uint32_t x_bytes, const uint32_t w_bytes, const int ntiles) {
-    typedef bf16_t T;
-    // the descriptor is read through an opaque pointer: its ~60 words are then scalar loads from the kernel-argument
-    // segment where they are used (tile setup, epilogue) instead of living in SGPRs across the whole tile loop (which
-    // spilled 59-71 of them to VGPR lanes)
-    typedef const __attribute__((address_space(4))) uint32_t* KArgPtr;
-    KArgPtr ap = (KArgPtr)__builtin_amdgcn_kernarg_segment_ptr();
-    static_assert(sizeof(ConvArgs) % 4 == 0, "descriptor is copied by words");
-    auto load_args = [&](ConvArgs& dst) {
-        asm volatile("" : "+s"(ap));           // loads below cannot be hoisted above this point
-        uint32_t* d = reinterpret_cast<uint32_t*>(&dst);
-#pragma unroll
-        for (int i = 0; i < (int)(sizeof(ConvArgs) / 4); ++i) d[i] = ap[i];
-    };
-    ConvArgs a;
-    load_args(a);
-    constexpr int NST = 3, BM = 128, WAVES = 4;
-    constexpr int STAGE = (BM + BN) * BK;
-    constexpr int TM = 64, TN = BN / 2, MT = 4, NT = TN / 16;
-    constexpr int A_I = 2, B_I = BN / 16 / WAVES;
-    constexpr int NI = A_I + B_I;
-    constexpr uint32_t OOB = 0x80000000u;
-
-    __shared__ __attribute__((aligned(1024))) T smem[NST * STAGE];
-
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const int wm = wave >> 1, wn = wave & 1;
-
-    // this workgroup's tiles: the XCD's contiguous share of the tile list (xcd_remap's split), strided by the
-    // workgroups of that XCD, so that the tiles in flight on an XCD at any time are neighbours (shared rows / weights)
-    const int xcd = blockIdx.x & 7, per = gridDim.x >> 3;
-    const int tq = ntiles >> 3, tr = ntiles & 7;
-    const int tbase = xcd < tr ? xcd * (tq + 1) : tr * (tq + 1) + (xcd - tr) * tq;
-    const int tcnt = tq + (xcd < tr ? 1 : 0);
-    int ti = blockIdx.x >> 3;
-    if (ti >= tcnt) return;
-
-    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.x), 0, (int)x_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(a.w), 0, (int)w_bytes, 0x00020000);
-
-    const int prow = lane >> 2;
-    const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
-    const int sh2 = (MODE != 0 && a.stride == 2) ? 1 : 0;
-
-    struct TileAddr {
-        int a_base[A_I];
-        uint32_t a_mask[A_I];
-        uint32_t b_off[B_I];
-        int ir, is, ic0, kt;      // filter tap / channel offset / K step of the next stage to issue
-        int m0, n0;
-    };
-    auto setup = [&](TileAddr& t, const int tile) {
-        const int blk_m = tile / a.nblk_n, blk_n = tile - blk_m * a.nblk_n;
-        t.m0 = blk_m * BM;
-        t.n0 = blk_n * BN;
-        t.ir = 0; t.is = 0; t.ic0 = 0; t.kt = 0;
-#pragma unroll
-        for (int jj = 0; jj < A_I; ++jj) {
-            const int m = t.m0 + (wave * A_I + jj) * 16 + prow;
-            t.a_base[jj] = 0;
-            t.a_mask[jj] = 0;
-            if (m < a.M) {
-                const uint32_t b = fdiv((uint32_t)m, a.div_howo);
-                const uint32_t rem = (uint32_t)m - b * (uint32_t)(a.Ho * a.Wo);
-                const uint32_t yo = fdiv(rem, a.div_wo);
-                const uint32_t xo = rem - yo * (uint32_t)a.Wo;
-                const int iy = MODE == 0 ? (int)yo * a.stride - a.pad : (int)yo + a.pad;
-                const int ix = MODE == 0 ? (int)xo * a.stride - a.pad : (int)xo + a.pad;
-                const int by = MODE == 0 ? iy : (iy >> sh2), bx = MODE == 0 ? ix : (ix >> sh2);
-                t.a_base[jj] = ((((int)b * a.Hi + by) * a.Wi + bx) * a.ldx + lchunk * 8) * 2;
-                uint32_t mk = 0;
-                for (int r = 0, tp = 0; r < a.R; ++r)
-                    for (int q = 0; q < a.S; ++q, ++tp) {
-                        bool ok;
-                        if (MODE == 0) {
-                            const int ys = iy + r * a.dil, xs = ix + q * a.dil;
-                            ok = ((unsigned)ys < (unsigned)a.Hi) && ((unsigned)xs < (unsigned)a.Wi);
-                        } else {
-                            const int ty = iy - r * a.dil, tx = ix - q * a.dil;
-                            ok = (sh2 == 0 || (((ty | tx) & 1) == 0)) && ty >= 0 && tx >= 0 && ((ty >> sh2) < a.Hi) &&
-                                 ((tx >> sh2) < a.Wi);
-                        }
-                        mk |= ok ? (1u << tp) : 0u;
-                    }
-                t.a_mask[jj] = mk;
-            }
-        }
-#pragma unroll
-        for (int jj = 0; jj < B_I; ++jj) {
-            const int row = (wave * B_I + jj) * 16 + prow, n = t.n0 + row;
-            const int bchunk = swz_chunk<T>(b_rho<NT>(row), lane & 3);
-            t.b_off[jj] = n < a.N ? (uint32_t)(((int64_t)n * a.Ktot + bchunk * 8) * 2) : OOB;
-        }
-    };
-    auto issue = [&](TileAddr& t, const int stage) {
-        T* sbase = smem + stage * STAGE;
-        const uint32_t tapbit = 1u << (t.ir * a.S + t.is);
-        const int soff = (MODE == 0 ? ((t.ir * a.dil) * a.Wi + t.is * a.dil) * a.ldx
-                                    : -((((t.ir * a.dil) >> sh2) * a.Wi + ((t.is * a.dil) >> sh2)) * a.ldx)) * 2 + t.ic0 * 2;
-#pragma unroll
-        for (int jj = 0; jj < A_I; ++jj) {
-            const uint32_t voff = (t.a_mask[jj] & tapbit) ? (uint32_t)(t.a_base[jj] + soff) : OOB;
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(sbase + (wave * A_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
-        }
-#pragma unroll
-        for (int jj = 0; jj < B_I; ++jj) {
-            const uint32_t voff = t.b_off[jj] + (uint32_t)(t.kt * BK * 2);
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(sbase + BM * BK + (wave * B_I + jj) * 16 * BK), 16, voff, 0, 0, 0);
-        }
-        ++t.kt;
-        t.ic0 += BK;
-        if (t.ic0 >= a.C) {
-            t.ic0 = 0;
-            if (++t.is == a.S) { t.is = 0; ++t.ir; }
-        }
-    };
-
-    const int KT = a.Ktot / BK;                 // >= 2 (host side)
-    const int lr = lane & 15, lq = lane >> 4;
-    TileAddr cur, nxt;
-    setup(cur, tbase + ti);
-    issue(cur, 0);
-    issue(cur, 1);
-    int rd = 0, wr = 2;                         // ring stage read by the next K step / written by the next issue
-
-    for (;;) {
-        load_args(a);
-        const int tn = ti + per;
-        const bool has_next = tn < tcnt;
-        if (has_next) setup(nxt, tbase + tn);
-
-        f32x4 acc[NT][MT];
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-        for (int kt = 0; kt < KT; ++kt) {
-            // in flight: this step's stage and, unless the list ends here, the one after it
-            if (kt + 1 < KT || has_next) wait_vmcnt<NI>();
-            else wait_vmcnt<0>();
-            __builtin_amdgcn_s_barrier();
-            if (kt + 2 < KT) issue(cur, wr);
-            else if (has_next) issue(nxt, wr);
-            const T* as = smem + rd * STAGE + (wm * TM) * BK;
-            const T* bs = smem + rd * STAGE + BM * BK + (wn * TN) * BK;
-            wr = wr == NST - 1 ? 0 : wr + 1;
-            rd = rd == NST - 1 ? 0 : rd + 1;
-            mfma_bf16x8 bf[NT], af[MT];
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-                bf[i] = *reinterpret_cast<const mfma_bf16x8*>(bs + b_row<NT>(i, lr) * BK + swz_chunk<T>(lr, lq) * 8);
-#pragma unroll
-            for (int j = 0; j < MT; ++j) {
-                const int row = j * 16 + lr;
-                af[j] = *reinterpret_cast<const mfma_bf16x8*>(as + row * BK + swz_chunk<T>(row, lq) * 8);
-            }
-#pragma unroll
-            for (int i = 0; i < NT; ++i)
-#pragma unroll
-                for (int j = 0; j < MT; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[i], af[j], acc[i][j], 0, 0, 0);
-        }
-#pragma unroll
-        for (int i = 0; i < NT; ++i)
-#pragma unroll
-            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
-        load_args(a);                           // the epilogue's fields: not live across the K loop
-        conv_epilogue<T, NT, MT, MODE>(acc, a, cur.m0 + wm * TM, cur.n0 + wn * TN, lr, lq);
-        if (!has_next) break;
-        cur = nxt;
-        ti = tn;
-    }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -2845,7 +2651,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
     // non-temporal epilogue stores for outputs that do not fit the L2 anyway (st16); smaller ones are better left there for
     // their consumer (1x1 1024 -> 256 at 48 x 48, 19 MB: 45.3 us plain, 46.9 non-temporal).  DML_CONV_NT: 0 never, 1 this
     // rule (default), 2 always
-    static const int nt_mode = getenv("DML_CONV_NT") ? atoi(getenv("DML_CONV_NT")) : 1;
+    constexpr int nt_mode = 1;
     // the partial statistics (64 B per wave instruction) follow only where they are many: beside non-temporal outputs,
     // 19 MB of plain partial stores bring the stalls back (192 x 192, 64 -> 256: 158 us, 126 with both non-temporal; all
     // plain 141), while 4.7 MB do better plain (48 x 48, 256 -> 1024: 41.1 against 45.4 us)
@@ -2888,18 +2694,12 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // tile width to double the workgroup count; per-FLOP the 128 x 64 tile is 15-25 % slower, so only below 200
             // workgroups (1024 x 2048 bs 1: 235 -> 250 images/s, 5-scale open-set evaluation 92 -> 97.5 frames/s; the
             // training grids are all larger)
-            static const int narrow_below = getenv("DML_CONV_NARROW_BELOW") ? atoi(getenv("DML_CONV_NARROW_BELOW")) : 200;
-            const bool narrow = a.nblk_m * ((a.N + 127) / 128) < narrow_below;
-            // short K loops (1x1 convolutions over <= 256 channels: 2-8 K steps) are dominated by the latency of the first
-            // loads and of the epilogue's stores; a 2-stage ring (32 KB) and a 128-register budget put four workgroups on a
-            // CU instead of three to cover it (tools/bench_conv.py; DML_CONV_SMALLK=0 switches it off)
-            static const int smallk = getenv("DML_CONV_SMALLK") ? atoi(getenv("DML_CONV_SMALLK")) : 0;
+            const bool narrow = a.nblk_m * ((a.N + 127) / 128) < 200;
             // tiles of the partially filled last round, split along K (DmlConvDesc::tail_*): when the remainder is at most
             // half a round of the CUs, q = CUs / remainder parts per tile give every CU the same share
             a.tail_full = 0;
             a.tail_q = 1;
-            static const bool tail_on = getenv("DML_CONV_TAIL") ? atoi(getenv("DML_CONV_TAIL")) != 0 : true;
-            if (tail_on && a.tail_ws != nullptr && a.N > 64 && !narrow) {
+            if (a.tail_ws != nullptr && a.N > 64 && !narrow) {
                 constexpr int CUS = 256;
                 const int ntiles = a.nblk_m * ((a.N + 127) / 128), full = ntiles / CUS * CUS, rem = ntiles - full;
                 if (full >= CUS && full <= 6 * CUS && rem > 0 && rem <= CUS / 2) {
@@ -2925,17 +2725,10 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             static const int bm256 = getenv("DML_CONV_BM256") ? atoi(getenv("DML_CONV_BM256")) : 1;
             const int tiles256 = ((a.M + 255) / 256) * (a.N / 128);
             const bool long_k = bm256 >= 64 ? a.Ktot >= bm256 : (a.Ktot >= 4608 || (a.Ktot >= 2304 && tiles256 >= 512));
-            // The 256-row tile runs as 4 waves on 128 x 64 WAVE tiles (conv_igemm_dma_kernel<..., 256, 128>: 32 MFMAs per
-            // wave and K step against 12 KB of fragment reads, half the barriers per FLOP) instead of 8 waves on 64 x 64:
-            // in the plan (serial profile, r03) decoder 3x3 data gradient 1.064 -> 0.957 ms, forward 0.869 -> 0.832, layer4
-            // 3x3 d2 data gradients 0.440 -> 0.370, forward 0.371 -> 0.345, ASPP 3x3 unchanged (~1000-1070 TFLOP/s either
-            // way); whole step 385.3 -> 388.3 images/s.  It does NOT help the layers the rule above keeps on 128-row tiles:
-            // layer3's 3x3 (K = 2304, 288 such tiles = one per CU at ONE wave per SIMD) 662 -> 640 / 603 -> 540 TFLOP/s.
-            // DML_CONV_WW: 0 = the 8-wave variant, 1 = this (default), >= 64 = also every eligible layer with K >= that
-            static const int ww = getenv("DML_CONV_WW") ? atoi(getenv("DML_CONV_WW")) : 1;
-            const bool ww_extra = ww >= 64 && a.Ktot >= ww;
-            const bool wide_wave = ww != 0;
-            if ((bm256 == 2 || (bm256 != 0 && long_k) || ww_extra) && a.N >= 128 && !narrow && a.N % 128 == 0) {
+            // The 256-row tile runs as 4 waves on 128 x 64 WAVE tiles (conv_igemm_dma_kernel<..., 256, 128>: 32 MFMAs per wave and
+            // K step against 12 KB of fragment reads, half the barriers per FLOP); the 8-wave variant on 64 x 64 wave tiles it
+            // replaced in round 3 (decoder 3x3 data gradient 1.064 -> 0.957 ms, whole step 385.3 -> 388.3 images/s) is gone.
+            if ((bm256 == 2 || (bm256 != 0 && long_k)) && a.N >= 128 && !narrow && a.N % 128 == 0) {
                 // 256-row tiles: whole tiles on the first multiple of 256 workgroups, the remainder split along K
                 constexpr int CUS = 256;
                 a.nblk_m = (a.M + 255) / 256;
@@ -2954,50 +2747,15 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                     }
                 }
                 const int grid = a.tail_q > 1 ? a.tail_full + (ntiles - a.tail_full) * a.tail_q : ntiles;
-                if (wide_wave)
-                    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3, 2, 256, 128>), dim3(grid), dim3(256), 0, st, a,
-                                       (uint32_t)xb, (uint32_t)wb);
-                else
-                    hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3, 4, 256>), dim3(grid), dim3(512), 0, st, a, (uint32_t)xb,
-                                       (uint32_t)wb);
+                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3, 2, 256, 128>), dim3(grid), dim3(256), 0, st, a, (uint32_t)xb,
+                                   (uint32_t)wb);
                 DML_LAUNCH_CHECK();
                 return 0;
-            }
-            // short K loops over more than a round of tiles: persistent workgroups (conv_igemm_dma_persist_kernel), as many
-            // as share the tile list evenly.  DML_CONV_PERSIST: 0 = off (default), otherwise the largest K-step count it
-            // applies to.  Measured (tools/bench_1x1.py, profiles/r02_persist_variant.txt): bit-identical and NOT faster --
-            // 1x1 K = 256 -> 1024 forward 58.1 -> 56.3 us, its data gradient with the BN-backward sums 85.7 -> 99.7 us, 3x3
-            // K = 576 91 -> 104 us: with three workgroups per CU the hardware already runs one tile's epilogue under the
-            // other two's K loops, and a static tile list loses the dispatcher's load balancing.
-            const int persist_kt = g_persist_kt < 0 ? (g_persist_kt = getenv("DML_CONV_PERSIST") ? atoi(getenv("DML_CONV_PERSIST")) : 0)
-                                                    : g_persist_kt;
-            if (MODE != 2 && persist_kt > 0 && !a.w_tiled && a.tail_q == 1 && !narrow && a.Ktot / BK >= 2 && a.Ktot / BK <= persist_kt) {
-                constexpr int SLOTS = 768;                      // three workgroups per CU
-                const bool wide = a.N > 64;
-                a.nblk_n = wide ? (a.N + 127) / 128 : (a.N + 63) / 64;
-                const int ntiles = a.nblk_m * a.nblk_n;
-                if (ntiles > SLOTS) {
-                    const int rounds = (ntiles + SLOTS - 1) / SLOTS;
-                    const int grid = ((ntiles + rounds - 1) / rounds + 7) / 8 * 8;
-                    constexpr int PM = MODE == 2 ? 1 : MODE;      // (never taken with MODE 2: no such instantiation)
-                    if (wide)
-                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<128, PM>), dim3(grid), dim3(NTHREADS), 0, st, a,
-                                           (uint32_t)xb, (uint32_t)wb, ntiles);
-                    else
-                        hipLaunchKernelGGL((conv_igemm_dma_persist_kernel<64, PM>), dim3(grid), dim3(NTHREADS), 0, st, a,
-                                           (uint32_t)xb, (uint32_t)wb, ntiles);
-                    DML_LAUNCH_CHECK();
-                    return 0;
-                }
             }
             if (a.tail_q > 1) {
                 a.nblk_n = (a.N + 127) / 128;
                 const int ntiles = a.nblk_m * a.nblk_n;
                 hipLaunchKernelGGL((conv_igemm_dma_kernel<128, MODE, 3>), dim3(a.tail_full + (ntiles - a.tail_full) * a.tail_q),
-                                   dim3(NTHREADS), 0, st, a, (uint32_t)xb, (uint32_t)wb);
-            } else if (MODE != 2 && a.N > 64 && !narrow && smallk > 0 && a.Ktot <= smallk) {
-                a.nblk_n = (a.N + 127) / 128;
-                hipLaunchKernelGGL((conv_igemm_dma_kernel<128, (MODE == 2 ? 1 : MODE), 2, 4>), dim3(a.nblk_m * a.nblk_n),
                                    dim3(NTHREADS), 0, st, a, (uint32_t)xb, (uint32_t)wb);
             } else if (a.N > 64 && !narrow) {
                 a.nblk_n = (a.N + 127) / 128;
@@ -3032,8 +2790,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             return 0;
         }
         if (a.f32_split && aligned && a.N > 32) {      // (f32_split == 2 launches the planes kernel did not take: three-term split)
-            static const int x3bn = getenv("DML_X3_BN") ? atoi(getenv("DML_X3_BN")) : 128;
-            if (a.N > 64 && x3bn != 64) {
+            if (a.N > 64) {
                 a.nblk_n = (a.N + 127) / 128;
                 hipLaunchKernelGGL((conv_igemm_x3_kernel<128, MODE>), dim3(a.nblk_m * a.nblk_n), dim3(NTHREADS), 0, st, a);
             } else {
@@ -3103,7 +2860,6 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if (d->dtype != DML_F32 && d->dtype != DML_BF16) return DML_EINVAL;
     const int vec = d->dtype == DML_BF16 ? 8 : 4;
     if (d->C % vec || d->ldx % vec) return DML_EALIGN;
-    if (d->pre_scale || d->pre_shift) return DML_EUNSUPPORTED;
     if (d->mode != 0 && d->mode != 1) return DML_EINVAL;
     if (d->mode == 1 && d->stride != 1 && d->stride != 2) return DML_EUNSUPPORTED;
     if (d->B <= 0 || d->Ho <= 0 || d->Wo <= 0 || d->N <= 0 || d->R <= 0 || d->S <= 0) return DML_EINVAL;
@@ -3193,22 +2949,10 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
 }
 
-// tuning aid (not part of the ABI header): the bf16 128x128 forward kernel with parts removed
-// tests / tuning: K steps per barrier of the large weight-gradient kernel (returns the previous setting)
-extern "C" int dml_debug_wgrad_depth(int depth) {
-    const int prev = wgrad_depth();
-    g_wgrad_depth = depth == 1 ? 1 : 2;
-    return prev;
-}
-
-// tests / tuning: switch the persistent short-K kernel in-process (returns the previous setting)
-extern "C" int dml_debug_conv_persist(int max_k_steps) {
-    const int prev = g_persist_kt;
-    g_persist_kt = max_k_steps;
-    return prev;
-}
-
-extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream) {
+// tuning builds only (make tuning -> libdmlnet_hip_tuning.so; tools/bench_conv.py abl / phases / dmaphases): the 128 x 128
+// forward kernels with parts removed or with s_memtime stamps.  Not part of the ABI, not in the product library.
+#ifdef DML_TUNING
+extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, float* dbg, const float* aux0, const float* aux1, void* stream) {
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.y = d->y; a.bias = nullptr; a.stats = d->stats;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
@@ -3218,7 +2962,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     a.nblk_m = (a.M + 127) / 128; a.nblk_n = (a.N + 127) / 128;
     a.div_wo = make_fastdiv((uint32_t)d->Wo); a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
-    a.dbg = const_cast<float*>(d->pre_scale);
+    a.dbg = dbg;
     a.bnr_y = nullptr; a.bnr_mask = nullptr; a.bnr_mean = nullptr; a.bnr_invstd = nullptr; a.bnr_partials = nullptr;
     a.bnr_ldy = 0; a.bnr_relu = 0;
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
@@ -3239,7 +2983,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     }
     else if (abl == 4) {
         a.dbg = nullptr;
-        a.bnr_mean = d->pre_scale; a.bnr_invstd = d->pre_shift;       // per INPUT channel: the probe's scale / shift
+        a.bnr_mean = aux0; a.bnr_invstd = aux1;       // per INPUT channel: the probe's scale / shift
         if (!a.bnr_mean || !a.bnr_invstd) return DML_EINVAL;
         hipLaunchKernelGGL((conv_igemm_kernel<bf16_t, 128, true, 0, 4>), grid, dim3(NTHREADS), 0, st, a);
     }
@@ -3247,6 +2991,8 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, void* stream
     DML_LAUNCH_CHECK();
     return 0;
 }
+
+#endif
 
 extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     if (!d || !d->x || !d->dy || !d->dw) return DML_EINVAL;
@@ -3290,8 +3036,7 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     // With a workspace every weight gradient is a fixed-order sum of slabs: the train step is bitwise reproducible.  (Small
     // weight tensors -- below 64 K elements -- used to take fp32 atomics instead, the reduce pass being latency-bound there;
     // DML_WGRAD_ATOMICS=1 restores that.)  Without a workspace: atomics.
-    static const bool small_atomics = getenv("DML_WGRAD_ATOMICS") && atoi(getenv("DML_WGRAD_ATOMICS")) != 0;
-    const bool use_ws = d->ws != nullptr && (!small_atomics || plane >= 65536 || cm != d->C);
+    const bool use_ws = d->ws != nullptr;
     int splitk = d->splitk;
     if (splitk <= 0) {
         const int base = a.nblk_n * a.nblk_k;
@@ -3316,10 +3061,9 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     // splits and the slab traffic eats the gain, so those run as 128 workgroups (32 splits): standalone that is a
     // few % slower than the small-tile kernel, but the weight gradients share the chip with the main stream and what
     // counts there is CU-time -- whole step +0.75 % (3 interleaved A/B runs of bench.py).
-    static const bool wg_v1 = getenv("DML_WGRAD_V1") != nullptr;
     const int64_t xb64 = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2;
     const int64_t yb64 = (((int64_t)a.M - 1) * a.ldy + a.N) * 2;
-    if (!wg_v1 && d->dtype == DML_BF16 && use_ws && a.N % 256 == 0 && (a.N / 256) * ((a.Ktot + 255) / 256) >= 4 &&
+    if (d->dtype == DML_BF16 && use_ws && a.N % 256 == 0 && (a.N / 256) * ((a.Ktot + 255) / 256) >= 4 &&
         tiles >= 16 &&
         xb64 < (1ll << 31) && yb64 < (1ll << 31) && (int64_t)(a.B + 1) * a.Hi * a.Wi < (1 << 24) && a.M < (1 << 24) &&
         a.ldx < (1 << 22) && a.ldy < (1 << 22)) {
@@ -3351,10 +3095,7 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         a.ws = d->ws;
         a.slab_tiles = (tiles + sk - 1) / sk;
         sk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
-        if (wgrad_depth() == 2)
-            hipLaunchKernelGGL(conv_wgrad_big_kernel<2>, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
-        else
-            hipLaunchKernelGGL(conv_wgrad_big_kernel<1>, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
+        hipLaunchKernelGGL(conv_wgrad_big_kernel<WGRAD_DEPTH>, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), 1), dim3(256), 0, st, d->ws, d->dw, sk, nrs,
                            cm, d->C, 1, 0);
@@ -3363,10 +3104,9 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
     }
     a.ws = use_ws ? d->ws : nullptr;
     // N <= 64 (bf16): 64 x 256 tiles instead of half-empty 128 x 128 ones
-    static const bool n64_on = getenv("DML_WGRAD_N64") ? atoi(getenv("DML_WGRAD_N64")) != 0 : true;
     // (measured, tools/bench_conv.py wgrad at 192 x 192: 3x3 64 -> 64 164 -> 160 us; the 1x1 layers are bound by the
     // operand loads, not by the idle MFMA rows, and LOSE 20 % with the wider x tile -- they stay on the 128 x 128 kernel)
-    const bool n64 = n64_on && d->dtype == DML_BF16 && a.N <= 64 && a.R * a.S > 1;
+    const bool n64 = d->dtype == DML_BF16 && a.N <= 64 && a.R * a.S > 1;
     if (n64) {
         a.nblk_n = 1;
         a.nblk_k = (a.Ktot + 255) / 256;
@@ -3492,10 +3232,7 @@ extern "C" int dml_conv_wgrad_group(const DmlWgradDesc* const* descs, int n, flo
         off += (int64_t)sk[j] * plane[j];
     }
     hipStream_t st = static_cast<hipStream_t>(stream);
-    if (wgrad_depth() == 2)
-        hipLaunchKernelGGL(conv_wgrad_group_kernel<2>, dim3(g.start[n]), dim3(WB_THREADS), 0, st, g);
-    else
-        hipLaunchKernelGGL(conv_wgrad_group_kernel<1>, dim3(g.start[n]), dim3(WB_THREADS), 0, st, g);
+    hipLaunchKernelGGL(conv_wgrad_group_kernel<WGRAD_DEPTH>, dim3(g.start[n]), dim3(WB_THREADS), 0, st, g);
     hipLaunchKernelGGL(wgrad_reduce_group_kernel, dim3(grid_for(max_items, 256, 1024), n), dim3(256), 0, st, r);
     DML_LAUNCH_CHECK();
     return 0;

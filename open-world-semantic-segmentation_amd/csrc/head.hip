@@ -1087,7 +1087,7 @@ extern "C" int dml_proto_dist_fwd(const float* x_nchw, const float* protos, floa
     hipStream_t st = static_cast<hipStream_t>(stream);
     if (HW % 4 == 0 && C == 16 && K == 16) {
         const int64_t groups = (int64_t)B * HW / 4;
-        static const bool nt = getenv("DML_DIST_NT") ? atoi(getenv("DML_DIST_NT")) != 0 : DIST_NT_DEFAULT;
+        constexpr bool nt = DIST_NT_DEFAULT;
         if (nt)
             hipLaunchKernelGGL(proto_dist_fwd_c16_kernel<true>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st,
                                x_nchw, protos, logits, feats, argmax, dissum, B, HW);
@@ -1118,9 +1118,9 @@ extern "C" int dml_upsample_dist_fwd(const float* e, const float* protos, float*
     if (C <= 0 || C > MAXC || K <= 0 || K > MAXK) return DML_EUNSUPPORTED;
     const float sy = (float)h / (float)H, sx = (float)w / (float)W;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    static const bool staged = getenv("DML_UPS_STAGED") ? atoi(getenv("DML_UPS_STAGED")) != 0 : true;
+    constexpr bool staged = true;      // (the gathered variant it replaced: profiles/r02_dist_variants.txt)
     if (staged && H == 4 * h && W == 4 * w && C == 16 && K == 16 && argmax == nullptr && dissum == nullptr) {
-        static const bool nt4 = getenv("DML_DIST_NT") ? atoi(getenv("DML_DIST_NT")) != 0 : DIST_NT_DEFAULT;
+        constexpr bool nt4 = DIST_NT_DEFAULT;
         const int64_t blocks = (int64_t)B * (h + 1) * ((W + 255) / 256);
         if (blocks >= (1ll << 31)) return DML_EINVAL;
         if (nt4)
@@ -1131,7 +1131,7 @@ extern "C" int dml_upsample_dist_fwd(const float* e, const float* protos, float*
                                feats, B, h, w);
     } else if (W % 4 == 0 && C == 16 && K == 16 && argmax == nullptr && dissum == nullptr) {
         const int64_t groups = (int64_t)B * H * (W / 4);
-        static const bool nt = getenv("DML_DIST_NT") ? atoi(getenv("DML_DIST_NT")) != 0 : DIST_NT_DEFAULT;
+        constexpr bool nt = DIST_NT_DEFAULT;
         if (nt)
             hipLaunchKernelGGL(upsample_dist_fwd_c16_kernel<true>, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, st, e,
                                protos, logits, feats, B, h, w, H, W, sy, sx);

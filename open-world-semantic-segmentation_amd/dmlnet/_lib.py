@@ -9,7 +9,9 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libdmlnet_hip.so")
+# DML_LIB_PATH: another build of the same library (A/B runs of two builds, the tuning build `make tuning`) -- selected here, not by
+# copying over the in-tree file another process may have mapped
+LIB_PATH = os.environ.get("DML_LIB_PATH") or os.path.join(_HERE, "libdmlnet_hip.so")
 
 DML_F32, DML_BF16 = 0, 1
 STAT_ROWS = 64
@@ -23,12 +25,11 @@ c_f = C.c_float
 
 class ConvDesc(C.Structure):
     _fields_ = [("x", c_p), ("w", c_p), ("y", c_p), ("bias", c_p), ("stats", c_p),
-                ("pre_scale", c_p), ("pre_shift", c_p),
                 ("B", C.c_int32), ("Hi", C.c_int32), ("Wi", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32),
                 ("Ho", C.c_int32), ("Wo", C.c_int32), ("N", C.c_int32), ("ldy", C.c_int32),
                 ("R", C.c_int32), ("S", C.c_int32), ("stride", C.c_int32), ("dil", C.c_int32),
                 ("pad", C.c_int32), ("dtype", C.c_int32), ("y_f32", C.c_int32), ("accum", C.c_int32),
-                ("mode", C.c_int32), ("pre_relu", C.c_int32),
+                ("mode", C.c_int32),
                 # mode 1: fused BN-backward partial sums of the tensor being written (see the header)
                 ("bnr_y", c_p), ("bnr_mask", c_p), ("bnr_mean", c_p), ("bnr_invstd", c_p), ("bnr_partials", c_p),
                 ("bnr_ldy", C.c_int32), ("bnr_relu", C.c_int32),

@@ -533,10 +533,9 @@ class Plan:
     def conv_fwd(self, x: Act, conv: nn.Conv2d, y: Act, w, stats_ptr, bias_ptr=None, post=None, N=None):
         kh, kw, s, d, p, Ho, Wo = self.conv_geom(conv, x)
         assert (Ho, Wo) == (y.H, y.W), ((Ho, Wo), (y.H, y.W))
-        dsc = ConvDesc(x=x.ptr, w=w.data_ptr(), y=y.ptr, bias=bias_ptr, stats=stats_ptr, pre_scale=None,
-                       pre_shift=None, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
+        dsc = ConvDesc(x=x.ptr, w=w.data_ptr(), y=y.ptr, bias=bias_ptr, stats=stats_ptr, B=x.B, Hi=x.H, Wi=x.W, C=x.C, ldx=x.ld, Ho=Ho, Wo=Wo,
                        N=N or conv.out_channels, ldy=y.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt,
-                       y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0, pre_relu=0)
+                       y_f32=1 if (y.f32 and self.dtype != torch.float32) else 0, accum=0, mode=0)
         self.set_planes(dsc, x, w, dsc.N, kh * kw * x.C, self.fwd)
         dsc.w_tiled = 1 if getattr(w, "tiled", False) else 0
         dsc.ws_min_tiles = self.ws_min_tiles
@@ -557,10 +556,9 @@ class Plan:
         this one (only looked at for staged gradients, stage_grad32)."""
         gx = self.grad_of(x)
         kh, kw, s, d, p, _, _ = self.conv_geom(conv, x)
-        dsc = ConvDesc(x=dy.ptr, w=wt.data_ptr(), y=gx.ptr, bias=None, stats=None, pre_scale=None,
-                       pre_shift=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld, Ho=x.H, Wo=x.W, N=x.C,
+        dsc = ConvDesc(x=dy.ptr, w=wt.data_ptr(), y=gx.ptr, bias=None, stats=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld, Ho=x.H, Wo=x.W, N=x.C,
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
-                       accum=1 if x.root.grad_init else 0, mode=1, pre_relu=0)
+                       accum=1 if x.root.grad_init else 0, mode=1)
         self.set_planes(dsc, dy, wt, x.C, kh * kw * dy.C, self.bwd)
         dsc.w_tiled = 1 if getattr(wt, "tiled", False) else 0
         dsc.ws_min_tiles = self.ws_min_tiles

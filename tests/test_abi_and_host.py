@@ -26,6 +26,11 @@ def test_library_exports_every_declared_symbol():
     for s in syms:
         assert hasattr(lib, s), "missing export " + s
     assert sorted(_lib.EXPORTS) == syms, "binding and header disagree"
+    # the product library exports exactly the header's entry points: no tuning / debug symbols (those live in `make tuning`)
+    import subprocess
+    nm = subprocess.run(["nm", "-D", "--defined-only", _lib.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("dml_") and " T " in ln})
+    assert exported == syms, (sorted(set(exported) - set(syms)), sorted(set(syms) - set(exported)))
     lib2 = _lib.load()
     assert lib2.dml_abi_version() == 2
     assert lib2.dml_target_arch() == b"gfx950"
@@ -33,18 +38,18 @@ def test_library_exports_every_declared_symbol():
 
 def test_struct_layout_matches_header():
     from dmlnet._lib import ConvDesc, WgradDesc
-    # 7 ptr + 19 int32 (+4 pad) | bnr: 5 ptr + 2 int32 | post: 4 ptr + 2 int32 | tail: ptr, int64, ptr, 2 int32 |
-    # res: 2 ptr + 2 int32
-    assert ctypes.sizeof(ConvDesc) == 7 * 8 + 19 * 4 + 4 + 5 * 8 + 2 * 4 + 4 * 8 + 2 * 4 + 8 + 8 + 8 + 2 * 4 + 2 * 8 + 2 * 4 + 8 + 2 * 4 + 2 * 4 + 6 * 8
-    assert ConvDesc.ws_min_tiles.offset == 300 and ConvDesc.x_planes.offset == 304 and ConvDesc.w_plane_stride.offset == 344
-    assert ConvDesc.tail_ws.offset == 224 and ConvDesc.tail_counters_len.offset == 248
-    assert ConvDesc.res_dz.offset == 256 and ConvDesc.res_ld.offset == 272
-    assert ConvDesc.acc32.offset == 280 and ConvDesc.acc32_ld.offset == 288 and ConvDesc.f32_split.offset == 292 and ConvDesc.w_tiled.offset == 296
-    assert ConvDesc.bnr_y.offset == 136 and ConvDesc.bnr_ldy.offset == 176 and ConvDesc.post_scale.offset == 184
+    # 5 ptr + 18 int32 | bnr: 5 ptr + 2 int32 | post: 4 ptr + 2 int32 | tail: ptr, int64, ptr, 2 int32 | res: 2 ptr + 2 int32 |
+    # acc32: ptr + int32, f32_split, w_tiled, ws_min_tiles | planes: 4 ptr + 2 int64
+    assert ctypes.sizeof(ConvDesc) == 328
+    assert ConvDesc.B.offset == 40 and ConvDesc.mode.offset == 40 + 17 * 4
+    assert ConvDesc.bnr_y.offset == 112 and ConvDesc.bnr_ldy.offset == 152 and ConvDesc.post_scale.offset == 160
+    assert ConvDesc.tail_ws.offset == 200 and ConvDesc.tail_counters_len.offset == 224
+    assert ConvDesc.res_dz.offset == 232 and ConvDesc.res_ld.offset == 248
+    assert ConvDesc.acc32.offset == 256 and ConvDesc.acc32_ld.offset == 264 and ConvDesc.f32_split.offset == 268 and ConvDesc.w_tiled.offset == 272
+    assert ConvDesc.ws_min_tiles.offset == 276 and ConvDesc.x_planes.offset == 280 and ConvDesc.w_plane_stride.offset == 320
     from dmlnet._lib import BnEvalDesc
     assert ctypes.sizeof(BnEvalDesc) == 48
     assert ctypes.sizeof(WgradDesc) == 3 * 8 + 17 * 4 + 4 + 8 + 8 + 2 * 4 + 6 * 8 and WgradDesc.f32_split.offset == 112 and WgradDesc.x_planes.offset == 120
-    assert ConvDesc.B.offset == 56 and ConvDesc.pre_relu.offset == 56 + 18 * 4
     from dmlnet._lib import PrepDesc
     assert ctypes.sizeof(PrepDesc) == 48 and PrepDesc.w_tiled.offset == 40 and PrepDesc.wt_tiled.offset == 44
     from dmlnet._lib import AugSample

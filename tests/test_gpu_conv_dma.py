@@ -22,20 +22,29 @@ def test_conv_ops_through_the_register_staged_kernel():
     assert "passed" in r.stdout
 
 
-@pytest.mark.parametrize("wide_wave", ["1", "0"])
-def test_every_unit_locally_exact_through_the_256_row_tiles(wide_wave):
-    """The 256-row tile variants of the LDS-DMA kernel run by themselves only on the long-K layers (K >= 4608, or the
-    decoder's 3x3 at 16 x 192 x 192); DML_CONV_BM256=2 forces them on every eligible layer of a bf16 train step -- fused
-    statistics, fused BN-backward sums, accumulate, the K-split tail -- and every unit must still be exact to one bf16
-    ulp.  wide_wave = 1 (default): 4 waves on 128 x 64 wave tiles (conv_igemm_dma_kernel<.., 256, 128>), all three cases
-    of the locally-exact gate incl. 768 x 768; 0: the 8-wave variant on 64 x 64 wave tiles, the small case."""
-    env = dict(os.environ, DML_CONV_BM256="2", DML_CONV_WW=wide_wave)
-    sel = "locally_exact" if wide_wave == "1" else "locally_exact and shape1"
+def test_every_unit_locally_exact_through_the_256_row_tiles():
+    """The 256-row tile of the LDS-DMA kernel (4 waves on 128 x 64 wave tiles, conv_igemm_dma_kernel<.., 256, 128>) runs by itself
+    only on the long-K layers (K >= 4608, or the decoder's 3x3 at 16 x 192 x 192); DML_CONV_BM256=2 forces it on every eligible
+    layer of a bf16 train step -- fused statistics, fused BN-backward sums, accumulate, the K-split tail -- and every unit must
+    still be exact to one bf16 ulp (all three cases of the locally-exact gate incl. 768 x 768)."""
+    env = dict(os.environ, DML_CONV_BM256="2")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_bf16_parity.py"), "-m", "gpu",
-                        "-q", "-x", "-k", sel, "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                        "-q", "-x", "-k", "locally_exact", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                        cwd=H.ROOT, timeout=1500)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert ("3 passed" if wide_wave == "1" else "1 passed") in r.stdout
+    assert "3 passed" in r.stdout
+
+
+def test_every_unit_locally_exact_through_the_wave_specialised_kernel():
+    """DML_WS_MIN_TILES=1 (DmlConvDesc.ws_min_tiles of every conv of the plan) + DML_CONV_WS=1 sends every eligible layer of
+    the bf16 train step through conv_ws_kernel -- 144-row tiles, 48-row statistics groups, fused BN-backward sums and
+    identity adds in its epilogue -- and every unit must still be exact to one bf16 ulp on its stored inputs."""
+    env = dict(os.environ, DML_WS_MIN_TILES="1", DML_CONV_WS="1")
+    r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_bf16_parity.py"), "-m", "gpu",
+                        "-q", "-x", "-k", "locally_exact", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                       cwd=H.ROOT, timeout=1500)
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
+    assert "3 passed" in r.stdout
 
 
 def test_sync_batchnorm_two_ranks_match_one_process():
@@ -174,6 +183,8 @@ def test_bench_gpus_flag_launches_ranks_itself():
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo"
     assert d["config"]["global_batch"] == 4 and d["value"] > 0
+    # self-diagnosis of the first real multi-GPU run: one 32 MB all-reduce on the comm stream, time and bus bandwidth on the line
+    assert d["config"]["allreduce_32mb_ms"] > 0 and d["config"]["allreduce_32mb_busbw_GBps"] > 0
 
 
 def test_bench_script_default_path_small():
@@ -188,6 +199,11 @@ def test_bench_script_default_path_small():
               "vs_baseline", "dtype", "data", "config", "roofline", "hbm_kernel", "input_pipeline"):
         assert k in d, k
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0 and d["value"] > 0
+    # the headline is the fp32-accurate mode (fp32 tensors, two-term fp16 split of the conv products); bf16 storage, the exact
+    # fp32 MFMA and the three-term split ride along as companions
+    assert d["dtype"] == "f32" and "two-term" in d["config"]["arithmetic"]
+    assert d["bf16_companion"]["value"] > 0 and d["bf16_companion"]["roofline"]["achieved"] > 0
+    assert d["fp32_exact_companion"]["value"] > 0 and d["fp32_exact_companion"]["three_term_split"]["value"] > 0
     r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--mode", "infer", "--height", "128", "--width",
                         "256", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, cwd=H.ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]

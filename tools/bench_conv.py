@@ -1,4 +1,6 @@
-"""Micro-benchmark (GPU box): conv kernels on the headline shapes; sweeps wgrad split-K and epilogue options."""
+"""Micro-benchmark (GPU box): conv kernels on the headline shapes; sweeps wgrad split-K and epilogue options.
+The abl / phases / dmaphases modes need the tuning build: make -C open-world-semantic-segmentation_amd/csrc tuning, then
+DML_LIB_PATH=open-world-semantic-segmentation_amd/dmlnet/libdmlnet_hip_tuning.so python3 tools/bench_conv.py phases"""
 import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path[:0] = [ROOT, os.path.join(ROOT, "open-world-semantic-segmentation_amd")]
@@ -37,8 +39,8 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
     if which in ("all", "fwd"):
         for use_stats in (True, False):
             d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=stats.data_ptr() if use_stats else None,
-                         pre_scale=None, pre_shift=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k,
-                         stride=1, dil=dil, pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
+                         B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k,
+                         stride=1, dil=dil, pad=pad, dtype=1, y_f32=0, accum=0, mode=0)
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
             line += "fwd%s %.1fus %.0fTF | " % ("+st" if use_stats else "", t * 1e6, fl / t / 1e12)
             if use_stats:                                # the same with the K-split of the last round's tiles allowed
@@ -50,17 +52,15 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
     if which == "abl":
         import ctypes
         lib.dml_debug_conv_ablate.restype = ctypes.c_int
-        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]
-        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, pre_scale=None, pre_shift=None,
-                     B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
-                     y_f32=0, accum=0, mode=0, pre_relu=0)
+        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
+        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
+                     y_f32=0, accum=0, mode=0)
         for abl, nm in ((0, "full"), (1, "no-global/no-ldswrite"), (2, "no-mfma")):
-            t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), abl, st))
+            t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), abl, None, None, None, st))
             line += "%s %.1fus (%.0fTF-equiv) | " % (nm, t * 1e6, fl / t / 1e12)
         # normalise-on-load probe: per-input-channel affine + ReLU between the global load and the LDS write
         psc, psh = torch.rand(Cc, device="cuda") + 0.5, torch.randn(Cc, device="cuda") * 0.1
-        d.pre_scale, d.pre_shift = psc.data_ptr(), psh.data_ptr()
-        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), 4, st))
+        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), 4, None, psc.data_ptr(), psh.data_ptr(), st))
         line += "affine+relu on load %.1fus | " % (t * 1e6)
         # what it would replace: one BN apply pass over the input tensor
         yb = torch.empty_like(x); mk = torch.empty(x.numel() // 8, dtype=torch.uint8, device="cuda")
@@ -71,13 +71,12 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
     if which == "phases":
         import ctypes
         lib.dml_debug_conv_ablate.restype = ctypes.c_int
-        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]
+        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         nblk = ((M + 127) // 128) * ((N + 127) // 128)
         dbg = torch.zeros(nblk * 4 * 8, device="cuda")
-        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, pre_scale=dbg.data_ptr(),
-                     pre_shift=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil,
-                     pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
-        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), 3, st))
+        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil,
+                     pad=pad, dtype=1, y_f32=0, accum=0, mode=0)
+        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), 3, dbg.data_ptr(), None, None, st))
         torch.cuda.synchronize()
         full = dbg.view(nblk * 4, 8).cpu()
         ph = full[:, :6]
@@ -101,9 +100,8 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         tws = torch.empty(512 * 128 * 128, device="cuda"); tcnt = torch.zeros(128, dtype=torch.int32, device="cuda")
         fl_ = 2.0 * M_ * N * k * k * Cc
         for nm, acc_, res_, bnr_ in (("plain", 0, 0, 0), ("accum", 1, 0, 0), ("res", 0, 1, 0), ("bnr", 0, 0, 1), ("res+bnr", 0, 1, 1)):
-            d = ConvDesc(x=dy.data_ptr(), w=wt.data_ptr(), y=gx.data_ptr(), bias=None, stats=None, pre_scale=None, pre_shift=None,
-                         B=B, Hi=H, Wi=W, C=N, ldx=N, Ho=H, Wo=W, N=Cc, ldy=Cc, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
-                         y_f32=0, accum=acc_, mode=1, pre_relu=0)
+            d = ConvDesc(x=dy.data_ptr(), w=wt.data_ptr(), y=gx.data_ptr(), bias=None, stats=None, B=B, Hi=H, Wi=W, C=N, ldx=N, Ho=H, Wo=W, N=Cc, ldy=Cc, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
+                         y_f32=0, accum=acc_, mode=1)
             d.tail_ws, d.tail_ws_elems, d.tail_counters, d.tail_counters_len = tws.data_ptr(), tws.numel(), tcnt.data_ptr(), 128
             if res_:
                 d.res_dz, d.res_mask, d.res_ld = rdz.data_ptr(), mask.data_ptr(), Cc
@@ -117,13 +115,12 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         # cycles per K step of the LDS-DMA 128 x 128 kernel by phase (s_memtime stamps, dml_debug_conv_ablate 5)
         import ctypes
         lib.dml_debug_conv_ablate.restype = ctypes.c_int
-        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p]
+        lib.dml_debug_conv_ablate.argtypes = [ctypes.POINTER(ConvDesc), ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p]
         nblk = ((M + 127) // 128) * ((N + 127) // 128)
         dbg = torch.zeros(nblk * 4 * 8, device="cuda")
-        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, pre_scale=dbg.data_ptr(),
-                     pre_shift=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil,
-                     pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
-        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), int(os.environ.get("DMAPH_ABL", "5")), st))
+        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil,
+                     pad=pad, dtype=1, y_f32=0, accum=0, mode=0)
+        t = timeit(lambda: lib.dml_debug_conv_ablate(C.byref(d), int(os.environ.get("DMAPH_ABL", "5")), dbg.data_ptr(), None, None, st))
         torch.cuda.synchronize()
         full = dbg.view(nblk * 4, 8).cpu()
         names = ("vmcnt-wait", "barrier", "dma-issue", "frag-read+mfma-issue")

@@ -23,6 +23,6 @@ for (H, Cc, N) in ((192, 64, 256), (96, 128, 512), (48, 256, 1024), (48, 1024, 2
     nsets = max(2, min(8, int(1.2e9 // (M * (Cc + N) * 2))))
     sets = [(torch.randn(B, H, H, Cc, device="cuda").to(bf), torch.empty(B, H, H, N, device="cuda", dtype=bf), torch.empty((M + 63) // 64 * N * 2, device="cuda")) for _ in range(nsets)]
     for use_stats in (0, 1):
-        descs = [ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=s.data_ptr() if use_stats else None, pre_scale=None, pre_shift=None, B=B, Hi=H, Wi=H, C=Cc, ldx=Cc, Ho=H, Wo=H, N=N, ldy=N, R=1, S=1, stride=1, dil=1, pad=0, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0) for (x, y, s) in sets]
+        descs = [ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=s.data_ptr() if use_stats else None, B=B, Hi=H, Wi=H, C=Cc, ldx=Cc, Ho=H, Wo=H, N=N, ldy=N, R=1, S=1, stride=1, dil=1, pad=0, dtype=1, y_f32=0, accum=0, mode=0) for (x, y, s) in sets]
         t = timeit([lambda d=d: lib.dml_conv_igemm(C.byref(d), st) for d in descs])
         print("DML_CONV_NT=%s %dx%d K=%d->N=%d stats=%d: %.1f us" % (os.environ.get("DML_CONV_NT", "1"), H, H, Cc, N, use_stats, t * 1e6), flush=True)

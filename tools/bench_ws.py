@@ -52,8 +52,8 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         for use_stats in (False, True):
             for nm, mt in (("ring", NEVER), ("ws", 1)):
                 d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=stats.data_ptr() if use_stats else None,
-                             pre_scale=None, pre_shift=None, B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k,
-                             stride=1, dil=dil, pad=pad, dtype=1, y_f32=0, accum=0, mode=0, pre_relu=0)
+                             B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k,
+                             stride=1, dil=dil, pad=pad, dtype=1, y_f32=0, accum=0, mode=0)
                 d.w_tiled, d.ws_min_tiles = 1, mt
                 t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
                 line += "fwd%s %s %.1fus %.0fTF | " % ("+st" if use_stats else "", nm, t * 1e6, fl / t / 1e12)
@@ -70,9 +70,8 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         if Cc % 128 == 0:
             for lab, res_, bnr_ in (("plain", 0, 0), ("bnr", 0, 1), ("res+bnr", 1, 1)):
                 for nm, mt in (("ring", NEVER), ("ws", 1)):
-                    d = ConvDesc(x=dy.data_ptr(), w=wt.data_ptr(), y=gx.data_ptr(), bias=None, stats=None, pre_scale=None, pre_shift=None,
-                                 B=B, Hi=H, Wi=W, C=N, ldx=N, Ho=H, Wo=W, N=Cc, ldy=Cc, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
-                                 y_f32=0, accum=0, mode=1, pre_relu=0)
+                    d = ConvDesc(x=dy.data_ptr(), w=wt.data_ptr(), y=gx.data_ptr(), bias=None, stats=None, B=B, Hi=H, Wi=W, C=N, ldx=N, Ho=H, Wo=W, N=Cc, ldy=Cc, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=1,
+                                 y_f32=0, accum=0, mode=1)
                     d.w_tiled, d.ws_min_tiles = 1, mt
                     if res_:
                         d.res_dz, d.res_mask, d.res_ld = rdz.data_ptr(), mask.data_ptr(), Cc

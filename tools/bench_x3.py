@@ -28,9 +28,8 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
     fl = 2.0 * M * N * k * k * Cc
     line = "B%d %dx%d C%d->N%d k%d d%d | " % (B, H, W, Cc, N, k, dil)
     for split in (0, 1):
-        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=stats.data_ptr(), pre_scale=None, pre_shift=None,
-                     B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=0, y_f32=0,
-                     accum=0, mode=0, pre_relu=0)
+        d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=stats.data_ptr(), B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N, R=k, S=k, stride=1, dil=dil, pad=pad, dtype=0, y_f32=0,
+                     accum=0, mode=0)
         d.f32_split = split
         t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
         line += "%s %.1f us %.0f TF | " % ("split" if split else "exact", t * 1e6, fl / t / 1e12)

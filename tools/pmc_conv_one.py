@@ -18,9 +18,9 @@ sets = [(torch.randn(B, H, H, Cc, device="cuda").to(torch.bfloat16), torch.zeros
         for _ in range(NL)]
 torch.cuda.synchronize()
 for x, y in sets:
-    d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, pre_scale=None, pre_shift=None, B=B,
+    d = ConvDesc(x=x.data_ptr(), w=w.data_ptr(), y=y.data_ptr(), bias=None, stats=None, B=B,
                  Hi=H, Wi=H, C=Cc, ldx=Cc, Ho=H, Wo=H, N=N, ldy=N, R=k, S=k, stride=1, dil=1, pad=k // 2, dtype=1, y_f32=0,
-                 accum=accum, mode=mode, pre_relu=0)
+                 accum=accum, mode=mode)
     assert lib.dml_conv_igemm(C.byref(d), st) == 0
 torch.cuda.synchronize()
 print("algorithmic per launch: read %.1f MB (x %.1f + w %.2f%s), write %.1f MB" % (

@@ -4,7 +4,9 @@
 # distance kernel), PMC HBM traffic per kernel and per conv shape class (bf16 and fp32), SQ counters per kernel template.
 #   gpurun -- bash tools/run_r03_profiles.sh v1   ->  gpurun_out/final_r03_v1/
 # Every profiled program is `python3 bench.py ...` directly after `--` (no env / bash -c hop), counters in their own runs.
-TAG=$1
+set -euo pipefail
+TAG=${1:?tag}
+: "${GRAFT_REPO_ROOT:?run under gpurun}"
 cd /tmp && export TMPDIR=/tmp
 R=$GRAFT_REPO_ROOT
 OUT=$R/gpurun_out/final_r03_$TAG
