@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DML_ABI_VERSION 2
+#define DML_ABI_VERSION 3
 
 enum { DML_F32 = 0, DML_BF16 = 1 };
 enum { DML_EINVAL = -1, DML_EALIGN = -2, DML_EUNSUPPORTED = -3 };
@@ -269,16 +269,22 @@ int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, void* stream
  * y, res, z have independent pitches.  `mask` (optional): one bit per element, z > 0, one BYTE per 16-byte vector of z --
  * DML_BF16: mask[m*(N/8) + c/8] bit c%8; DML_F32: mask[m*(N/4) + c/4] bit c%4 -- the backward passes then read 1 byte
  * instead of 16 bytes of z.  `amax` (optional): 1024 floats the caller zeroed; their maximum afterwards is max |z| (one
- * order-independent atomic maximum per workgroup, spread over the words: dml_h2_split, amax_known). */
+ * order-independent atomic maximum per workgroup, spread over the words: dml_h2_split, amax_known).
+ * `planes` (optional, DML_F32): the output also as the two fp16 planes a conv of the f16x2 mode reads (dml_h2_split's arithmetic and
+ * layout 0: hi at planes[m * ldp + c], lo `plane_stride` elements further), scaled by 1 / unscale[0], a power of two the caller
+ * fixed BEFORE this launch from a bound on |z| (dml_h2_bound_bn) -- no dml_h2_split pass over z then; z may be NULL when nothing
+ * reads the fp32 tensor. */
 int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
                  const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
-                 int dtype, float drop_p, uint64_t drop_seed, float* amax, void* stream);
+                 int dtype, float drop_p, uint64_t drop_seed, float* amax, void* planes, int64_t plane_stride,
+                 int32_t ldp, const float* unscale, void* stream);
 /* backward, pass 1: per-channel sums of g = dz*[z>0]*gscale and g*xhat -> partials[blocks][N][2]
  * ([z>0] from `mask` when given, else from z).
- * returns the number of partial rows through *nblocks (host int). */
+ * returns the number of partial rows through *nblocks (host int).  `gmax` (optional): 1024 zeroed floats, their maximum
+ * afterwards is max |g| (as `amax` of dml_bn_apply; input of dml_h2_bound_bn_bwd). */
 int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* save_mean,
                       const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
-                      int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream);
+                      int ldz, int relu, float gscale, int dtype, int* nblocks, float* gmax, void* stream);
 /* backward, pass 1b: fold partials, write dgamma/dbeta (+=) and the per-channel coefficients
  * coef[4][N] with dy = coef0*g + coef1*(y - coef3) + coef2  (coef3 = batch mean).
  * M = 0 selects a layer that normalised with FIXED statistics (BatchNorm2d.eval() inside a training step, the
@@ -289,10 +295,23 @@ int dml_bn_bwd_finalize(float* partials, int nblocks, int64_t M, int N, const fl
                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
                         float* coef, void* stream);
 /* backward, pass 2: dy = coef0*g + coef1*(y - coef3) + coef2; optionally dres (+)= g for the identity branch.  `amax`
- * (optional): max |dy|, as in dml_bn_apply. */
+ * (optional): max |dy|, as in dml_bn_apply.  `planes` / `plane_stride` / `ldp` / `unscale` (optional, DML_F32): dy as fp16 planes,
+ * as in dml_bn_apply (scale from dml_h2_bound_bn_bwd); dy may then be NULL. */
 int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* coef, void* dy,
                      void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
-                     int relu, float gscale, int dres_accum, int dtype, float* amax, void* stream);
+                     int relu, float gscale, int dres_accum, int dtype, float* amax, void* planes, int64_t plane_stride,
+                     int32_t ldp, const float* unscale, void* stream);
+/* Scale of a batch-statistics BatchNorm output's fp16 planes from a BOUND on its magnitude, available before the tensor is
+ * written: every normalised element obeys |y - mean| * invstd <= sqrt(count) (count = elements per channel over all ranks that
+ * share the statistics), so |z| <= max_c (|gamma_c| sqrt(count) + |beta_c|) * mult + max |res| (`mult`: 1, or the dropout's
+ * 1 / (1 - p); `res_amax`: NULL, or the 1024 amax words of the residual tensor) and, in the backward, |dy| <= max_c (|coef0_c| max|g|
+ * + |coef1_c| sqrt(count) / invstd_c + |coef2_c|) (`g_amax`: the words dml_bn_bwd_reduce raised).  work[1024] receives 1 / s, s the
+ * power of two that puts the bound into [2^14, 2^15) -- the `unscale` of the apply kernels and DmlConvDesc.x_unscale.  A bound 2^k
+ * above the true maximum costs the planes k of the ~12 binades over which an element keeps its full 2^-22 relative precision. */
+int dml_h2_bound_bn(const float* gamma, const float* beta, int N, int64_t count, float mult, const float* res_amax,
+                    float* work, void* stream);
+int dml_h2_bound_bn_bwd(const float* coef, const float* save_invstd, int N, int64_t count, const float* g_amax,
+                        float* work, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling (network/backbone/resnet.py:143; network/utils.py:320,326-329).
@@ -498,7 +517,7 @@ int dml_ood_measures(const float* conf, const int64_t* seg_label, const uint8_t*
  *           enqueued on `stream` so far (one of `events`, a ring of hipEvent_t, is recorded there)
  * Ops [first, last) are issued; on failure the index goes to *failed_op and the op's code is returned.
  * ---------------------------------------------------------------------------------------------- */
-#define DML_PLAN_MAX_ARGS 22
+#define DML_PLAN_MAX_ARGS 24
 typedef struct DmlPlanOp {
     int32_t fn, nargs;
     int32_t stream, wait;

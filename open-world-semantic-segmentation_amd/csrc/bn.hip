@@ -158,13 +158,31 @@ __device__ __forceinline__ void amax_publish(uint32_t amx, uint32_t* __restrict_
     }
 }
 
+// fp32 -> (hi, lo) fp16 planes of the power-of-two-scaled value (dml_h2_split's arithmetic), four elements: the BatchNorm apply
+// kernels write a conv operand's planes themselves when the scale is known beforehand (dml_h2_bound_bn / _bn_bwd)
+__device__ __forceinline__ void h2_store4(_Float16* __restrict__ hi_p, _Float16* __restrict__ lo_p, const float (&v)[4], const float s) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    h4 hi, lo;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float xs = v[e] * s;
+        const _Float16 h = (_Float16)xs;
+        hi[e] = h;
+        lo[e] = (_Float16)(xs - (float)h);
+    }
+    *reinterpret_cast<h4*>(hi_p) = hi;
+    *reinterpret_cast<h4*>(lo_p) = lo;
+}
+__device__ __forceinline__ void h2_store4(_Float16*, _Float16*, const float (&)[8], const float) {}      // (bf16 plans: no planes)
+
 template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
     const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, uint8_t* __restrict__ mask, int64_t M, int N,
     int ldy, int ldres, int ldz, int relu, float drop_p, uint64_t drop_seed, int CB, int RB, int rows_per_block,
-    uint32_t* __restrict__ amax) {
+    uint32_t* __restrict__ amax, _Float16* __restrict__ planes, int64_t plane_stride, int ldp, const float* __restrict__ unscale) {
     constexpr int V = Vec16<T>::N;
+    const float h2s = planes != nullptr ? 1.0f / unscale[0] : 1.0f;      // exact: a power of two
     const int NV = N / V;
     const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
     const int vcol = blockIdx.y * CB + col;
@@ -208,7 +226,8 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
                 for (int q = 0; q < V; ++q)
                     v[u][q] = drop_keep(drop_seed, (uint64_t)m * N + c + q, thresh) ? v[u][q] * keep_scale : 0.f;
             }
-            Vec16<T>::store(z + m * ldz + c, v[u]);
+            if (z != nullptr) Vec16<T>::store(z + m * ldz + c, v[u]);
+            if (planes != nullptr) h2_store4(planes + m * ldp + c, planes + plane_stride + m * ldp + c, v[u], h2s);
             if (mask != nullptr) {           // one byte per 16-byte vector: 8 bits (bf16) / 4 bits (fp32)
                 uint32_t bits = 0;
 #pragma unroll
@@ -258,9 +277,11 @@ template <typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
     const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const uint8_t* __restrict__ mask,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* __restrict__ partials,
-    int64_t M, int N, int lddz, int ldy, int ldz, int relu, float gscale, int rows_per_block, int chv, int rt) {
+    int64_t M, int N, int lddz, int ldy, int ldz, int relu, float gscale, int rows_per_block, int chv, int rt,
+    uint32_t* __restrict__ gmax) {
     constexpr int V = Vec16<T>::N;
     __shared__ float sh[256 * 2 * V];
+    uint32_t gmx = 0;                  // largest |g| this thread has seen (dml_h2_bound_bn_bwd)
     const int NV = N / V;
     const int col = threadIdx.x % chv, rl = threadIdx.x / chv;
     const int v = blockIdx.y * chv + col;
@@ -300,6 +321,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
                 for (int q = 0; q < V; ++q) {
                     const bool on = !relu || (use_mask ? ((bits[u] >> q) & 1u) != 0 : zz[u][q] > 0.f);
                     const float gg = on ? g[u][q] * gscale : 0.f;
+                    gmx = max(gmx, __float_as_uint(gg) & 0x7fffffffu);
                     sg[q] += gg;
                     sgx[q] += gg * (yy[u][q] - mu[q]) * is[q];
                 }
@@ -326,6 +348,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(
 #pragma unroll
         for (int q = 0; q < V; ++q) { p[2 * q] = sg[q]; p[2 * q + 1] = sgx[q]; }
     }
+    if (gmax != nullptr) amax_publish(gmx, gmax);
 }
 
 // many partial rows (the 64-row groups of a fused reduce on the 192 x 192 layers: 9216): chunks of R rows are summed
@@ -419,8 +442,10 @@ template <typename T, int U>
 __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
     const T* __restrict__ dz, const T* __restrict__ y, const T* __restrict__ z, const uint8_t* __restrict__ mask,
     const float* __restrict__ coef, T* __restrict__ dy, T* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy,
-    int lddres, int relu, float gscale, int dres_accum, int CB, int RB, int rows_per_block, uint32_t* __restrict__ amax) {
+    int lddres, int relu, float gscale, int dres_accum, int CB, int RB, int rows_per_block, uint32_t* __restrict__ amax,
+    _Float16* __restrict__ planes, int64_t plane_stride, int ldp, const float* __restrict__ unscale) {
     constexpr int V = Vec16<T>::N;
+    const float h2s = planes != nullptr ? 1.0f / unscale[0] : 1.0f;
     const int NV = N / V;
     const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
     const int vcol = blockIdx.y * CB + col;
@@ -469,7 +494,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
             float o[V];
 #pragma unroll
             for (int q = 0; q < V; ++q) o[q] = cA[q] * g[u][q] + cB[q] * (yy[u][q] - cM[q]) + cC[q];
-            Vec16<T>::store(dy + m * lddy + c, o);
+            if (dy != nullptr) Vec16<T>::store(dy + m * lddy + c, o);
+            if (planes != nullptr) h2_store4(planes + m * ldp + c, planes + plane_stride + m * ldp + c, o, h2s);
             if (amax != nullptr) {
 #pragma unroll
                 for (int q = 0; q < V; ++q) amx = max(amx, __float_as_uint(o[q]) & 0x7fffffffu);
@@ -628,11 +654,16 @@ extern "C" int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, v
 
 extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
                             const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
-                            int dtype, float drop_p, uint64_t drop_seed, float* amax, void* stream) {
-    if (!y || !z || !scale || !shift || !mean || M <= 0 || N <= 0) return DML_EINVAL;
-    if (!vec_ok(dtype, N) || !vec_ok(dtype, ldy) || !vec_ok(dtype, ldz) || (res && !vec_ok(dtype, ldres)))
+                            int dtype, float drop_p, uint64_t drop_seed, float* amax, void* planes, int64_t plane_stride,
+                            int32_t ldp, const float* unscale, void* stream) {
+    if (!y || (!z && !planes) || !scale || !shift || !mean || M <= 0 || N <= 0) return DML_EINVAL;
+    if (!vec_ok(dtype, N) || !vec_ok(dtype, ldy) || (z && !vec_ok(dtype, ldz)) || (res && !vec_ok(dtype, ldres)))
         return DML_EALIGN;
     if (M >= (1ll << 31)) return DML_EINVAL;
+    if (planes) {           // fp32 only: the output also (or only: z == NULL) as two fp16 planes scaled by 1 / unscale[0]
+        if (dtype != DML_F32 || !unscale || plane_stride <= 0 || ldp < N) return DML_EINVAL;
+        if ((ldp & 3) || (plane_stride & 3) || (reinterpret_cast<uintptr_t>(planes) & 7)) return DML_EALIGN;
+    }
     const int V = dtype == DML_BF16 ? 8 : 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype));
@@ -640,18 +671,20 @@ extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float
     if (dtype == DML_BF16)
         hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)y, (const bf16_t*)res,
                            (bf16_t*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
-                           g.rows_per_block, reinterpret_cast<uint32_t*>(amax));
+                           g.rows_per_block, reinterpret_cast<uint32_t*>(amax), (_Float16*)nullptr, (int64_t)0, 0,
+                           (const float*)nullptr);
     else
         hipLaunchKernelGGL((bn_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)y, (const float*)res,
                            (float*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
-                           g.rows_per_block, reinterpret_cast<uint32_t*>(amax));
+                           g.rows_per_block, reinterpret_cast<uint32_t*>(amax), static_cast<_Float16*>(planes), plane_stride,
+                           (int)ldp, unscale);
     DML_LAUNCH_CHECK();
     return 0;
 }
 
 extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* save_mean,
                                  const float* save_invstd, float* partials, int64_t M, int N, int lddz, int ldy,
-                                 int ldz, int relu, float gscale, int dtype, int* nblocks, void* stream) {
+                                 int ldz, int relu, float gscale, int dtype, int* nblocks, float* gmax, void* stream) {
     if (!dz || !y || !save_mean || !save_invstd || !partials || !nblocks || M <= 0 || N <= 0) return DML_EINVAL;
     if (relu && !z && !mask) return DML_EINVAL;
     if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || (relu && !mask && !vec_ok(dtype, ldz)))
@@ -671,11 +704,11 @@ extern "C" int dml_bn_bwd_reduce(const void* dz, const void* y, const void* z, c
     if (dtype == DML_BF16)
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<bf16_t>, grid, dim3(256), 0, st, (const bf16_t*)dz,
                            (const bf16_t*)y, (const bf16_t*)z, mask, save_mean, save_invstd, partials, M, N, lddz, ldy,
-                           ldz, relu, gscale, (int)rpb, chv, rt);
+                           ldz, relu, gscale, (int)rpb, chv, rt, reinterpret_cast<uint32_t*>(gmax));
     else
         hipLaunchKernelGGL(bn_bwd_reduce_kernel<float>, grid, dim3(256), 0, st, (const float*)dz,
                            (const float*)y, (const float*)z, mask, save_mean, save_invstd, partials, M, N, lddz, ldy,
-                           ldz, relu, gscale, (int)rpb, chv, rt);
+                           ldz, relu, gscale, (int)rpb, chv, rt, reinterpret_cast<uint32_t*>(gmax));
     DML_LAUNCH_CHECK();
     return 0;
 }
@@ -787,13 +820,18 @@ extern "C" int dml_bn_bwd_coef(const double* sums, int64_t M_total, int N, const
 
 extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, const uint8_t* mask, const float* coef, void* dy,
                                 void* dres, int64_t M, int N, int lddz, int ldy, int ldz, int lddy, int lddres,
-                                int relu, float gscale, int dres_accum, int dtype, float* amax, void* stream) {
-    if (!dz || !y || !coef || !dy || M <= 0 || N <= 0) return DML_EINVAL;
+                                int relu, float gscale, int dres_accum, int dtype, float* amax, void* planes,
+                                int64_t plane_stride, int32_t ldp, const float* unscale, void* stream) {
+    if (!dz || !y || !coef || (!dy && !planes) || M <= 0 || N <= 0) return DML_EINVAL;
     if (relu && !z && !mask) return DML_EINVAL;
-    if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || !vec_ok(dtype, lddy) ||
+    if (!vec_ok(dtype, N) || !vec_ok(dtype, lddz) || !vec_ok(dtype, ldy) || (dy && !vec_ok(dtype, lddy)) ||
         (relu && !mask && !vec_ok(dtype, ldz)) || (dres && !vec_ok(dtype, lddres)))
         return DML_EALIGN;
     if (M >= (1ll << 31)) return DML_EINVAL;
+    if (planes) {           // fp32 only: dy also (or only: dy == NULL) as two fp16 planes scaled by 1 / unscale[0]
+        if (dtype != DML_F32 || !unscale || plane_stride <= 0 || ldp < N) return DML_EINVAL;
+        if ((ldp & 3) || (plane_stride & 3) || (reinterpret_cast<uintptr_t>(planes) & 7)) return DML_EALIGN;
+    }
     const int V = dtype == DML_BF16 ? 8 : 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
     const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype));
@@ -802,11 +840,80 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
         hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)dz,
                            (const bf16_t*)y, (const bf16_t*)z, mask, coef, (bf16_t*)dy, (bf16_t*)dres, M, N, lddz, ldy,
                            ldz, lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block,
-                           reinterpret_cast<uint32_t*>(amax));
+                           reinterpret_cast<uint32_t*>(amax), (_Float16*)nullptr, (int64_t)0, 0, (const float*)nullptr);
     else
         hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)dz,
                            (const float*)y, (const float*)z, mask, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
-                           lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block, reinterpret_cast<uint32_t*>(amax));
+                           lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block, reinterpret_cast<uint32_t*>(amax),
+                           static_cast<_Float16*>(planes), plane_stride, (int)ldp, unscale);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- scale of a BatchNorm output's fp16 planes from a BOUND on its magnitude, known before the tensor exists -----------
+// Batch statistics bound the normalised value: sum_m (y_m - mean)^2 = count * var, so |y_m - mean| * invstd <= sqrt(count)
+// for every element, whatever the data.  Forward:  |z| <= max_c (|gamma_c| sqrt(count) + |beta_c|) * mult + max |res|.
+// Backward (dy = A g + Bc (y - mean) + C0, bn_bwd_finalize_kernel): |dy| <= max_c (|A_c| max|g| + |Bc_c| sqrt(count) / invstd_c
+// + |C0_c|).  The bounds sit 2^4 .. 2^8 above the true maxima of this network's tensors; the planes then resolve an element x
+// to 2^-22 |x| down to |x| ~ 2^-11 of the bound and to 2^-33 of the bound below -- invisible beside the 2^-22 of the large
+// elements of the same dot product.  (Running-statistics BatchNorm has no such bound: those outputs go through dml_h2_split.)
+namespace {
+__global__ __launch_bounds__(256) void h2_bound_kernel(const float* __restrict__ p0, const float* __restrict__ p1,
+                                                       const float* __restrict__ p2, const float* __restrict__ invstd, int N,
+                                                       float root_count, float mult, const float* __restrict__ words,
+                                                       float* __restrict__ work, int bwd) {
+    __shared__ float sh[4];
+    __shared__ uint32_t shw[4];
+    uint32_t wm = 0;
+    if (words != nullptr)
+        for (int i = threadIdx.x; i < 1024; i += 256) wm = max(wm, __float_as_uint(words[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, o, 64));
+    if ((threadIdx.x & 63) == 0) shw[threadIdx.x >> 6] = wm;
+    __syncthreads();
+    const float wmax = __uint_as_float(max(max(shw[0], shw[1]), max(shw[2], shw[3])));      // max |res| (forward) / max |g| (backward)
+    float b = 0.f;
+    for (int n = threadIdx.x; n < N; n += 256) {
+        float v;
+        if (!bwd) v = fabsf(p0 ? p0[n] : 1.f) * root_count + fabsf(p1 ? p1[n] : 0.f);
+        else v = fabsf(p0[n]) * wmax + fabsf(p1[n]) * root_count / invstd[n] + fabsf(p2[n]);
+        b = fmaxf(b, v);                                       // (NaN coefficients: fmaxf drops them; the tensor carries them anyway)
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    b = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    b = bwd ? b : b * mult + wmax;
+    b *= 1.0009765625f;                                        // rounding of the statistics and of this sum
+    // scale = 2^(14 - floor(log2 b)): b * scale in [2^14, 2^15), as dml_h2_split
+    const uint32_t m = __float_as_uint(b);
+    float s = 1.0f;
+    if (m != 0) {
+        int se = 14 - ((int)(m >> 23) - 127);
+        se = se > 127 ? 127 : (se < -126 ? -126 : se);
+        s = __uint_as_float((uint32_t)(se + 127) << 23);
+        if (m >= 0x7f800000u) s = 1.0f;                        // the bound overflowed: the tensor is not finite either
+    }
+    work[1024] = 1.0f / s;
+}
+}  // namespace
+
+extern "C" int dml_h2_bound_bn(const float* gamma, const float* beta, int N, int64_t count, float mult, const float* res_amax,
+                               float* work, void* stream) {
+    if (!work || N <= 0 || count <= 0 || !(mult > 0.f)) return DML_EINVAL;
+    hipLaunchKernelGGL(h2_bound_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), gamma, beta, (const float*)nullptr,
+                       (const float*)nullptr, N, sqrtf((float)count) * 1.0001f, mult, res_amax, work, 0);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+extern "C" int dml_h2_bound_bn_bwd(const float* coef, const float* save_invstd, int N, int64_t count, const float* g_amax,
+                                   float* work, void* stream) {
+    if (!coef || !save_invstd || !g_amax || !work || N <= 0 || count <= 0) return DML_EINVAL;
+    hipLaunchKernelGGL(h2_bound_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), coef, coef + N, coef + 2 * N,
+                       save_invstd, N, sqrtf((float)count) * 1.0001f, 1.0f, g_amax, work, 1);
     DML_LAUNCH_CHECK();
     return 0;
 }

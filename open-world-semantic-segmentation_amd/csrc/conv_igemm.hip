@@ -1313,6 +1313,12 @@ typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
 constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
 constexpr int WS_STAT_ROWS = 48;               // rows per statistics group of this kernel
 constexpr int WS_NST = 6, WS_D = 2;            // ring stages; stages in flight per loader behind the published one
+#ifndef DML_WS_ABL
+#define DML_WS_ABL 0                           // tuning builds: 1 = no MFMAs, 2 = no DMA (tools/ab_lib.sh with bench_h2.py)
+#endif
+#ifndef DML_WS_PLANES_NLD
+#define DML_WS_PLANES_NLD 3                    // loader waves of the two-plane instantiation
+#endif
 
 // LDS-DMA piece (16 B per lane, 1 KB per wave) from inline asm: m0 = LDS byte address of the piece (wave-uniform), voff per
 // lane, soff scalar; offsets beyond the descriptor write zeros.  Not counted by hipcc: completion by wait_vmcnt only.
@@ -1358,7 +1364,7 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
     const int lchunk = (lane & 3) ^ ((0x78 >> (((lane >> 4) & 3) * 2)) & 3);
     const int sh2 = (MODE != 0 && a.stride == 2) ? 1 : 0;
     const int KT = a.Ktot / BK;
-    uint32_t g = 0;
+    uint32_t g = 0, pub = 0;               // K steps issued / published as landed
     int base[MYP];
     uint32_t mask[MYP];
     int prev_blk_m = -1;
@@ -1414,11 +1420,21 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
             if (g >= (uint32_t)NST) {
                 // the stage this K step overwrites must have been read by every consumer wave
                 const uint32_t need = g - NST + 1;
+                bool drained = false;
                 for (;;) {
                     uint32_t mn = ws_ld(consumed);
 #pragma unroll
                     for (int w = 1; w < NCW; ++w) mn = min(mn, ws_ld(consumed + w));
                     if (mn >= need) break;
+                    if (!drained) {
+                        // ring full, nothing to issue: let everything in flight land and publish it now instead of D issues
+                        // later -- with the shallow ring of the two-plane mode (3 stages) the consumers otherwise only ever
+                        // see one stage ahead
+                        wait_vmcnt<0>();
+                        ws_st(ready + LW, g);
+                        pub = g;
+                        drained = true;
+                    }
                     __builtin_amdgcn_s_sleep(1);
                 }
                 asm volatile("" ::: "memory");
@@ -1430,6 +1446,7 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
 #pragma unroll
             for (int q = 0; q < MYP; ++q) {
                 const int p = q * NLD + LW;
+                if (DML_WS_ABL == 2) continue;
                 if (p < PL * PA) {
                     const uint32_t voff = (mask[q] & tapbit) ? (uint32_t)(base[q] + soff) : OOB;
                     ws_dma16(rs_x, sbase + p * 1024, voff, p < PA ? 0u : a.x_plane_bytes);
@@ -1444,9 +1461,10 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
                 if (++is == a.S) { is = 0; ++ir; }
             }
             ++g;
-            if (g > (uint32_t)D) {
+            if (g > (uint32_t)D + pub) {
                 wait_vmcnt<D * MYP>();             // at most D stages of this wave's pieces in flight: stage g - 1 - D has landed
-                ws_st(ready + LW, g - D);
+                pub = g - D;
+                ws_st(ready + LW, pub);
             }
         }
     }
@@ -1557,40 +1575,83 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             }
             if (kt < KT) step(bfA, bfB, alA, alB, false);
         } else {
-            // two fp16 planes per operand: x s = xh + xl, w t = wh + wl; per 16 x 16 x 32 block the three products wl xh, wh xl,
-            // wh xh (the dropped wl xl is below 2^-22 of the block) -- 108 MFMAs per K step against 26 fragment reads.  The
-            // weight fragments of a step are read at its start (exposed: ~8 % of the step), the activation fragments of row
-            // group j + 1 under the twelve MFMAs of group j.
-            for (int kt = 0; kt < KT; ++kt) {
-                wait_ready(g + 1);
+            // two fp16 planes per operand: x s = xh + xl, w t = wh + wl; per 16 x 16 x 32 block the three products wh xh, wh xl,
+            // wl xh (the dropped wl xl is below 2^-22 of the block) -- 108 MFMAs per K step against 26 fragment reads.
+            // Every fragment is in flight one row group (12 MFMAs, ~200 cycles) before its first use: the activation pair of
+            // group j + 1 is read ahead of group j's MFMAs (two register slots; 9 groups per step, so the slot of group 0
+            // alternates from step to step: P), the hi weight fragments of step k + 1 under groups 5.. of step k (two sets,
+            // alternating), the lo weight fragments -- used LAST in every group -- right after step k's final MFMAs, under the
+            // first eight of step k + 1.  __builtin_amdgcn_sched_barrier pins that order: left to itself hipcc sinks each
+            // read to just before its use and waits lgkmcnt(0) there, nine exposed LDS latencies per step (measured: 1.45 us per
+            // step against 0.72 of MFMA issue).
+            mfma_f16x8 bhA[NT], bhB[NT], bl[NT], ah[2], al[2];
+            uint32_t pl[NLD];
+            wait_ready(g + 1);                                      // first K step of the tile: exposed once per tile
+            {
                 const char* sb = smem + (g % NST) * SB;
-                mfma_f16x8 bh[NT], bl[NT], ah[2], al[2];
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    bh[i] = *reinterpret_cast<const mfma_f16x8*>(sb + b_off[i]);
+                    bhA[i] = *reinterpret_cast<const mfma_f16x8*>(sb + b_off[i]);
                     bl[i] = *reinterpret_cast<const mfma_f16x8*>(sb + b_off[i] + B_PLANE);
                 }
                 ah[0] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[0]);
                 al[0] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[0] + A_PLANE);
+            }
+            auto step = [&](auto pc, mfma_f16x8 (&bc)[NT], mfma_f16x8 (&bn)[NT], const bool has_next) {
+                constexpr int P = decltype(pc)::value;
+                const char* sb = smem + (g % NST) * SB;
+                // (last step of the tile: the "next" reads fall on this stage again and are never used)
+                const char* sn = has_next ? smem + ((g + 1) % NST) * SB : sb;
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     if (j + 1 < MT) {
-                        ah[(j + 1) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1]);
-                        al[(j + 1) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1] + A_PLANE);
+                        ah[(j + 1 + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1]);
+                        al[(j + 1 + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1] + A_PLANE);
                     } else {
                         asm volatile("" ::: "memory");
                         ws_st(consumed + wave, g + 1);      // every read of stage g has been issued
+                        ah[(MT + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sn + a_off[0]);
+                        al[(MT + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sn + a_off[0] + A_PLANE);
+                    }
+                    if (j == 1) {                           // the next step's poll, answered under the MFMAs
+#pragma unroll
+                        for (int w = 0; w < NLD; ++w) pl[w] = ws_ld(ready + w);
+                    }
+                    if (j == 4) {
+                        rflag = pl[0];
+#pragma unroll
+                        for (int w = 1; w < NLD; ++w) rflag = min(rflag, pl[w]);
+                        if (has_next) wait_ready(g + 2);
+                    }
+                    if (j == 5) {
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) bn[i] = *reinterpret_cast<const mfma_f16x8*>(sn + b_off[i]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (DML_WS_ABL == 1) {
+#pragma unroll
+                        for (int i = 0; i < NT; ++i) acc[i][j][0] += (float)(bc[i][0] + bl[i][0] + ah[(j + P) & 1][0] + al[(j + P) & 1][0]);
+                        continue;
                     }
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[i], ah[j & 1], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[i], ah[(j + P) & 1], acc[i][j], 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[i], al[j & 1], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[i], al[(j + P) & 1], acc[i][j], 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bh[i], ah[j & 1], acc[i][j], 0, 0, 0);
-                    if (j == MT / 2) rflag = read_ready();      // the next step's poll, answered under the MFMAs
+                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[i], ah[(j + P) & 1], acc[i][j], 0, 0, 0);
+                    __builtin_amdgcn_sched_barrier(0);
                 }
+#pragma unroll
+                for (int i = 0; i < NT; ++i) bl[i] = *reinterpret_cast<const mfma_f16x8*>(sn + b_off[i] + B_PLANE);
+                __builtin_amdgcn_sched_barrier(0);
                 ++g;
+            };
+            int kt = 0;
+            for (; kt + 1 < KT; kt += 2) {
+                step(std::integral_constant<int, 0>{}, bhA, bhB, true);
+                step(std::integral_constant<int, 1>{}, bhB, bhA, kt + 2 < KT);
             }
+            if (kt < KT) step(std::integral_constant<int, 0>{}, bhA, bhB, false);
         }
         // cut the accumulators' live ranges (see conv_igemm_kernel), then the shared epilogue per 48-row group
 #pragma unroll
@@ -2774,7 +2835,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
     if constexpr (sizeof(T) == 4 && MODE != 2) {
         if (conv_ws_planes_eligible(a)) {
             // fp32 tensors, products of two fp16 planes per operand on the matrix cores (DmlConvDesc.x_planes ...)
-            constexpr int CUS = 256, NLD = 3;
+            constexpr int CUS = 256, NLD = DML_WS_PLANES_NLD;
             const bool wide = (a.N % 256) == 0;
             const int bm = wide ? 144 : 288;
             a.nblk_m = (a.M + bm - 1) / bm;

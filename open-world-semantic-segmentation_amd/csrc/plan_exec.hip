@@ -107,6 +107,8 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_class_feature_sum),
     DML_ENTRY(dml_label_encode),
     DML_ENTRY(dml_h2_split),
+    DML_ENTRY(dml_h2_bound_bn),
+    DML_ENTRY(dml_h2_bound_bn_bwd),
 };
 constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 

@@ -48,7 +48,7 @@ class ConvDesc(C.Structure):
                 ("x_plane_stride", C.c_int64), ("w_plane_stride", C.c_int64)]
 
 
-PLAN_MAX_ARGS = 22
+PLAN_MAX_ARGS = 24
 
 
 class PlanOp(C.Structure):
@@ -104,12 +104,15 @@ _PROTOS = {
     "dml_bn_stats": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
     "dml_bn_eval_coeffs_table": (c_i, [c_p, c_i, c_p]),
-    "dml_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.c_uint64, c_p, c_p]),
+    "dml_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.c_uint64, c_p,
+                           c_p, c_i64, c_i, c_p, c_p]),
     "dml_bn_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_f, c_i,
-                                C.POINTER(c_i), c_p]),
+                                C.POINTER(c_i), c_p, c_p]),
     "dml_bn_bwd_finalize": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
-                               c_i, c_i, c_p, c_p]),
+                               c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
+    "dml_h2_bound_bn": (c_i, [c_p, c_p, c_i, c_i64, c_f, c_p, c_p, c_p]),
+    "dml_h2_bound_bn_bwd": (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p]),
     "dml_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_global_avgpool_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
@@ -176,7 +179,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.dml_abi_version() != 2:
+    if lib.dml_abi_version() != 3:
         raise DmlError("libdmlnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

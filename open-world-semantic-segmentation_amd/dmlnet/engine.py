@@ -264,7 +264,7 @@ class ParamStore:
 # ---------------------------------------------------------------------------------------------------
 class Act:
     """An NHWC activation (or gradient) living in a plan-owned buffer; may be a channel slice."""
-    __slots__ = ("t", "ptr", "B", "H", "W", "C", "ld", "f32", "es", "grad", "grad_init", "root", "g32", "h2", "amax")
+    __slots__ = ("t", "ptr", "B", "H", "W", "C", "ld", "f32", "es", "grad", "grad_init", "root", "g32", "h2", "amax", "h2_used")
 
     def __init__(self, t, ptr, B, H, W, C, ld, f32, es):
         self.t, self.ptr, self.B, self.H, self.W, self.C, self.ld, self.f32, self.es = t, ptr, B, H, W, C, ld, f32, es
@@ -274,6 +274,7 @@ class Act:
         self.g32 = None             # fp32 staging of the gradient while it still has producers to come (Plan.stage_grad32)
         self.h2 = None              # (fp16 hi / lo planes, work) of this fp32 tensor once a conv has asked for them (Plan.h2_of)
         self.amax = None            # its `work` buffer when the producers of the tensor collect max |x| into work[0] (Plan.amax_of)
+        self.h2_used = False        # has a conv asked for the planes?  (planes written by the producer itself: Plan.h2_direct)
 
     @property
     def M(self):
@@ -333,6 +334,11 @@ class Plan:
         # the forward zeroes every amax word the step's producers will raise (dml_bn_apply / dml_bn_bwd_apply, `amax`)
         self.h2_slots = torch.zeros(1025 * 1024, dtype=torch.float32, device=self.device) if self.f32_split == 2 else None
         self.h2_used = 0
+        # f16x2: a batch-statistics BatchNorm writes the fp16 planes of its output (forward) / of dy (backward) itself, scaled
+        # from a bound known beforehand (dml_h2_bound_bn): no dml_h2_split pass over those tensors, and no fp32 copy at all where
+        # only convolutions read them.  DML_H2_DIRECT=0: every tensor through dml_h2_split (A/B, tests)
+        self.h2_direct_on = os.environ.get("DML_H2_DIRECT", "1") != "0"
+        self.direct_planes = []        # (activation, argument list, index of its `planes` argument): cleared when nobody asks
         self.fuse_res_grad = os.environ.get("DML_FUSE_RES_GRAD", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
@@ -448,6 +454,12 @@ class Plan:
         """shapes the planes kernel takes (conv_ws_planes_eligible); the others run the three-term split on the fp32 tensors"""
         return self.f32_split == 2 and self.dtype == torch.float32 and C % 32 == 0 and N % 64 == 0 and N >= 128 and taps <= 32
 
+    @staticmethod
+    def planes_fit(M, ld):
+        """both fp16 planes of an [M][ld] tensor within the 31-bit byte offsets of the planes kernels (launch_conv / dml_conv_wgrad
+        fall back to the fp32 tensors beyond): a tensor may exist as planes ONLY when this holds"""
+        return 4 * M * ld < (1 << 31) - 4096
+
     def h2_work(self):
         assert self.h2_used < 1024, "out of dml_h2_split work buffers"
         w = self.h2_slots[self.h2_used * 1025:(self.h2_used + 1) * 1025]
@@ -469,6 +481,7 @@ class Plan:
         appended to `ops` the first time a conv asks -- every tensor of a plan is complete before its first consumer and never
         rewritten within a step, so one split per tensor and step serves all its consumers (forward conv, weight gradient)."""
         root = a.root
+        root.h2_used = True
         if root.h2 is None:
             planes = torch.empty(2 * root.M * root.ld, dtype=torch.float16, device=self.device)
             known = root.amax is not None           # its producers collected max |x| (amax_of)
@@ -479,6 +492,16 @@ class Plan:
             root.h2 = (planes, work)
         planes, work = root.h2
         return planes.data_ptr() + (a.ptr - root.ptr) // 2, root.M * root.ld, work.data_ptr() + 4096
+
+    def h2_direct(self, B, H, W, C, fp32_too: bool, work=None) -> Act:
+        """a new fp32 activation whose producer (dml_bn_apply / dml_bn_bwd_apply) writes the fp16 planes itself; without
+        `fp32_too` the fp32 tensor does not exist -- the Act then points at the planes (same extent: 2 x 2 bytes per element)
+        and only planes consumers may read it"""
+        planes = torch.empty(2 * B * H * W * C, dtype=torch.float16, device=self.device)
+        self.keep.append(planes)
+        a = self.new(B, H, W, C) if fp32_too else Act(planes, planes.data_ptr(), B, H, W, C, C, True, 4)
+        a.h2 = (planes, work if work is not None else self.h2_work())
+        return a
 
     def h2_weight(self, w, rows, K):
         """planes of a prepared fp32 weight copy [rows][K] (tile-major), refreshed with the copies (refresh_weights)"""
@@ -659,8 +682,9 @@ class Plan:
         self.param_last_op[self.e.store._index(p)] = len(self.bwd) - 1
 
     def cbr(self, x: Act, conv: nn.Conv2d, bn: nn.BatchNorm2d, relu=True, res: Optional[Act] = None,
-            out: Optional[Act] = None, drop: Optional[nn.Dropout] = None, need_dgrad=True) -> ConvUnit:
-        """conv -> BN(batch or running stats) -> (+res) -> (ReLU) -> (dropout); z may be a concat slice."""
+            out: Optional[Act] = None, drop: Optional[nn.Dropout] = None, need_dgrad=True, planes_only=False) -> ConvUnit:
+        """conv -> BN(batch or running stats) -> (+res) -> (ReLU) -> (dropout); z may be a concat slice.
+        planes_only: only planes consumers read z (the convolutions of an f16x2 plan) -- no fp32 z where the BN writes planes."""
         lib, st = self.lib, self.e.store
         u = ConvUnit()
         u.conv, u.bn, u.x, u.relu, u.res, u.drop = conv, bn, x, relu, res, drop
@@ -670,7 +694,17 @@ class Plan:
         N = conv.out_channels
         u.w, u.wt = self.prep_weight(conv, u.Cp, self.training and need_dgrad, x_bytes=x.M * x.ld * x.es,
                                      dy_bytes=x.B * Ho * Wo * N * x.es)
-        u.z = out if out is not None else self.new(x.B, Ho, Wo, N)
+        # f16x2 training: this BN writes z's fp16 planes itself (Plan.h2_direct) -- batch statistics bound the output
+        direct = (self.h2_direct_on and self.training and bn.training and self.f32_split == 2 and self.dtype == torch.float32
+                  and out is None and N % 8 == 0 and drop is None
+                  and (res is None or (res is res.root and res.amax is not None)))
+        planes_only = planes_only and direct and self.planes_fit(x.B * Ho * Wo, N)
+        if direct:
+            u.z = self.h2_direct(x.B, Ho, Wo, N, fp32_too=not planes_only)
+            if not planes_only:
+                u.z.amax = u.z.h2[1]           # (the amax words and the scale word share the tensor's work buffer)
+        else:
+            u.z = out if out is not None else self.new(x.B, Ho, Wo, N)
         u.y = self.new(x.B, Ho, Wo, N) if self.training else None      # inference never materialises it
         M = u.z.M
         u.scale, u.shift = self.fbuf(N), self.fbuf(N)
@@ -729,10 +763,19 @@ class Plan:
             u.mask = torch.empty(M * (N // self.vec), dtype=torch.uint8, device=self.device)
             self.keep.append(u.mask)
         mask_ptr = u.mask.data_ptr() if u.mask is not None else None
+        pl = (None, 0, 0, None)
+        if direct:
+            planes, work = u.z.h2
+            self.call(self.fwd, lib.dml_h2_bound_bn, g_ptr, b_ptr, N, M * self.world, 1.0,
+                      res.amax.data_ptr() if res is not None else None, work.data_ptr())
+            pl = (planes.data_ptr(), M * N, N, work.data_ptr() + 4096)
+        only = direct and planes_only
         u.apply_args = self.call(self.fwd, lib.dml_bn_apply, u.y.ptr, res.ptr if res is not None else None,
-                                 u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), mean_ptr, mask_ptr, M, N, u.y.ld,
-                                 res.ld if res is not None else 0, u.z.ld, 1 if relu else 0, self.dt, 0.0, 0,
-                                 self.amax_of(u.z) if self.training else None)
+                                 None if only else u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), mean_ptr, mask_ptr, M, N,
+                                 u.y.ld, res.ld if res is not None else 0, u.z.ld, 1 if relu else 0, self.dt, 0.0, 0,
+                                 self.amax_of(u.z) if (self.training and not only) else None, *pl)
+        if direct and not only:
+            self.direct_planes.append((u.z, u.apply_args, 17))
         if drop is not None and self.training:
             self.drop_units.append(u)
         self.units.append(u)
@@ -746,7 +789,19 @@ class Plan:
         lib, st = self.lib, self.e.store
         N, M = u.conv.out_channels, u.y.M
         bn = u.bn
-        dy = self.new(u.y.B, u.y.H, u.y.W, N)
+        # f16x2: the BN backward writes dy's fp16 planes itself, scaled from a bound (dml_h2_bound_bn_bwd); dy exists in fp32
+        # only if one of its two consumers (weight gradient, data gradient) cannot read planes
+        kh, kw = u.conv.kernel_size
+        dy_direct = self.h2_direct_on and self.f32_split == 2 and self.dtype == torch.float32 and N % 8 == 0
+        gwork = None
+        if dy_direct:
+            only = (u.x.C % 8 == 0 and self.planes_fit(M, N) and self.planes_fit(u.x.root.M, u.x.root.ld)
+                    and (not need_dgrad or self.h2_ok(N, u.x.C, kh * kw)))
+            dy = self.h2_direct(u.y.B, u.y.H, u.y.W, N, fp32_too=not only)
+            gwork = self.h2_work()
+        else:
+            only = False
+            dy = self.new(u.y.B, u.y.H, u.y.W, N)
         u.dz, u.dy = dz, dy
         coef = self.fbuf(4 * N)
         nblk = C.c_int(0)
@@ -776,7 +831,7 @@ class Plan:
             sp = self.sp
             a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, mk, u.mean.data_ptr(),
                            u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if u.relu else 0, 1.0,
-                           self.dt, C.byref(nblk))
+                           self.dt, C.byref(nblk), gwork.data_ptr() if gwork is not None else None)
         if self.sync and not u.frozen:
             sums = self.dbuf(N * 2)
             self.call(self.bwd, lib.dml_bn_bwd_sums, sp, nblk, N, sums.data_ptr(), st.grad_ptr_of(bn.weight),
@@ -791,10 +846,16 @@ class Plan:
                       st.grad_ptr_of(bn.bias), coef.data_ptr())
         self.mark_grad(bn.weight)
         self.mark_grad(bn.bias)
-        a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, mk, coef.data_ptr(), dy.ptr,
-                       dres.ptr if dres is not None else None, M, N, dz.ld, u.y.ld, u.z.ld, dy.ld,
+        pl = (None, 0, 0, None)
+        if dy_direct:
+            planes, work = dy.h2
+            self.call(self.bwd, lib.dml_h2_bound_bn_bwd, coef.data_ptr(), u.invstd.data_ptr(), N, M * self.world,
+                      gwork.data_ptr(), work.data_ptr())
+            pl = (planes.data_ptr(), M * N, N, work.data_ptr() + 4096)
+        a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, mk, coef.data_ptr(),
+                       None if only else dy.ptr, dres.ptr if dres is not None else None, M, N, dz.ld, u.y.ld, u.z.ld, dy.ld,
                        dres.ld if dres is not None else 0, 1 if u.relu else 0, 1.0,
-                       1 if dres_accum else 0, self.dt, self.amax_of(dy))
+                       1 if dres_accum else 0, self.dt, None if dy_direct else self.amax_of(dy), *pl)
         u.gscale_slots += ([(a1, 13)] if a1 is not None else []) + [(a3, 15)]
         if dres is not None:
             self.last_dgrad.pop(dres.ptr, None)   # written by the BN kernel, not by a data gradient
@@ -804,8 +865,11 @@ class Plan:
 
     def block_fwd(self, x: Act, blk: nn.Module):
         """one Bottleneck (resnet.py:95-115): 1x1 -> 3x3 -> 1x1, + identity or downsample branch, ReLU"""
-        u1 = self.cbr(x, blk.conv1, blk.bn1)
-        u2 = self.cbr(u1.z, blk.conv2, blk.bn2)
+        # (f16x2: u1.z / u2.z feed one convolution each -- where that one reads planes, the fp32 tensors are never written)
+        n1, n2, n3 = blk.conv1.out_channels, blk.conv2.out_channels, blk.conv3.out_channels
+        kk = blk.conv2.kernel_size[0] * blk.conv2.kernel_size[1]
+        u1 = self.cbr(x, blk.conv1, blk.bn1, planes_only=self.h2_ok(n1, n2, kk))
+        u2 = self.cbr(u1.z, blk.conv2, blk.bn2, planes_only=self.h2_ok(n2, n3, 1))
         ud = None
         if blk.downsample is not None:
             ud = self.cbr(x, blk.downsample[0], blk.downsample[1], relu=False)
@@ -931,6 +995,9 @@ class Plan:
         self.unit_bwd(stem, dz0, need_dgrad=False)
         self.flush_wgrad()
         self.backbone_bwd_range = (backbone_start, len(self.bwd))
+        for a, args, i in self.direct_planes:       # planes nobody reads (outputs that only feed resizes / concats): not written
+            if not a.h2_used:
+                args[i] = None
 
     def _head_fwd(self, head: nn.Module, low: Act, out: Act):
         """DeepLabHeadV3Plus + final upsample + distance head (network/utils.py:8-32,84-118) on the backbone features."""

@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 def test_conv_ops_through_the_register_staged_kernel():
     env = dict(os.environ, DML_CONV_V1="1")
     r = subprocess.run([sys.executable, "-m", "pytest", os.path.join(H.ROOT, "tests", "test_gpu_ops.py"), "-m", "gpu",
-                        "-q", "-x", "-k", "conv", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
+                        "-q", "-x", "-k", "conv and not wave_specialised and not two_plane", "-p", "no:cacheprovider"], env=env, capture_output=True, text=True,
                        cwd=H.ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
     assert "passed" in r.stdout

@@ -227,7 +227,7 @@ def test_dgrad_emits_bn_backward_partials(lib, accum, relu):
     part2 = torch.zeros(4096 * Cin * 2, device="cuda")
     nb = C.c_int(0)
     chk(lib.dml_bn_bwd_reduce(dx.data_ptr(), ybn.data_ptr(), None, bits.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
-                              part2.data_ptr(), M, Cin, Cin, Cin, Cin, relu, 1.0, 1, C.byref(nb), st()))
+                              part2.data_ptr(), M, Cin, Cin, Cin, Cin, relu, 1.0, 1, C.byref(nb), None, st()))
     torch.cuda.synchronize()
     a = part.view(G, Cin, 2).double().sum(0)
     b = part2[: nb.value * Cin * 2].view(nb.value, Cin, 2).double().sum(0)
@@ -321,7 +321,7 @@ def test_sync_bn_building_blocks(lib):
 
     def reduce(dzs, ys):
         chk(lib.dml_bn_bwd_reduce(dzs.data_ptr(), ys.data_ptr(), None, None, mean.data_ptr(), invstd.data_ptr(), part.data_ptr(),
-                                  dzs.shape[0], N, N, N, N, 0, 1.0, 0, C.byref(nb), st()))
+                                  dzs.shape[0], N, N, N, N, 0, 1.0, 0, C.byref(nb), None, st()))
 
     coef_ref, dg_ref, db_ref = torch.empty(4 * N, device="cuda"), torch.zeros(N, device="cuda"), torch.zeros(N, device="cuda")
     reduce(dz, y)
@@ -491,9 +491,31 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     bitmask = torch.zeros(M * Cc // (8 if dname == "bf16" else 4), device="cuda", dtype=torch.uint8) if use_mask else None
     mk = bitmask.data_ptr() if bitmask is not None else None
     amax = torch.zeros(1024, device="cuda")
+    # fp32: the output also as fp16 hi / lo planes, scaled from the bound dml_h2_bound_bn derives from gamma / beta / count
+    # (+ max |res| from the residual's amax words, x the dropout's 1 / (1 - p))
+    planes_ok = dname == "f32" and Cc % 4 == 0
+    pz, zwork, rwork = None, torch.zeros(1025, device="cuda"), torch.zeros(1024, device="cuda")
+    if planes_ok:
+        pz = torch.zeros(2, M * Cc, device="cuda", dtype=torch.float16)
+        if res:
+            rwork[17] = rd.abs().max()
+        chk(lib.dml_h2_bound_bn(g_d.data_ptr(), b_d.data_ptr(), Cc, M, 1.0 / (1.0 - drop), rwork.data_ptr() if res else None,
+                                zwork.data_ptr(), st()))
     chk(lib.dml_bn_apply(yd.data_ptr(), rd.data_ptr() if res else None, zd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
-                         mu.data_ptr(), mk, M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, amax.data_ptr(), st()))
+                         mu.data_ptr(), mk, M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, amax.data_ptr(),
+                         pz.data_ptr() if planes_ok else None, M * Cc, Cc, zwork.data_ptr() + 4096 if planes_ok else None, st()))
     torch.cuda.synchronize()
+    if planes_ok:
+        un = zwork[1024].item()
+        bound = (gamma.detach().abs() * M ** 0.5 + beta.detach().abs()).max().item() / (1.0 - drop) + (rd.abs().max().item() if res else 0.0)
+        zmax = zd.abs().max().item()
+        assert np.log2(un) == np.round(np.log2(un)) and zmax / un < 2.0 ** 15, (un, zmax)
+        assert 2.0 ** 14 <= bound * 1.002 / un and bound / un < 2.0 ** 15, (bound, un)
+        rec = (pz[0].double() + pz[1].double()) * un
+        err = (rec - zd.double().view(-1)).abs().max().item()
+        # hi + lo resolves 2^-22 of an element down to ~2^-11 of the bound, 2^-33 of the bound below
+        assert err <= 2.0 ** -21 * zmax + 2.0 ** -32 * bound, (err, zmax, bound)
+        assert torch.isfinite(pz.float()).all()
     # (taken from the fp32 value before a bf16 store rounds it)
     assert abs(amax.max().item() - zd.float().abs().max().item()) <= 2.0 ** -7 * amax.max().item(), "amax side output of dml_bn_apply"
     relclose(rm.cpu(), rm_ref, 1e-4, "running_mean")
@@ -516,9 +538,10 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     gzd = nhwc(gz, tdt)
     nblk = C.c_int(0)
     zarg = None if mk else zd.data_ptr()          # with the bitmask the backward never touches z
+    gwork, dwork = torch.zeros(1024, device="cuda"), torch.zeros(1025, device="cuda")
     chk(lib.dml_bn_bwd_reduce(gzd.data_ptr(), yd.data_ptr(), zarg, mk, mu.data_ptr(), inv.data_ptr(),
                               part.data_ptr(), M, Cc, Cc, Cc, Cc, 1 if (relu or drop > 0) else 0, gs, dt,
-                              C.byref(nblk), st()))
+                              C.byref(nblk), gwork.data_ptr(), st()))
     coef = torch.empty(4 * Cc, device="cuda")
     dg, db = torch.zeros(Cc, device="cuda"), torch.zeros(Cc, device="cuda")
     chk(lib.dml_bn_bwd_finalize(part.data_ptr(), nblk, M, Cc, g_d.data_ptr(), mu.data_ptr(), inv.data_ptr(),
@@ -526,10 +549,27 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
     dyd = torch.empty_like(yd)
     dres = torch.empty_like(yd) if res else None
     amax_dy = torch.zeros(1024, device="cuda")
+    pdy = torch.zeros(2, M * Cc, device="cuda", dtype=torch.float16) if planes_ok else None
+    if planes_ok:
+        chk(lib.dml_h2_bound_bn_bwd(coef.data_ptr(), inv.data_ptr(), Cc, M, gwork.data_ptr(), dwork.data_ptr(), st()))
     chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zarg, mk, coef.data_ptr(), dyd.data_ptr(),
                              dres.data_ptr() if res else None, M, Cc, Cc, Cc, Cc, Cc, Cc,
-                             1 if (relu or drop > 0) else 0, gs, 0, dt, amax_dy.data_ptr(), st()))
+                             1 if (relu or drop > 0) else 0, gs, 0, dt, amax_dy.data_ptr(),
+                             pdy.data_ptr() if planes_ok else None, M * Cc, Cc, dwork.data_ptr() + 4096 if planes_ok else None, st()))
     torch.cuda.synchronize()
+    if planes_ok:
+        un, dmax = dwork[1024].item(), dyd.abs().max().item()
+        assert np.log2(un) == np.round(np.log2(un)) and dmax / un < 2.0 ** 15, (un, dmax)
+        assert dmax / un >= 2.0 ** 3, "the bound of dml_h2_bound_bn_bwd is more than 2^12 above max |dy|: %g" % (dmax / un)
+        rec = (pdy[0].double() + pdy[1].double()) * un
+        err = (rec - dyd.double().view(-1)).abs().max().item()
+        assert err <= 2.0 ** -21 * dmax + 2.0 ** -32 * un * 2.0 ** 15, (err, dmax, un)
+        # planes only (dy == NULL) writes the same planes
+        pdy2 = torch.zeros_like(pdy)
+        chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zarg, mk, coef.data_ptr(), None, None, M, Cc, Cc, Cc, Cc, Cc, 0,
+                                 1 if (relu or drop > 0) else 0, gs, 0, dt, None, pdy2.data_ptr(), M * Cc, Cc, dwork.data_ptr() + 4096, st()))
+        torch.cuda.synchronize()
+        assert torch.equal(pdy2, pdy)
     assert abs(amax_dy.max().item() - dyd.float().abs().max().item()) <= 2.0 ** -7 * amax_dy.max().item()
     btol = 1e-4 if dname == "f32" else 2e-2
     relclose(dg.cpu(), gamma.grad, btol, "dgamma")
@@ -766,7 +806,7 @@ def test_rejects_bad_arguments(lib):
     assert lib.dml_conv_igemm(C.byref(d), None) == -1
     x = torch.zeros(64, device="cuda")
     assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 6, 6, 6,
-                            6, 1, 0, 0.0, 0, None, st()) == -2
+                            6, 1, 0, 0.0, 0, None, None, 0, 0, None, st()) == -2
     assert lib.dml_proto_dist_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 64, 16, 1, 1, st()) == -3
 
 

@@ -34,16 +34,16 @@ for (M, N) in SHAPES:
     def apply(res):
         i = it[0] = (it[0] + 1) % nbuf
         _lib.check(lib.dml_bn_apply(ys[i].data_ptr(), rs[i % len(rs)].data_ptr() if res else None, zs[i].data_ptr(), sc.data_ptr(),
-                                    sh.data_ptr(), mu.data_ptr(), mk.data_ptr(), M, N, N, N, N, 1, 1, 0.0, 0, None, st), "apply")
+                                    sh.data_ptr(), mu.data_ptr(), mk.data_ptr(), M, N, N, N, N, 1, 1, 0.0, 0, None, None, 0, 0, None, st), "apply")
     def reduce():
         i = it[0] = (it[0] + 1) % nbuf
         _lib.check(lib.dml_bn_bwd_reduce(zs[i].data_ptr(), ys[i].data_ptr(), None, mk.data_ptr(), mu.data_ptr(), inv.data_ptr(),
-                                         part.data_ptr(), M, N, N, N, N, 1, 1.0, 1, C.byref(nb), st), "reduce")
+                                         part.data_ptr(), M, N, N, N, N, 1, 1.0, 1, C.byref(nb), None, st), "reduce")
     def bapply(res):
         i = it[0] = (it[0] + 1) % nbuf
         _lib.check(lib.dml_bn_bwd_apply(zs[i].data_ptr(), ys[i].data_ptr(), None, mk.data_ptr(), coef.data_ptr(),
                                         zs[(i + 1) % nbuf].data_ptr(), rs[i % len(rs)].data_ptr() if res else None, M, N, N, N, N, N, N,
-                                        1, 1.0, 0, 1, None, st), "bwd apply")
+                                        1, 1.0, 0, 1, None, None, 0, 0, None, st), "bwd apply")
     line = "M=%d N=%d | " % (M, N)
     for name, fn, bytes_ in (("apply", lambda: apply(False), 4.125 * E), ("apply+res", lambda: apply(True), 6.125 * E),
                              ("bwd_reduce", reduce, 4.125 * E), ("bwd_apply", lambda: bapply(False), 6.125 * E),
