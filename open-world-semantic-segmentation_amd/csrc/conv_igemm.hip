@@ -152,7 +152,7 @@ __device__ __forceinline__ void st16f(float* p, float a, float b, float c, float
 // shared epilogue: BN partial statistics, bias, accumulate, fp32 / storage-dtype stores
 // acc[i][j][e] = out[m = mw0 + j*16 + (lane&15)][n = nw0 + frag_chan<NT>(i, lane>>4) + e]
 // ------------------------------------------------------------------------------------------------
-template <typename T, int NT, int MT, int MODE, bool WIDE_MASK = true>
+template <typename T, int NT, int MT, int MODE, bool WIDE_MASK = true, bool STATS_ONLY = false>
 __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvArgs& a, const int mw0, const int nw0,
                                               const int lr, const int lq) {
     constexpr int TM = MT * 16;
@@ -225,6 +225,8 @@ __device__ __forceinline__ void conv_epilogue(f32x4 (&acc)[NT][MT], const ConvAr
             }
         }
     }
+
+    if constexpr (STATS_ONLY) return;      // (the caller stores the tile itself: conv_epilogue_rows)
 
     float bv[CL];
 #pragma unroll
@@ -1309,13 +1311,84 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
 //     conv_epilogue on 48-row sub-tiles, and the finalize kernels take the group height (dml_conv_stat_rows).
 // Weights must be the tile-major copy (w_tiled).  MODE as conv_igemm_dma_kernel.
 // ------------------------------------------------------------------------------------------------
+// fp32 output of a 48 x 64 sub-tile as WHOLE 256-byte rows: straight from the accumulators a store instruction writes, per pixel
+// row, four 16-byte pieces 32 bytes apart (the lane's channel runs, frag_chan) -- 16 rows x 4 pieces per instruction, and the
+// chip takes a 144 x 256 fp32 tile per CU (37.7 MB per launch) in 14-16 us, every K loop waiting behind it.  Staged through
+// 12 KB of LDS (row-major, 16-byte chunk index XOR row: conflict-free both ways) every store instruction -- and every read
+// of the accumulate / residual operands -- covers four pixel rows x 256 contiguous bytes: 5-6 us (profiles/r04_h2_epilogue.txt).
+// BatchNorm statistics come from the accumulators as before (conv_epilogue, STATS_ONLY); accumulate and the stores happen on the
+// row side (launches with a bias or the inference epilogue post_* keep conv_epilogue).  `stage`: this wave's own 12 KB.
+template <int NT, int MODE>
+__device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
+                                                   const int lane, char* stage) {
+    static_assert(NT == 4, "64-channel wave tile");
+    const int lr = lane & 15, lq = lane >> 4;
+    if (MODE == 0 && a.stats != nullptr) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
+#pragma unroll
+    for (int i = 0; i < NT; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int row = j * 16 + lr, chunk = frag_chan<NT>(i, lq) >> 2;
+            *reinterpret_cast<f32x4*>(stage + row * 256 + ((chunk ^ (row & 15)) << 4)) = acc[i][j];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own writes, read back by other lanes
+    const int c0 = nw0 + (lane & 15) * 4;
+    if (c0 >= a.N) return;                                       // (a last, half-empty 128-wide block)
+    const bool has_old = a.accum != 0;
+    float* const yb = static_cast<float*>(a.y);
+    // Two code paths on a wave-uniform branch.  Without an accumulate operand the twelve stores of the sub-tile depend on LDS reads
+    // only and leave back to back.  (One path with the operand selected per element made every store wait vmcnt(0) -- stores count
+    // there too on gfx950 -- i.e. for the store before it: 36 serialised round trips per tile, as slow as the scattered stores this
+    // function replaces.)  With the operand, the loads of the NEXT group of four rows are issued before this group's stores, so that
+    // waiting for them does not wait for the stores.
+    auto body = [&](auto ho) {
+        constexpr bool HO = decltype(ho)::value;
+        float4 old[2][4];
+        auto load_old = [&](const int g4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = mw0 + (g4 * 4 + u) * 4 + (lane >> 4);
+                old[g4 & 1][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (m < a.M) old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
+            }
+        };
+        if (HO) load_old(0);
+#pragma unroll
+        for (int g4 = 0; g4 < 3; ++g4) {
+            if (HO && g4 + 1 < 3) load_old(g4 + 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = (g4 * 4 + u) * 4 + (lane >> 4), m = mw0 + r;
+                if (m >= a.M) continue;
+                float4 o = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
+                if (HO) { o.x += old[g4 & 1][u].x; o.y += old[g4 & 1][u].y; o.z += old[g4 & 1][u].z; o.w += old[g4 & 1][u].w; }
+                st16f(yb + (int64_t)m * a.ldy + c0, o.x, o.y, o.z, o.w, (a.nt_out & 1) != 0);
+            }
+        }
+    };
+    if (has_old) {
+        body(std::true_type{});
+    } else {
+        // all twelve LDS reads first (into the registers the sub-tile's accumulators just left), then twelve stores back to back:
+        // read -> wait -> store per row costs an LDS round trip per store, ~3 us per tile
+        float4 o[12];
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int r = k * 4 + (lane >> 4);
+            o[k] = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
+        }
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+            const int m = mw0 + k * 4 + (lane >> 4);
+            if (m < a.M) st16f(yb + (int64_t)m * a.ldy + c0, o[k].x, o[k].y, o[k].z, o[k].w, (a.nt_out & 1) != 0);
+        }
+    }
+}
+
 typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
 constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
 constexpr int WS_STAT_ROWS = 48;               // rows per statistics group of this kernel
 constexpr int WS_NST = 6, WS_D = 2;            // ring stages; stages in flight per loader behind the published one
-#ifndef DML_WS_ABL
-#define DML_WS_ABL 0                           // tuning builds: 1 = no MFMAs, 2 = no DMA (tools/ab_lib.sh with bench_h2.py)
-#endif
 #ifndef DML_WS_PLANES_NLD
 #define DML_WS_PLANES_NLD 3                    // loader waves of the two-plane instantiation
 #endif
@@ -1415,6 +1488,10 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
                 base[q] = n < a.N ? (int)((((int64_t)(n >> 6) * KT) * 2048 + (n & 63) * 32 + bchunk * 8) * 2) : (int)OOB;
             }
         }
+        // (K order: every workgroup walks K from step 0.  The workgroups of an XCD share one L2 and -- on the m-fastest tile walk -- the
+        // same weight rows; letting each start at its own K step, to spread their simultaneous requests over the L2 channels, LOSES:
+        // the weight working set of the moment grows from one K step to the whole matrix and falls out of the 4 MB L2 (ASPP 3x3
+        // 278 -> 389 us in bf16, 732 -> 870 us on two planes; gpurun_out/r04 h2_krot).)
         int ir = 0, is = 0, ic0 = 0;
         for (int kt = 0; kt < KT; ++kt) {
             if (g >= (uint32_t)NST) {
@@ -1446,7 +1523,6 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
 #pragma unroll
             for (int q = 0; q < MYP; ++q) {
                 const int p = q * NLD + LW;
-                if (DML_WS_ABL == 2) continue;
                 if (p < PL * PA) {
                     const uint32_t voff = (mask[q] & tapbit) ? (uint32_t)(base[q] + soff) : OOB;
                     ws_dma16(rs_x, sbase + p * 1024, voff, p < PA ? 0u : a.x_plane_bytes);
@@ -1506,7 +1582,8 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     // ---------------------------------------------------------------------- consumer
     const int wm = wave / NW, wn = wave % NW;
     const int lr = lane & 15, lq = lane >> 4;
-    uint32_t g = 0, rflag = 0;
+    uint32_t g = 0, rflag = 0, tiles_done = 0;
+    uint32_t* const edone = consumed + 4;                  // [4] tiles whose last fragment reads were issued, per consumer wave
     auto read_ready = [&]() -> uint32_t {
         uint32_t v = ws_ld(ready);
 #pragma unroll
@@ -1520,20 +1597,28 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         }
         asm volatile("" ::: "memory");
     };
-    int a_off[MT], b_off[NT];          // fragment byte offsets inside a stage (hi plane; the lo plane is BM / BN rows further)
-#pragma unroll
-    for (int j = 0; j < MT; ++j) a_off[j] = (wm * (16 * MT) + j * 16 + lr) * (BK * 2) + swz_chunk<T>(j * 16 + lr, lq) * 16;
-#pragma unroll
-    for (int i = 0; i < NT; ++i) b_off[i] = PL * BM * BK * 2 + (wn * 64 + b_row<NT>(i, lr)) * (BK * 2) + swz_chunk<T>(lr, lq) * 16;
     constexpr int A_PLANE = BM * BK * 2, B_PLANE = BN * BK * 2;      // bytes from the hi plane to the lo plane inside a stage
 
     for (int tile = first_tile; tile < ntiles; tile += (int)gridDim.x) {
         const int blk_m = tile % a.nblk_m, blk_n = tile / a.nblk_m;
-        f32x4 acc[NT][MT];
+        // fragment byte offsets inside a stage (hi plane; the lo plane is BM / BN rows further).  Recomputed per tile from a lane
+        // index the optimiser cannot see through: hoisted out of the tile loop these 13 registers stay live across the epilogue,
+        // where the 144 accumulator registers leave no room for them (spills, and a scratch reload waits vmcnt(0) -- for every
+        // store issued before it).
+        int lr_k = lr, lq_k = lq;
+        asm volatile("" : "+v"(lr_k), "+v"(lq_k));
+        int a_off[MT], b_off[NT];
+#pragma unroll
+        for (int j = 0; j < MT; ++j) a_off[j] = (wm * (16 * MT) + j * 16 + lr_k) * (BK * 2) + swz_chunk<T>(j * 16 + lr_k, lq_k) * 16;
+#pragma unroll
+        for (int i = 0; i < NT; ++i) b_off[i] = PL * BM * BK * 2 + (wn * 64 + b_row<NT>(i, lr_k)) * (BK * 2) + swz_chunk<T>(lr_k, lq_k) * 16;
+        // accumulators by 48-row sub-tile: ACC(i, j) = acc3[j / 3][i][j % 3], so that the epilogue takes a sub-tile by reference
+        f32x4 acc3[3][NT][3];
+#define ACC(i, j) acc3[(j) / 3][i][(j) % 3]
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            for (int j = 0; j < MT; ++j) ACC(i, j) = (f32x4){0.f, 0.f, 0.f, 0.f};
 
         if constexpr (PL == 1) {
             mfma_bf16x8 bfA[NT], bfB[NT], af[MT], alA, alB;       // af[MT - 1] unused: the last A fragment alternates alA / alB
@@ -1560,12 +1645,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 #pragma unroll
                 for (int j = 0; j < MT - 1; ++j) {
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], af[j], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < NT; ++i) ACC(i, j) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], af[j], ACC(i, j), 0, 0, 0);
                     if (has_next) af[j] = *reinterpret_cast<const mfma_bf16x8*>(sn + a_off[j]);
                     if (j == (MT - 1) / 2) rflag = read_ready();      // the next step's poll, answered under the MFMAs
                 }
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][MT - 1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], alc, acc[i][MT - 1], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) ACC(i, MT - 1) = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bc[i], alc, ACC(i, MT - 1), 0, 0, 0);
                 ++g;
             };
             int kt = 0;
@@ -1586,16 +1671,17 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             // step against 0.72 of MFMA issue).
             mfma_f16x8 bhA[NT], bhB[NT], bl[NT], ah[2], al[2];
             uint32_t pl[NLD];
+#define WS_FRAG(p) (*reinterpret_cast<const mfma_f16x8*>(p))
             wait_ready(g + 1);                                      // first K step of the tile: exposed once per tile
             {
                 const char* sb = smem + (g % NST) * SB;
 #pragma unroll
                 for (int i = 0; i < NT; ++i) {
-                    bhA[i] = *reinterpret_cast<const mfma_f16x8*>(sb + b_off[i]);
-                    bl[i] = *reinterpret_cast<const mfma_f16x8*>(sb + b_off[i] + B_PLANE);
+                    bhA[i] = WS_FRAG(sb + b_off[i]);
+                    bl[i] = WS_FRAG(sb + b_off[i] + B_PLANE);
                 }
-                ah[0] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[0]);
-                al[0] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[0] + A_PLANE);
+                ah[0] = WS_FRAG(sb + a_off[0]);
+                al[0] = WS_FRAG(sb + a_off[0] + A_PLANE);
             }
             auto step = [&](auto pc, mfma_f16x8 (&bc)[NT], mfma_f16x8 (&bn)[NT], const bool has_next) {
                 constexpr int P = decltype(pc)::value;
@@ -1605,13 +1691,15 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
                     if (j + 1 < MT) {
-                        ah[(j + 1 + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1]);
-                        al[(j + 1 + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sb + a_off[j + 1] + A_PLANE);
+                        ah[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1]);
+                        al[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1] + A_PLANE);
                     } else {
                         asm volatile("" ::: "memory");
-                        ws_st(consumed + wave, g + 1);      // every read of stage g has been issued
-                        ah[(MT + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sn + a_off[0]);
-                        al[(MT + P) & 1] = *reinterpret_cast<const mfma_f16x8*>(sn + a_off[0] + A_PLANE);
+                        // every read of stage g has been issued (the tile's LAST stage is announced after the epilogue, which
+                        // stages the output rows in its slot)
+                        if (has_next) ws_st(consumed + wave, g + 1);
+                        ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
+                        al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
                     }
                     if (j == 1) {                           // the next step's poll, answered under the MFMAs
 #pragma unroll
@@ -1625,24 +1713,19 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                     }
                     if (j == 5) {
 #pragma unroll
-                        for (int i = 0; i < NT; ++i) bn[i] = *reinterpret_cast<const mfma_f16x8*>(sn + b_off[i]);
+                        for (int i = 0; i < NT; ++i) bn[i] = WS_FRAG(sn + b_off[i]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
-                    if (DML_WS_ABL == 1) {
 #pragma unroll
-                        for (int i = 0; i < NT; ++i) acc[i][j][0] += (float)(bc[i][0] + bl[i][0] + ah[(j + P) & 1][0] + al[(j + P) & 1][0]);
-                        continue;
-                    }
+                    for (int i = 0; i < NT; ++i) ACC(i, j) = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[i], ah[(j + P) & 1], ACC(i, j), 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[i], ah[(j + P) & 1], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < NT; ++i) ACC(i, j) = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[i], al[(j + P) & 1], ACC(i, j), 0, 0, 0);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bc[i], al[(j + P) & 1], acc[i][j], 0, 0, 0);
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[i], ah[(j + P) & 1], acc[i][j], 0, 0, 0);
+                    for (int i = 0; i < NT; ++i) ACC(i, j) = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[i], ah[(j + P) & 1], ACC(i, j), 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
                 }
 #pragma unroll
-                for (int i = 0; i < NT; ++i) bl[i] = *reinterpret_cast<const mfma_f16x8*>(sn + b_off[i] + B_PLANE);
+                for (int i = 0; i < NT; ++i) bl[i] = WS_FRAG(sn + b_off[i] + B_PLANE);
                 __builtin_amdgcn_sched_barrier(0);
                 ++g;
             };
@@ -1657,31 +1740,63 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < NT; ++i)
 #pragma unroll
-            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(ACC(i, j)));
         if constexpr (PL == 2) {
             const float un = a.x_unscale[0] * a.w_unscale[0];      // exact powers of two
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < MT; ++j) acc[i][j] *= un;
+                for (int j = 0; j < MT; ++j) ACC(i, j) *= un;
         }
         // (three explicit copies: hipcc does not unroll a loop around the inlined epilogue, and a run-time index into acc
         // sends all 36 accumulator fragments through scratch memory -- 37 MB written and read back per launch, +25 us)
-        auto epi = [&](auto hc) {
-            constexpr int h = decltype(hc)::value;
-            f32x4 sub[NT][3];
+        char* rows_stage = nullptr;
+        if constexpr (PL == 2) {
+            // the slot of the tile's last K step becomes the staging area of conv_epilogue_rows (12 KB per wave): every consumer
+            // wave must have issued its last fragment reads first
+            ++tiles_done;
+            asm volatile("" ::: "memory");
+            ws_st(edone + wave, tiles_done);
+            for (;;) {
+                uint32_t mn = ws_ld(edone);
+#pragma unroll
+                for (int w = 1; w < NCW; ++w) mn = min(mn, ws_ld(edone + w));
+                if (mn >= tiles_done) break;
+                __builtin_amdgcn_s_sleep(1);
+            }
+            asm volatile("" ::: "memory");
+            rows_stage = smem + ((g - 1) % NST) * SB + wave * (WS_STAT_ROWS * 256);
+        }
+        // One copy of the epilogue code, run three times on acc[.][0..2] with the accumulators rotated down by a sub-tile in
+        // between (2 x 96 register moves): three inlined copies -- what a compile-time sub-tile index costs; a run-time index into
+        // acc would send all of it through scratch memory -- made these kernels 10-19 K instructions, more than the instruction
+        // cache two CUs share.
+        static_assert(MT == 9, "three 48-row groups per wave tile");
+#pragma clang loop unroll(disable)
+        for (int h = 0; h < 3; ++h) {
+            const int mw0 = blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, nw0 = blk_n * BN + wn * 64;
+            if constexpr (PL == 1) conv_epilogue<bf16_t, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);
+            else if (MODE == 0 && (a.bias != nullptr || a.post_scale != nullptr)) {
+                conv_epilogue<float, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);      // (inference epilogue, bias: scattered stores)
+            } else {
+                conv_epilogue_rows<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // its reads of the staging area, before the next group's writes
+            }
 #pragma unroll
             for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) sub[i][j] = acc[i][h * 3 + j];
-            const int mw0 = blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, nw0 = blk_n * BN + wn * 64;
-            if constexpr (PL == 1) conv_epilogue<bf16_t, NT, 3, MODE, false>(sub, a, mw0, nw0, lr, lq);
-            else conv_epilogue<float, NT, 3, MODE, false>(sub, a, mw0, nw0, lr, lq);
-        };
-        static_assert(MT == 9, "three 48-row groups per wave tile");
-        epi(std::integral_constant<int, 0>{});
-        epi(std::integral_constant<int, 1>{});
-        epi(std::integral_constant<int, 2>{});
+                for (int j = 0; j < 3; ++j) {
+                    acc3[0][i][j] = acc3[1][i][j];
+                    acc3[1][i][j] = acc3[2][i][j];
+                    // (keeps the loop a loop: the optimiser must not see through the rotation and re-specialise the three trips)
+                    asm volatile("" : "+v"(acc3[0][i][j]), "+v"(acc3[1][i][j]));
+                }
+        }
+#undef ACC
+        if constexpr (PL == 2) {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            ws_st(consumed + wave, g);                  // the tile's last stage: its slot is free again
+        }
     }
 }
 
@@ -1709,6 +1824,12 @@ static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t 
 static bool conv_ws_planes_eligible(const ConvArgs& a) {
     if (a.f32_split != 2 || !a.x_planes || !a.w_planes || !a.x_unscale || !a.w_unscale) return false;
     if ((a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 64) != 0 || a.N < 128) return false;      // (N = 320: the decoder's data gradient)
+    // whole 16-byte vectors of the fp32 output and of every epilogue operand (conv_epilogue_rows)
+    if ((a.ldy & 3) != 0 || (a.post_res != nullptr && (a.post_ldres & 3) != 0) ||
+        ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.post_res) | reinterpret_cast<uintptr_t>(a.bias) |
+          reinterpret_cast<uintptr_t>(a.post_scale) | reinterpret_cast<uintptr_t>(a.post_shift) |
+          reinterpret_cast<uintptr_t>(a.post_mean)) & 15) != 0)
+        return false;
     const int64_t xb = (((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2, wb = (int64_t)a.N * a.Ktot * 2;
     return xb + a.x_plane_bytes < (1ll << 31) && wb + a.w_plane_bytes < (1ll << 31);
 }
