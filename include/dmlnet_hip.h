@@ -161,6 +161,17 @@ int dml_conv_stat_rows(const DmlConvDesc* desc);
 int dml_h2_split(const float* x, int64_t rows, int32_t C, int32_t ld, void* planes, int64_t plane_stride, int32_t ldp,
                  int32_t layout, float* work, int32_t amax_known, void* stream);
 
+/* The same for `count` tensors in two launches; `table_device` is a DEVICE array (the tensors' own constraints as above, checked by the
+ * caller: this entry point does not see the descriptors). */
+typedef struct DmlH2Desc {
+    const float* x;
+    void* planes;
+    float* work;
+    int64_t rows, plane_stride;
+    int32_t C, ld, ldp, layout;
+} DmlH2Desc;
+int dml_h2_split_table(const DmlH2Desc* table_device, int count, void* stream);
+
 typedef struct DmlWgradDesc {
     const void* x;        /* conv input [B,Hi,Wi,C], pitch ldx                                           */
     const void* dy;       /* output gradient [B,Ho,Wo,N], pitch ldy                                      */

@@ -370,6 +370,67 @@ extern "C" int dml_h2_split(const float* x, int64_t rows, int32_t C, int32_t ld,
     return 0;
 }
 
+// the same for a table of tensors in two launches (every weight copy of a plan after each optimizer step: ~200 tensors, whose
+// ~400 tiny launches cost ~2 ms of the step on the main stream)
+constexpr int H2_TABLE_BLK = 64;           // workgroups per tensor
+__global__ __launch_bounds__(256) void h2_amax_table_kernel(const DmlH2Desc* __restrict__ table) {
+    const DmlH2Desc d = table[blockIdx.y];
+    const int cv = d.C >> 2;
+    const int64_t total = d.rows * cv;
+    uint32_t m = 0;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)H2_TABLE_BLK * 256) {
+        const int64_t r = i / cv;
+        const int c = (int)(i - r * cv) * 4;
+        const float4 v = *reinterpret_cast<const float4*>(d.x + r * d.ld + c);
+        m = max(max(m, __float_as_uint(v.x) & 0x7fffffffu), max(__float_as_uint(v.y) & 0x7fffffffu, max(__float_as_uint(v.z) & 0x7fffffffu,
+                                                                                               __float_as_uint(v.w) & 0x7fffffffu)));
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = max(m, (uint32_t)__shfl_xor((int)m, o, 64));
+    __shared__ uint32_t sh[4];
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) d.work[blockIdx.x] = __uint_as_float(max(max(sh[0], sh[1]), max(sh[2], sh[3])));
+}
+__global__ __launch_bounds__(256) void h2_split_table_kernel(const DmlH2Desc* __restrict__ table) {
+    const DmlH2Desc d = table[blockIdx.y];
+    const float s = h2_scale_from(d.work, H2_TABLE_BLK);
+    if (blockIdx.x == 0 && threadIdx.x == 0) d.work[H2_MAXBLK] = 1.0f / s;
+    const int cv = d.C >> 3;
+    const int64_t total = d.rows * cv;
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    _Float16* const planes = static_cast<_Float16*>(d.planes);
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)H2_TABLE_BLK * 256) {
+        const int64_t r = i / cv;
+        const int c = (int)(i - r * cv) * 8;
+        const float4 v0 = *reinterpret_cast<const float4*>(d.x + r * d.ld + c);
+        const float4 v1 = *reinterpret_cast<const float4*>(d.x + r * d.ld + c + 4);
+        const float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        h8 hi, lo;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float xs = v[e] * s;
+            const _Float16 h = (_Float16)xs;
+            hi[e] = h;
+            lo[e] = (_Float16)(xs - (float)h);
+        }
+        int64_t off;
+        if (d.layout == 0) off = r * d.ldp + c;
+        else off = (((r >> 6) * (d.C >> 5) + (c >> 5)) * 64 + (r & 63)) * 32 + (c & 31);
+        *reinterpret_cast<h8*>(planes + off) = hi;
+        *reinterpret_cast<h8*>(planes + d.plane_stride + off) = lo;
+    }
+}
+
+extern "C" int dml_h2_split_table(const DmlH2Desc* table_device, int count, void* stream) {
+    if (!table_device || count <= 0) return DML_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    hipLaunchKernelGGL(h2_amax_table_kernel, dim3(H2_TABLE_BLK, count), dim3(256), 0, st, table_device);
+    hipLaunchKernelGGL(h2_split_table_kernel, dim3(H2_TABLE_BLK, count), dim3(256), 0, st, table_device);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int Cm, int Cp, void* stream) {
     if (!src || !dst || Cp < Cm) return DML_EINVAL;
     hipLaunchKernelGGL(unpad_wgrad_kernel, dim3(grid_for((int64_t)N * RS * Cm, 256)), dim3(256), 0,

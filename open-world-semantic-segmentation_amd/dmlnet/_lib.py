@@ -78,6 +78,12 @@ class PrepDesc(C.Structure):
                 ("Cp", C.c_int32), ("w_tiled", C.c_int32), ("wt_tiled", C.c_int32)]
 
 
+class H2Desc(C.Structure):
+    """DmlH2Desc: one tensor of a dml_h2_split_table launch"""
+    _fields_ = [("x", c_p), ("planes", c_p), ("work", c_p), ("rows", C.c_int64), ("plane_stride", C.c_int64),
+                ("C", C.c_int32), ("ld", C.c_int32), ("ldp", C.c_int32), ("layout", C.c_int32)]
+
+
 class AugSample(C.Structure):
     _fields_ = [("i", C.c_int32), ("j", C.c_int32), ("flip", C.c_int32), ("n_ops", C.c_int32),
                 ("op", C.c_int32 * 3), ("factor", C.c_float * 3)]
@@ -88,6 +94,7 @@ _PROTOS = {
     "dml_target_arch": (C.c_char_p, []),
     "dml_conv_igemm": (c_i, [C.POINTER(ConvDesc), c_p]),
     "dml_conv_stat_rows": (c_i, [C.POINTER(ConvDesc)]),
+    "dml_h2_split_table": (c_i, [c_p, c_i, c_p]),
     "dml_h2_split": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_i64, c_i, c_i, c_p, c_i, c_p]),
     "dml_conv_wgrad": (c_i, [C.POINTER(WgradDesc), c_p]),
     "dml_prep_weight": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

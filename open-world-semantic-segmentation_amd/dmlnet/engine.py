@@ -330,6 +330,7 @@ class Plan:
         # (2: two fp16 planes per operand, written by dml_h2_split before the first conv that reads a tensor: Plan.h2_of)
         self.f32_split = int(engine.f32_split) if dtype == torch.float32 else 0
         self.prep_h2 = []              # dml_h2_split argument lists of the weight copies, run after every dml_prep_weights
+        self.prep_h2_table = None      # (device array of DmlH2Desc, count) built from them: dml_h2_split_table
         # `work` buffers of dml_h2_split (1025 floats per tensor), carved from one allocation so that ONE fill at the head of
         # the forward zeroes every amax word the step's producers will raise (dml_bn_apply / dml_bn_bwd_apply, `amax`)
         self.h2_slots = torch.zeros(1025 * 1024, dtype=torch.float32, device=self.device) if self.f32_split == 2 else None
@@ -1196,8 +1197,16 @@ class Plan:
                 self.prep_table.append((raw.to(self.device), len(ent), dt))
         for tab, n, dt in self.prep_table:
             _lib.check(self.lib.dml_prep_weights(tab.data_ptr(), n, dt, stream), "dml_prep_weights")
-        for args in self.prep_h2:
-            _lib.check(self.lib.dml_h2_split(*args, stream), "dml_h2_split")
+        if self.prep_h2:
+            # fp16 planes of every weight copy (f16x2): one table, two launches
+            if self.prep_h2_table is None or self.prep_h2_table[1] != len(self.prep_h2):
+                arr = (_lib.H2Desc * len(self.prep_h2))()
+                for i, (x, rows, Cc, ld, planes, pstride, ldp, layout, work, _) in enumerate(self.prep_h2):
+                    arr[i] = _lib.H2Desc(x, planes, work, rows, pstride, Cc, ld, ldp, layout)
+                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+                self.prep_h2_table = (raw.to(self.device), len(self.prep_h2))
+            _lib.check(self.lib.dml_h2_split_table(self.prep_h2_table[0].data_ptr(), self.prep_h2_table[1], stream),
+                       "dml_h2_split_table")
         self.prepped_version = key
 
     # ---- replay: one C call per contiguous run of ops (dml_plan_run) unless the engine is told to stay in Python

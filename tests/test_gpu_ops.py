@@ -1307,6 +1307,25 @@ def test_h2_split_reconstructs_the_tensor(lib, scale):
     assert v == 0.0 or not np.isfinite(v)
 
 
+def test_h2_split_table_equals_the_single_tensor_calls(lib):
+    """dml_h2_split_table (all weight copies of a plan in two launches) writes the planes and scales of per-tensor dml_h2_split
+    calls bit for bit: both layouts, tensors from 64 x 32 to 512 x 2304, one all-zero."""
+    from dmlnet._lib import H2Desc
+    g = torch.Generator(device="cuda").manual_seed(11)
+    shapes = [(64, 32, 1, 1.0), (256, 2304, 1, 0.05), (192, 96, 0, 3e3), (512, 256, 1, 1e-4), (64, 64, 0, 0.0)]
+    xs = [(torch.randn(r, c, device="cuda", generator=g) * sc).contiguous() for r, c, _, sc in shapes]
+    ref = [h2_planes(lib, x, lay) for x, (_, _, lay, _) in zip(xs, shapes)]
+    pls = [torch.zeros_like(p) for p, _ in ref]
+    works = [torch.zeros(1025, device="cuda") for _ in ref]
+    arr = (H2Desc * len(xs))(*[H2Desc(x.data_ptr(), p.data_ptr(), w.data_ptr(), x.shape[0], x.numel(), x.shape[1], x.shape[1],
+                                     x.shape[1], lay) for x, p, w, (_, _, lay, _) in zip(xs, pls, works, shapes)])
+    tab = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).cuda()
+    chk(lib.dml_h2_split_table(tab.data_ptr(), len(xs), st()))
+    torch.cuda.synchronize()
+    for (p0, w0), p1, w1 in zip(ref, pls, works):
+        assert torch.equal(p0, p1) and w0[1024].item() == w1[1024].item()
+
+
 H2_CASES = [("h2_1x1", 2, 24, 20, 64, 128, 1, 1, 1), ("h2_3x3", 2, 19, 23, 64, 256, 3, 1, 1), ("h2_3x3_d2", 2, 16, 16, 128, 256, 3, 1, 2),
             ("h2_3x3_s2", 2, 22, 18, 128, 128, 3, 2, 1), ("h2_rows", 3, 40, 40, 256, 256, 3, 1, 1), ("h2_1x1_n384", 2, 13, 29, 96, 384, 1, 1, 1)]
 
