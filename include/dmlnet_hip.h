@@ -65,7 +65,9 @@ typedef struct DmlConvDesc {
      * dml_bn_apply; the epilogue then also writes that BN's backward partial sums, exactly what
      * dml_bn_bwd_reduce would produce from the stored dz: bnr_partials[ceil(M/rows)][N][2], rows = dml_conv_stat_rows() =
      * (sum g, sum g*(bnr_y - mean)*invstd), g = dz * [mask bit] -- pass it with nblocks = ceil(M/rows) to
-     * dml_bn_bwd_finalize.  bf16, N % 8 == 0, N > 32. */
+     * dml_bn_bwd_finalize.  DML_BF16: N % 8 == 0, N > 32.  DML_F32: only launches the two-plane kernel takes (f32_split == 2 with
+     * planes; dml_conv_stat_rows() == 48), bnr_y fp32, the mask one byte per four channels, N % 64 == 0; bnr_gmax (optional there):
+     * 1024 zeroed floats whose maximum afterwards is max |g| (as `gmax` of dml_bn_bwd_reduce, for dml_h2_bound_bn_bwd). */
     const void* bnr_y;
     const uint8_t* bnr_mask;
     const float* bnr_mean;
@@ -137,6 +139,7 @@ typedef struct DmlConvDesc {
     const float* x_unscale;
     const float* w_unscale;
     int64_t x_plane_stride, w_plane_stride;
+    float* bnr_gmax;      /* see bnr_* above                                                             */
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */

@@ -51,6 +51,7 @@ struct ConvArgs {
     const float* bnr_mean;
     const float* bnr_invstd;
     float* bnr_partials;
+    float* bnr_gmax;
     int bnr_ldy, bnr_relu;
     // forward mode: inference epilogue (DmlConvDesc::post_*)
     const float* post_scale;
@@ -1318,6 +1319,7 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
 // of the accumulate / residual operands -- covers four pixel rows x 256 contiguous bytes: 5-6 us (profiles/r04_h2_epilogue.txt).
 // BatchNorm statistics come from the accumulators as before (conv_epilogue, STATS_ONLY); accumulate and the stores happen on the
 // row side (launches with a bias or the inference epilogue post_* keep conv_epilogue).  `stage`: this wave's own 12 KB.
+constexpr int WS_STAT_ROWS_C = 48;             // (= WS_STAT_ROWS, declared below)
 template <int NT, int MODE>
 __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
                                                    const int lane, char* stage) {
@@ -1335,42 +1337,13 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
     const int c0 = nw0 + (lane & 15) * 4;
     if (c0 >= a.N) return;                                       // (a last, half-empty 128-wide block)
     const bool has_old = a.accum != 0;
+    const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
     float* const yb = static_cast<float*>(a.y);
-    // Two code paths on a wave-uniform branch.  Without an accumulate operand the twelve stores of the sub-tile depend on LDS reads
-    // only and leave back to back.  (One path with the operand selected per element made every store wait vmcnt(0) -- stores count
-    // there too on gfx950 -- i.e. for the store before it: 36 serialised round trips per tile, as slow as the scattered stores this
-    // function replaces.)  With the operand, the loads of the NEXT group of four rows are issued before this group's stores, so that
-    // waiting for them does not wait for the stores.
-    auto body = [&](auto ho) {
-        constexpr bool HO = decltype(ho)::value;
-        float4 old[2][4];
-        auto load_old = [&](const int g4) {
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int m = mw0 + (g4 * 4 + u) * 4 + (lane >> 4);
-                old[g4 & 1][u] = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (m < a.M) old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
-            }
-        };
-        if (HO) load_old(0);
-#pragma unroll
-        for (int g4 = 0; g4 < 3; ++g4) {
-            if (HO && g4 + 1 < 3) load_old(g4 + 1);
-#pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const int r = (g4 * 4 + u) * 4 + (lane >> 4), m = mw0 + r;
-                if (m >= a.M) continue;
-                float4 o = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
-                if (HO) { o.x += old[g4 & 1][u].x; o.y += old[g4 & 1][u].y; o.z += old[g4 & 1][u].z; o.w += old[g4 & 1][u].w; }
-                st16f(yb + (int64_t)m * a.ldy + c0, o.x, o.y, o.z, o.w, (a.nt_out & 1) != 0);
-            }
-        }
-    };
-    if (has_old) {
-        body(std::true_type{});
-    } else {
-        // all twelve LDS reads first (into the registers the sub-tile's accumulators just left), then twelve stores back to back:
-        // read -> wait -> store per row costs an LDS round trip per store, ~3 us per tile
+    if (!has_old && !bnr) {
+        // all twelve LDS reads first (into the registers the sub-tile's accumulators just left), then twelve stores back to back.
+        // (One path with the accumulate operand selected per element made every store wait vmcnt(0) -- stores count there too on
+        // gfx950 -- i.e. for the store before it: 36 serialised round trips per tile, as slow as the scattered stores this function
+        // replaces; hence separate code paths on wave-uniform branches.)
         float4 o[12];
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
@@ -1382,6 +1355,88 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
             const int m = mw0 + k * 4 + (lane >> 4);
             if (m < a.M) st16f(yb + (int64_t)m * a.ldy + c0, o[k].x, o[k].y, o[k].z, o[k].w, (a.nt_out & 1) != 0);
         }
+        return;
+    }
+    // With an accumulate operand (the gradient has earlier producers) and / or the BatchNorm-backward sums of the tensor being
+    // written (DmlConvDesc.bnr_*: sum g, sum g * xhat per 48 rows and channel, g = dz * [ReLU mask bit] -- what dml_bn_bwd_reduce
+    // would compute from the stored tensor, without its pass over dz and y): groups of four rows, the operand loads of the NEXT
+    // group issued before this group's stores, so that waiting for them does not wait for the stores.
+    auto body = [&](auto ho, auto bn) {
+        constexpr bool HO = decltype(ho)::value, BNR = decltype(bn)::value;
+        float4 old[2][4], yv[2][4];
+        uint32_t mb[2][4];
+        float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1, mu = r1, is = r1;
+        uint32_t gmx = 0;
+        if (BNR) {
+            mu = *reinterpret_cast<const float4*>(a.bnr_mean + c0);
+            is = *reinterpret_cast<const float4*>(a.bnr_invstd + c0);
+        }
+        auto load_ops = [&](const int g4) {
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int m = mw0 + (g4 * 4 + u) * 4 + (lane >> 4);
+                old[g4 & 1][u] = make_float4(0.f, 0.f, 0.f, 0.f);
+                yv[g4 & 1][u] = old[g4 & 1][u];
+                mb[g4 & 1][u] = 0xfu;
+                if (m < a.M) {
+                    if (HO) old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
+                    if (BNR) {
+                        yv[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + (int64_t)m * a.bnr_ldy + c0);
+                        if (a.bnr_relu) mb[g4 & 1][u] = a.bnr_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
+                    }
+                }
+            }
+        };
+        load_ops(0);
+#pragma unroll
+        for (int g4 = 0; g4 < 3; ++g4) {
+            if (g4 + 1 < 3) load_ops(g4 + 1);
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                const int r = (g4 * 4 + u) * 4 + (lane >> 4), m = mw0 + r;
+                if (m >= a.M) continue;
+                float4 o = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
+                if (HO) { o.x += old[g4 & 1][u].x; o.y += old[g4 & 1][u].y; o.z += old[g4 & 1][u].z; o.w += old[g4 & 1][u].w; }
+                st16f(yb + (int64_t)m * a.ldy + c0, o.x, o.y, o.z, o.w, (a.nt_out & 1) != 0);
+                if (BNR) {
+                    const uint32_t bits = mb[g4 & 1][u];
+                    const float4 y4 = yv[g4 & 1][u];
+                    const float g0 = (bits & 1u) ? o.x : 0.f, g1 = (bits & 2u) ? o.y : 0.f, g2 = (bits & 4u) ? o.z : 0.f,
+                                g3 = (bits & 8u) ? o.w : 0.f;
+                    r1.x += g0; r1.y += g1; r1.z += g2; r1.w += g3;
+                    r2.x += g0 * (y4.x - mu.x) * is.x; r2.y += g1 * (y4.y - mu.y) * is.y;
+                    r2.z += g2 * (y4.z - mu.z) * is.z; r2.w += g3 * (y4.w - mu.w) * is.w;
+                    gmx = max(max(gmx, __float_as_uint(g0) & 0x7fffffffu), max(__float_as_uint(g1) & 0x7fffffffu,
+                              max(__float_as_uint(g2) & 0x7fffffffu, __float_as_uint(g3) & 0x7fffffffu)));
+                }
+            }
+        }
+        if (BNR) {
+            // the four lane groups (lane >> 4) hold the same four channels: fold, then lanes 0 .. 15 write their channels' pairs
+            float v[8] = {r1.x, r2.x, r1.y, r2.y, r1.z, r2.z, r1.w, r2.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += __shfl_xor(v[e], 16, 64);
+                v[e] += __shfl_xor(v[e], 32, 64);
+            }
+            if (lane < 16 && mw0 < a.M) {
+                float* pp = a.bnr_partials + ((int64_t)(mw0 / WS_STAT_ROWS_C) * a.N + c0) * 2;
+                st16f(pp, v[0], v[1], v[2], v[3], false);
+                st16f(pp + 4, v[4], v[5], v[6], v[7], false);
+            }
+            if (a.bnr_gmax != nullptr) {
+#pragma unroll
+                for (int o = 32; o > 0; o >>= 1) gmx = max(gmx, (uint32_t)__shfl_xor((int)gmx, o, 64));
+                if (lane == 0 && gmx != 0)
+                    atomicMax(reinterpret_cast<uint32_t*>(a.bnr_gmax) + ((blockIdx.x * 16u + (uint32_t)(mw0 / WS_STAT_ROWS_C) + (uint32_t)(nw0 >> 6)) & 1023u), gmx);
+            }
+        }
+    };
+    if (bnr) {
+        if (has_old) body(std::true_type{}, std::true_type{});
+        else body(std::false_type{}, std::true_type{});
+    } else {
+        body(std::true_type{}, std::false_type{});
     }
 }
 
@@ -3023,6 +3078,9 @@ extern "C" int dml_conv_stat_rows(const DmlConvDesc* d) {
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.ldx = d->ldx;
     a.M = d->B * d->Ho * d->Wo;
     a.Ktot = d->R * d->S * d->C;
+    a.y = d->y; a.ldy = d->ldy; a.bias = d->bias;
+    a.post_scale = d->post_scale; a.post_shift = d->post_shift; a.post_mean = d->post_mean; a.post_res = d->post_res;
+    a.post_ldres = d->post_ldres;
     if (d->dtype == DML_F32) {
         a.f32_split = d->f32_split; a.x_planes = d->x_planes; a.w_planes = d->w_planes;
         a.x_unscale = d->x_unscale; a.w_unscale = d->w_unscale;
@@ -3050,6 +3108,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     ConvArgs a;
     a.x = d->x; a.w = d->w; a.y = d->y; a.bias = d->bias; a.stats = d->stats; a.dbg = nullptr;
     a.bnr_y = nullptr; a.bnr_mask = nullptr; a.bnr_mean = nullptr; a.bnr_invstd = nullptr; a.bnr_partials = nullptr;
+    a.bnr_gmax = nullptr;
     a.bnr_ldy = 0; a.bnr_relu = 0;
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
@@ -3102,15 +3161,24 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
         a.post_scale = d->post_scale; a.post_shift = d->post_shift; a.post_mean = d->post_mean; a.post_res = d->post_res;
         a.post_ldres = d->post_ldres; a.post_relu = d->post_relu;
     }
+    a.bnr_gmax = nullptr;
     if (d->bnr_partials) {
-        // fused BN-backward reduce: data-gradient mode, bf16 result stored as 16-byte vectors, 8-channel mask bytes
-        if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || !d->bnr_y || !d->bnr_mean || !d->bnr_invstd ||
-            (d->bnr_relu && !d->bnr_mask))
+        // fused BN-backward reduce: data-gradient mode; bf16 result stored as 16-byte vectors, 8-channel mask bytes -- or fp32 on the
+        // two-plane kernel (checked below, once the launch is described), 4-channel mask bytes
+        if (d->mode != 1 || d->y_f32 || !d->bnr_y || !d->bnr_mean || !d->bnr_invstd || (d->bnr_relu && !d->bnr_mask))
             return DML_EINVAL;
-        if (d->N % 8 || d->ldy % 8 || d->bnr_ldy % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
-            (reinterpret_cast<uintptr_t>(d->bnr_y) & 15) || (reinterpret_cast<uintptr_t>(d->bnr_partials) & 15) || d->N <= 32)
-            return DML_EUNSUPPORTED;
-        if (d->bnr_relu && (d->N & 63) == 0 && (reinterpret_cast<uintptr_t>(d->bnr_mask) & 7)) return DML_EALIGN;
+        if (d->dtype == DML_BF16) {
+            if (d->N % 8 || d->ldy % 8 || d->bnr_ldy % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
+                (reinterpret_cast<uintptr_t>(d->bnr_y) & 15) || (reinterpret_cast<uintptr_t>(d->bnr_partials) & 15) || d->N <= 32)
+                return DML_EUNSUPPORTED;
+            if (d->bnr_relu && (d->N & 63) == 0 && (reinterpret_cast<uintptr_t>(d->bnr_mask) & 7)) return DML_EALIGN;
+        } else {
+            if (d->N % 64 || d->bnr_ldy % 4) return DML_EUNSUPPORTED;
+            if (((reinterpret_cast<uintptr_t>(d->bnr_y) | reinterpret_cast<uintptr_t>(d->bnr_partials) |
+                  reinterpret_cast<uintptr_t>(d->bnr_mean) | reinterpret_cast<uintptr_t>(d->bnr_invstd)) & 15) != 0)
+                return DML_EALIGN;
+            a.bnr_gmax = d->bnr_gmax;
+        }
         a.bnr_y = d->bnr_y; a.bnr_mask = d->bnr_mask; a.bnr_mean = d->bnr_mean; a.bnr_invstd = d->bnr_invstd;
         a.bnr_partials = d->bnr_partials; a.bnr_ldy = d->bnr_ldy; a.bnr_relu = d->bnr_relu;
     }
@@ -3128,6 +3196,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if (a.acc32) return launch_conv<bf16_t, 2>(a, st);
     if (d->dtype == DML_BF16)
         return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
+    if (a.bnr_partials && !conv_ws_planes_eligible(a)) return DML_EUNSUPPORTED;      // fp32: only the two-plane kernel writes the sums
     return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
 }
 
@@ -3146,6 +3215,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, float* dbg, 
     a.div_c = make_fastdiv((uint32_t)d->C);
     a.dbg = dbg;
     a.bnr_y = nullptr; a.bnr_mask = nullptr; a.bnr_mean = nullptr; a.bnr_invstd = nullptr; a.bnr_partials = nullptr;
+    a.bnr_gmax = nullptr;
     a.bnr_ldy = 0; a.bnr_relu = 0;
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;

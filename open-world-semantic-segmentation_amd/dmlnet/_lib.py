@@ -45,7 +45,7 @@ class ConvDesc(C.Structure):
                 ("w_tiled", C.c_int32), ("ws_min_tiles", C.c_int32),
                 # f32_split == 2: fp16 hi / lo planes of the scaled operands (dml_h2_split; see the header)
                 ("x_planes", c_p), ("w_planes", c_p), ("x_unscale", c_p), ("w_unscale", c_p),
-                ("x_plane_stride", C.c_int64), ("w_plane_stride", C.c_int64)]
+                ("x_plane_stride", C.c_int64), ("w_plane_stride", C.c_int64), ("bnr_gmax", c_p)]
 
 
 PLAN_MAX_ARGS = 24

@@ -819,12 +819,18 @@ class Plan:
         fused = (prod is not None and self.dtype == torch.bfloat16 and (u.mask is not None or not u.relu)
                  and u.drop is None and N % 8 == 0 and N > 32 and G <= 4096 and prod.N == N and prod.ldy == N
                  and dz.ld == N and prod.y == dz.ptr)
+        # fp32 tensors: the two-plane kernel's epilogue does the same (4-channel mask bytes, 48-row groups, max |g| for dy's bound)
+        fused = fused or (prod is not None and self.dtype == torch.float32 and prod.f32_split == 2 and prows == 48
+                          and (u.mask is not None or not u.relu) and u.drop is None and N % 64 == 0 and G <= 4096
+                          and prod.N == N and prod.ldy == N and dz.ld == N and prod.y == dz.ptr and u.y.ld % 4 == 0)
         a1 = None
         if fused:
             part = self.fbuf(G * N * 2)
             prod.bnr_y, prod.bnr_mask = u.y.ptr, mk
             prod.bnr_mean, prod.bnr_invstd = u.mean.data_ptr(), u.invstd.data_ptr()
             prod.bnr_partials, prod.bnr_ldy, prod.bnr_relu = part.data_ptr(), u.y.ld, 1 if u.relu else 0
+            if gwork is not None:
+                prod.bnr_gmax = gwork.data_ptr()
             nblk = C.c_int(G)
             self.keep.append(nblk)
             sp = part.data_ptr()

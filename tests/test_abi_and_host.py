@@ -39,8 +39,8 @@ def test_library_exports_every_declared_symbol():
 def test_struct_layout_matches_header():
     from dmlnet._lib import ConvDesc, WgradDesc
     # 5 ptr + 18 int32 | bnr: 5 ptr + 2 int32 | post: 4 ptr + 2 int32 | tail: ptr, int64, ptr, 2 int32 | res: 2 ptr + 2 int32 |
-    # acc32: ptr + int32, f32_split, w_tiled, ws_min_tiles | planes: 4 ptr + 2 int64
-    assert ctypes.sizeof(ConvDesc) == 328
+    # acc32: ptr + int32, f32_split, w_tiled, ws_min_tiles | planes: 4 ptr + 2 int64 | bnr_gmax
+    assert ctypes.sizeof(ConvDesc) == 336 and ConvDesc.bnr_gmax.offset == 328
     assert ConvDesc.B.offset == 40 and ConvDesc.mode.offset == 40 + 17 * 4
     assert ConvDesc.bnr_y.offset == 112 and ConvDesc.bnr_ldy.offset == 152 and ConvDesc.post_scale.offset == 160
     assert ConvDesc.tail_ws.offset == 200 and ConvDesc.tail_counters_len.offset == 224

@@ -76,7 +76,7 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
             ws = torch.empty(48 << 20, device="cuda")
             dw = torch.zeros(N, k, k, Cc, device="cuda")
             wg = WgradDesc(x=x.data_ptr(), dy=dy.data_ptr(), dw=dw.data_ptr(), B=B, Hi=H, Wi=W, C=Cc, ldx=Cc, Ho=H, Wo=W, N=N, ldy=N,
-                           R=k, S=k, stride=1, dil=dil, pad=pad, dtype=0, splitk=0, Cm=0, ws=ws.data_ptr(), ws_elems=ws.numel(),
+                           R=k, S=k, stride=1, dil=dil, pad=pad, dtype=0, splitk=int(os.environ.get("BENCH_SPLITK", "0")), Cm=0, ws=ws.data_ptr(), ws_elems=ws.numel(),
                            f32_split=sp)
             if sp == 2:
                 wg.x_planes, wg.x_unscale, wg.x_plane_stride = xp.data_ptr(), xw.data_ptr() + 4096, xp.shape[1]
