@@ -1403,6 +1403,63 @@ def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
         assert a_ <= max(4.0 * b_, 2e-6), errs
 
 
+@pytest.mark.parametrize("accum,relu", [(0, 1), (1, 1), (1, 0)])
+def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
+    """DmlConvDesc.bnr_* on fp32 tensors (the two-plane kernel's row epilogue): the data gradient writes the BN-backward sums of
+    the tensor it stores per 48 rows -- what dml_bn_bwd_reduce computes from that tensor -- and raises max |g| in bnr_gmax; a
+    ragged last group, the accumulate path, ReLU mask of one byte per four channels.  Other fp32 kernels refuse the request."""
+    B, Hh, Ww, Cin, Cout, k = 2, 13, 11, 128, 64, 3          # dgrad output: M = 286 rows (5.96 groups of 48) x 128 channels
+    M = B * Hh * Ww
+    gyd = (torch.randn(B, Hh, Ww, Cout, device="cuda") * 1e-2).contiguous()
+    wt = (torch.randn(Cin, k, k, Cout, device="cuda") * 0.05).contiguous()          # wt[Cin][R][S][Cout]
+    dx0 = torch.randn(B, Hh, Ww, Cin, device="cuda") * 3e-3
+    dx = dx0.clone()
+    ybn = torch.randn(M, Cin, device="cuda") * 1.5 + 0.3
+    bits = torch.randint(0, 16, (M * Cin // 4,), device="cuda", dtype=torch.uint8)
+    mean, invstd = torch.randn(Cin, device="cuda") * 0.2, torch.rand(Cin, device="cuda") + 0.5
+    G = (M + 47) // 48
+    part = torch.full((G * Cin * 2,), 7.0, device="cuda")
+    gmax = torch.zeros(1024, device="cuda")
+    d = make_desc(lib, gyd, wt, dx, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, 1, 1, 0, mode=1, accum=accum)
+    ap, aw = h2_planes(lib, gyd.view(-1, Cout), 0)
+    wp, ww = h2_planes(lib, wt.view(Cin, -1), 1)
+    d.f32_split = 2
+    d.x_planes, d.x_unscale, d.x_plane_stride = ap.data_ptr(), aw.data_ptr() + 4096, ap.shape[1]
+    d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
+    assert lib.dml_conv_stat_rows(C.byref(d)) == 48
+    d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+    d.bnr_partials, d.bnr_ldy, d.bnr_relu, d.bnr_gmax = part.data_ptr(), Cin, relu, gmax.data_ptr()
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    torch.cuda.synchronize()
+    # the stored tensor itself: conv (+ the earlier value)
+    ref = torch.nn.functional.conv_transpose2d(gyd.permute(0, 3, 1, 2).double(), wt.permute(3, 0, 1, 2).double(), padding=1)
+    ref = ref.permute(0, 2, 3, 1) + (dx0.double() if accum else 0.0)
+    assert (dx.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    g = dx.view(M, Cin).double()
+    if relu:
+        mk = ((bits.view(M, Cin // 4, 1) >> torch.arange(4, device="cuda").view(1, 1, 4)) & 1).reshape(M, Cin).double()
+        g = g * mk
+    xh = (ybn.double() - mean.double()) * invstd.double()
+    pad = G * 48 - M
+    gp = torch.cat([g, torch.zeros(pad, Cin, device="cuda", dtype=torch.float64)]).view(G, 48, Cin)
+    xp = torch.cat([xh, torch.zeros(pad, Cin, device="cuda", dtype=torch.float64)]).view(G, 48, Cin)
+    want = torch.stack([gp.sum(1), (gp * xp).sum(1)], dim=-1)
+    relclose(part.view(G, Cin, 2).cpu(), want.cpu(), 1e-5, "per-group partials")
+    assert abs(gmax.max().item() - g.abs().max().item()) <= 1e-6 * g.abs().max().item()
+    # against the stand-alone reduce on the stored tensor
+    part2 = torch.zeros(4096 * Cin * 2, device="cuda")
+    nb = C.c_int(0)
+    chk(lib.dml_bn_bwd_reduce(dx.data_ptr(), ybn.data_ptr(), None, bits.data_ptr(), mean.data_ptr(), invstd.data_ptr(),
+                              part2.data_ptr(), M, Cin, Cin, Cin, Cin, relu, 1.0, 0, C.byref(nb), None, st()))
+    torch.cuda.synchronize()
+    a = part.view(G, Cin, 2).double().sum(0)
+    b = part2[: nb.value * Cin * 2].view(nb.value, Cin, 2).double().sum(0)
+    relclose(a.cpu(), b.cpu(), 2e-6, "sums vs dml_bn_bwd_reduce")
+    # without planes (exact fp32 / three-term kernels) the request is refused, not ignored
+    d.f32_split, d.x_planes = 1, None
+    assert lib.dml_conv_igemm(C.byref(d), st()) == -3
+
+
 def _tile_major(mat):
     """[rows][K] -> [rows / 64][K / 32][64][32] (DmlPrepDesc.w_tiled)"""
     rows, K = mat.shape
