@@ -1856,12 +1856,18 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 }
 
 // may this launch run on conv_ws_kernel?  (shared by launch_conv and dml_conv_stat_rows)
-static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t wb) {
+static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t wb, const int mode = 1) {
     // bf16 plans: OPT-IN (DML_CONV_WS=1).  Per launch it wins where K is long (rule below), but in the train step the persistent
     // 150 KB-of-LDS workgroups keep the side stream's weight-gradient workgroups off the CUs they hold and static tile lists
     // cannot rebalance around them: whole step 391.5 / 392.2 images/s with it, 395.3 / 394.9 without (two interleaved pairs,
     // profiles/r04_ab_ws.txt).  The two-plane fp32 mode (conv_ws_planes_eligible) always runs on it.
-    static const int ws_on = getenv("DML_CONV_WS") ? atoi(getenv("DML_CONV_WS")) : 0;
+    static const int ws_env = getenv("DML_CONV_WS") ? atoi(getenv("DML_CONV_WS")) : -1;
+    // default (no DML_CONV_WS): FORWARD launches with a long K loop only -- nothing runs beside the forward's main stream, so the
+    // persistent workgroups cost nobody a CU, and the long-K layers are where the kernel is ahead (3x3 256 -> 256: 60.5 -> 52.9 us,
+    // ASPP 3x3 372 -> 284, layer4 3x3 207 -> 158)
+    // (not the decoder's 3x3 on the 192 x 192 map: sixteen tiles per CU, where the ring kernel's three workgroups per CU overlap
+    // epilogues with K loops and the two are level: 886 -> 825-870 us in isolation, nothing in the step)
+    const bool ws_on = ws_env > 0 || (ws_env < 0 && mode == 0 && a.R * a.S * a.C >= 2304 && (a.N % 256) == 0 && a.M <= 144 * 256 * 4);
     if ((!ws_on && a.ws_min_tiles <= 0) || !a.w_tiled || (a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 128) != 0) return false;
     if (xb >= (1ll << 31) || wb >= (1ll << 31)) return false;
     // long K loops only: a consumer wave runs its tile's epilogue itself, with nothing of the same workgroup to cover it, and
@@ -2910,7 +2916,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // N a multiple of 128, enough tiles to fill the chip.  Same-box microbenchmarks against the ring kernel below
             // (profiles/r04_ws_probe_3.txt vs r04_ws_probe_1_shipped.txt): layer3 3x3 67.5 -> 43.6 us, 1x1 1024 -> 256
             // 37.6 -> 24.2, 1x1 256 -> 1024 38.4 -> 31.0, ASPP 3x3 385 -> 325-357, decoder 3x3 886 -> 825-870.
-            if (conv_ws_eligible(a, xb, wb)) {
+            if (conv_ws_eligible(a, xb, wb, MODE)) {
                 constexpr int CUS = 256, NLD = 3;
                 const bool wide = (a.N % 256) == 0;
                 const int bm = wide ? 144 : 288;
@@ -3092,7 +3098,7 @@ extern "C" int dml_conv_stat_rows(const DmlConvDesc* d) {
     const int64_t xb = ((int64_t)(d->B * d->Hi) * d->Wi - 1) * d->ldx * 2 + (int64_t)d->C * 2;
     const int64_t wb = (int64_t)d->N * d->R * d->S * d->C * 2;
     static const bool use_v1 = getenv("DML_CONV_V1") != nullptr;
-    return (!use_v1 && conv_ws_eligible(a, xb, wb)) ? WS_STAT_ROWS : DML_STAT_ROWS;
+    return (!use_v1 && conv_ws_eligible(a, xb, wb, d->mode)) ? WS_STAT_ROWS : DML_STAT_ROWS;
 }
 
 extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
