@@ -1861,13 +1861,10 @@ static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t 
     // 150 KB-of-LDS workgroups keep the side stream's weight-gradient workgroups off the CUs they hold and static tile lists
     // cannot rebalance around them: whole step 391.5 / 392.2 images/s with it, 395.3 / 394.9 without (two interleaved pairs,
     // profiles/r04_ab_ws.txt).  The two-plane fp32 mode (conv_ws_planes_eligible) always runs on it.
-    static const int ws_env = getenv("DML_CONV_WS") ? atoi(getenv("DML_CONV_WS")) : -1;
-    // default (no DML_CONV_WS): FORWARD launches with a long K loop only -- nothing runs beside the forward's main stream, so the
-    // persistent workgroups cost nobody a CU, and the long-K layers are where the kernel is ahead (3x3 256 -> 256: 60.5 -> 52.9 us,
-    // ASPP 3x3 372 -> 284, layer4 3x3 207 -> 158)
-    // (not the decoder's 3x3 on the 192 x 192 map: sixteen tiles per CU, where the ring kernel's three workgroups per CU overlap
-    // epilogues with K loops and the two are level: 886 -> 825-870 us in isolation, nothing in the step)
-    const bool ws_on = ws_env > 0 || (ws_env < 0 && mode == 0 && a.R * a.S * a.C >= 2304 && (a.N % 256) == 0 && a.M <= 144 * 256 * 4);
+    // (forward-only for the long-K launches, where nothing runs beside the main stream, measured +0.1...0.4 % on the step -- and moved
+    // the bf16 plan's rounding (48-row statistics groups) enough to redraw the chaotic 30-step trajectory of
+    // tests/test_gpu_training_equivalence.py past its bar; not worth a different default)
+    static const int ws_on = getenv("DML_CONV_WS") ? atoi(getenv("DML_CONV_WS")) : 0;
     if ((!ws_on && a.ws_min_tiles <= 0) || !a.w_tiled || (a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 128) != 0) return false;
     if (xb >= (1ll << 31) || wb >= (1ll << 31)) return false;
     // long K loops only: a consumer wave runs its tile's epilogue itself, with nothing of the same workgroup to cover it, and

@@ -17,6 +17,7 @@ import ctypes as C
 import itertools
 import os
 import struct
+import weakref
 from typing import List, Optional
 
 import torch
@@ -1477,12 +1478,16 @@ class Engine:
         for rec in plan.heads:
             # a deferred loss gradient of this head's PREVIOUS forward that never reached backward() (the loss was dropped,
             # or a second forward ran first) is void now: its features buffer is about to be replaced
-            lazy_grad.drop_for(getattr(rec, "logits_ref", None))
+            lazy_grad.drop_for(rec.logits_ref() if getattr(rec, "logits_ref", None) is not None else None)
             lg = torch.empty((B, rec.K, H, W), dtype=torch.float32, device=x.device)
             ft = torch.empty((B, H, W, rec.Kp), dtype=torch.float32, device=x.device)
-            rec.feats_p = ft                 # the kernels' (channel-padded) features; the backward reads them again
+            # The plan must not own the tensors it hands out: returned from the autograd node they carry its grad_fn, whose context
+            # holds model and plan -- a cycle through C++ objects the garbage collector cannot see, and every dropped model would
+            # keep its plans (tens of GB at the benchmark size) for the life of the process.  An alias without autograd identity
+            # (same storage, same version counter) for the features, a weak reference for the identity test on the logits.
+            rec.feats_p = ft.detach()        # the kernels' (channel-padded) features; the backward reads them again
             rec.feats_version = None
-            rec.logits_ref = lg
+            rec.logits_ref = weakref.ref(lg)
             rec.head_args[2], rec.head_args[3] = lg.data_ptr(), ft.data_ptr()
             logits.append(lg)
             feats.append(ft)
@@ -1524,7 +1529,7 @@ class Engine:
                 skip.append(plan.head_bwd_range[hi])         # accumulating segment: nothing to add
                 continue
             lazy = lazy_grad.take(gl)
-            if lazy is not None and (lazy.logits is not rec.logits_ref
+            if lazy is not None and (lazy.logits is not rec.logits_ref()
                                      or tuple(lazy.logits.shape) != (plan.B, rec.K, plan.H, plan.W)):
                 # the marker belongs to another forward of this plan than the one whose activations it holds now (a second
                 # train-mode forward ran before this backward): the stored tensors are not the ones the loss saw
@@ -1546,8 +1551,8 @@ class Engine:
                                                  lazy.gout.data_ptr(), gl.data_ptr(), plan.B, rec.K, plan.H, plan.W,
                                                  int(lazy.ignore_index), float(lazy.alpha), float(lazy.n_images), stream),
                            "dml_loss_bwd")
-            elif gl is not None and lazy_grad.outstanding_for(getattr(rec, "logits_ref", None)):
-                lazy_grad.drop_for(rec.logits_ref)
+            elif gl is not None and lazy_grad.outstanding_for(rec.logits_ref()):
+                lazy_grad.drop_for(rec.logits_ref())
                 raise RuntimeError("the loss was built with fused_backward=True but the logits have another consumer: its "
                                    "gradient was added to the deferred-gradient marker.  Construct the loss with "
                                    "fused_backward=False")

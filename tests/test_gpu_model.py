@@ -434,8 +434,11 @@ def test_state_dict_roundtrip_into_oracle():
 def test_baseline_size_properties(dtype, products):
     """768x768 bs=16 (BASELINE configs[2]) train steps: size-independent properties of the head and loss, in bf16, exact fp32 and
     the bench headline's arithmetic (fp32 tensors, products of two fp16 planes per operand)."""
+    import gc
     import utils
     from dmlnet.optim import FusedSGD
+    gc.collect()                                      # the previous case's plan (tens of GB at this size) hangs in reference cycles
+    torch.cuda.empty_cache()
     m = build(dtype=dtype, fp32_products=products)
     m.classifier.aspp.project[3].train()             # dropout on, as in the real step
     g = torch.Generator(device="cpu").manual_seed(1234)
@@ -478,8 +481,12 @@ def test_baseline_size_f16x2_step_against_exact_fp32_step():
     lab = torch.randint(0, 16, (16, 768, 768), generator=g)
     lab[:, :38] = 255
     lab = lab.cuda()
+    import gc
     out = {}
     for products in ("exact", "bf16x3", "f16x2"):
+        gc.collect()                     # plans of earlier tests (tens of GB each at this size) hang in reference cycles
+        torch.cuda.empty_cache()
+        assert torch.cuda.memory_allocated() < 20e9, "plans of earlier tests are still allocated"
         m = build(fp32_products=products)
         crit = utils.DMLLoss(alpha=0.01, ignore_index=255)
         lg, ctr, ft = m(img)
@@ -488,7 +495,8 @@ def test_baseline_size_f16x2_step_against_exact_fp32_step():
         grads = {k: p.grad.detach().flatten()[:: max(1, p.numel() // 4096)].double().cpu() for k, p in m.named_parameters()}
         gn = {k: float(p.grad.detach().double().norm()) for k, p in m.named_parameters()}
         out[products] = (lg.detach()[:, :, ::16, ::16].double().cpu(), float(loss.detach()), grads, gn)
-        del m, lg, ctr, ft, loss
+        del m, lg, ctr, ft, loss, crit
+        gc.collect()
         torch.cuda.empty_cache()
     lg0, l0, g0, n0 = out["exact"]
     stats = {}
@@ -508,6 +516,32 @@ def test_baseline_size_f16x2_step_against_exact_fp32_step():
     (e3, n3), (e2, n2) = stats["bf16x3"], stats["f16x2"]
     assert np.median(e2) <= 1.5 * np.median(e3) + 1e-3 and e2.max() <= 2.0 * e3.max() + 1e-3
     assert np.median(n2) <= 1.5 * np.median(n3) + 1e-4 and np.percentile(n2, 95) <= 2.0 * np.percentile(n3, 95) + 1e-4
+
+
+def test_a_dropped_model_frees_its_plans():
+    """The plan hands out its logits / features through an autograd node whose context holds model and plan; it must not own
+    those tensors itself, or model + engine + plans form a cycle through C++ objects that the garbage collector never breaks
+    (round 4: every dropped model kept its plans -- 60-100 GB each at 16 x 768 x 768 -- until the process ended)."""
+    import gc
+    import weakref
+    import utils
+    gc.collect()
+    torch.cuda.empty_cache()
+    base = torch.cuda.memory_allocated()
+    m = build(fp32_products="f16x2")
+    img, lab = g5_inputs()
+    lg, ctr, ft = m(img)
+    loss = utils.DMLLoss(alpha=0.01, ignore_index=255)(lg, lab, ft)
+    loss.backward()
+    torch.cuda.synchronize()
+    plan = next(iter(m._engine.plans.values()))
+    wp, wm = weakref.ref(plan), weakref.ref(m)
+    assert torch.cuda.memory_allocated() - base > 500e6
+    del m, lg, ctr, ft, loss, plan
+    gc.collect()
+    torch.cuda.empty_cache()
+    assert wp() is None and wm() is None
+    assert torch.cuda.memory_allocated() - base < 50e6, torch.cuda.memory_allocated() - base
 
 
 def _multihead(dtype=torch.float32):

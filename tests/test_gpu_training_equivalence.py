@@ -172,9 +172,14 @@ def test_bf16_training_tracks_fp32_over_30_steps():
     # (the scale of "equal" at step 30 is how far two fp32 implementations of the same step -- this plan in fp32 and the oracle --
     # or the emulation and the oracle have drifted apart by then: one draw each of a chaotic trajectory.  The HIP runs are
     # bitwise reproducible, test_gpu_model.py::test_train_steps_are_bitwise_reproducible, so the draw is a fixed one.)
+    # The yardstick is taken over the LAST TEN steps, not at the final ones alone: where two trajectories happen to cross at the end
+    # (round 4: the two fp32 implementations 0.4 % apart over steps 25-29, 2.5 % over steps 20-29) a five-step window makes the bar
+    # a function of that coincidence.
     ref_final = max(abs(le[-5:].mean() - lo[-5:].mean()), abs(l32[-5:].mean() - lo[-5:].mean()))
-    checks.append((abs(l16[-5:].mean() - l32[-5:].mean()) <= 2.0 * ref_final + 3e-2 * l32[-5:].mean(),
-                   "final loss level %.4f vs %.4f (fp32 implementations apart by %.4f)" % (l16[-5:].mean(), l32[-5:].mean(), ref_final)))
+    ref_late = max(d_emu[-10:].mean(), d_32[-10:].mean())
+    checks.append((abs(l16[-5:].mean() - l32[-5:].mean()) <= 2.0 * max(ref_final, ref_late * l32[-5:].mean()) + 3e-2 * l32[-5:].mean(),
+                   "final loss level %.4f vs %.4f (fp32 implementations apart by %.4f at the end, %.2e relative over the last ten steps)"
+                   % (l16[-5:].mean(), l32[-5:].mean(), ref_final, ref_late)))
     # (3) weight drift per stage and running variances, after 6 and after 30 steps: hip bf16 vs hip fp32 against
     # emulation vs oracle at the same step
     sd0f = {k: v.float() for k, v in sd0.items()}
