@@ -116,7 +116,12 @@ typedef struct DmlConvDesc {
     /* dtype DML_F32 only (2: see x_planes below): 1 = compute the products on the bf16 matrix cores through a three-term split of both operands
      * (x = hi + mid + lo, six bf16 MFMAs per block: fp32-level error, 2.7x fewer matrix cycles than v_mfma_f32_16x16x4_f32);
      * 0 = the exact fp32 MFMA, the reference's arithmetic (network/utils.py:84-118 computes in fp32).  Shapes the split kernel
-     * does not take (C % 32 != 0, N <= 32) run exact either way. */
+     * does not take (C % 32 != 0, N <= 32) run exact either way.
+     * Both split modes REQUIRE finite operands within the narrow format's range: with f32_split == 1 an Inf (or |x| > 3.39e38,
+     * which rounds to a bf16 Inf) becomes hi = Inf, mid = Inf - Inf = NaN, so the output is NaN where exact fp32 would carry
+     * the Inf; with f32_split == 2 the scale of a tensor that holds an Inf or NaN is 0 / NaN and the whole output is NaN.
+     * Either way a non-finite input is visible in the output (never clipped or dropped), but not element for element as in
+     * the exact mode.  Residuals below 2^-126 (fp32 subnormals) are flushed. */
     int32_t f32_split;
     /* 1 = `w` is the tile-major copy dml_prep_weights writes (DmlPrepDesc.w_tiled: [N / 64][K / 32][64][32], K = R * S * C): the
      * weight half of every LDS-DMA instruction is one contiguous KB (whole 128-byte lines) instead of sixteen 64-byte row

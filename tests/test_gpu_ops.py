@@ -1260,6 +1260,29 @@ def test_conv_f32_three_term_split_is_fp32_accurate(lib, case):
         assert a_ <= max(4.0 * b_, 2e-6), errs
 
 
+def test_split_products_keep_a_non_finite_input_visible(lib):
+    """f32_split = 1: an Inf in the activations becomes hi = Inf, mid = Inf - Inf = NaN (include/dmlnet_hip.h): every output the Inf
+    reaches is non-finite (NaN where exact fp32 gives Inf), every output it does not reach is unaffected."""
+    B, Hh, Ww, Cin, Cout = 1, 8, 8, 64, 64
+    x = torch.randn(B, Hh, Ww, Cin, device="cuda")
+    x[0, 3, 4, 7] = float("inf")
+    w = (torch.randn(Cout, 1, 1, Cin, device="cuda") * 0.1).contiguous()
+    ys = {}
+    for split in (0, 1):
+        y = torch.zeros(B, Hh, Ww, Cout, device="cuda")
+        d = make_desc(lib, x, w, y, B, Hh, Ww, Cin, Hh, Ww, Cout, 1, 1, 1, 0, 0)
+        d.f32_split = split
+        chk(lib.dml_conv_igemm(C.byref(d), st()))
+        torch.cuda.synchronize()
+        ys[split] = y
+    hit = torch.zeros(B, Hh, Ww, dtype=torch.bool, device="cuda")
+    hit[0, 3, 4] = True
+    for split in (0, 1):
+        assert not torch.isfinite(ys[split][hit]).any(), split
+        assert torch.isfinite(ys[split][~hit]).all(), split
+    assert (ys[1][~hit] - ys[0][~hit]).abs().max().item() <= 1e-5 * ys[0][~hit].abs().max().item()
+
+
 def h2_planes(lib, t2d, layout=0, amax=None):
     """dml_h2_split of an fp32 [rows][C] cuda tensor -> (planes fp16 [2][rows * C], work) ; work[1024] = 1 / scale"""
     rows, Cc = t2d.shape
