@@ -98,9 +98,9 @@ typedef struct DmlConvDesc {
     int64_t tail_ws_elems;
     int32_t* tail_counters;
     int32_t tail_counters_len, tail_reserved;
-    /* mode 1 only, optional (bf16, same conditions as bnr_*; not with accum): y = conv + res_dz (.) [res_mask bit], i.e.
-     * the gradient that reaches a bottleneck's input through its identity branch -- the block output's gradient res_dz
-     * [M][N] (pitch res_ld) masked by the 1-bit ReLU mask of that output (dml_bn_apply's, one byte per 8 channels) --
+    /* mode 1 only, optional (same conditions as bnr_*: bf16, or fp32 on the two-plane kernel; not with accum): y = conv + res_dz (.)
+     * [res_mask bit], i.e. the gradient that reaches a bottleneck's input through its identity branch -- the block output's gradient
+     * res_dz [M][N] (pitch res_ld) masked by the 1-bit ReLU mask of that output (dml_bn_apply's, one byte per 16-byte vector) --
      * is added in the epilogue of conv1's data gradient (resnet.py:96-113 backward), so that the BN-backward apply of
      * the block's bn3 need not write the masked copy (dres = NULL there) for this launch to read back. */
     const void* res_dz;

@@ -1336,7 +1336,10 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own writes, read back by other lanes
     const int c0 = nw0 + (lane & 15) * 4;
     if (c0 >= a.N) return;                                       // (a last, half-empty 128-wide block)
-    const bool has_old = a.accum != 0;
+    // the accumulate operand: the gradient's earlier value (accum), or the identity branch's share of it -- the block output's
+    // gradient res_dz under its ReLU mask (DmlConvDesc.res_*, one mask byte per four channels)
+    const bool resm = MODE == 1 && a.res_dz != nullptr;
+    const bool has_old = a.accum != 0 || resm;
     const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
     float* const yb = static_cast<float*>(a.y);
     if (!has_old && !bnr) {
@@ -1379,7 +1382,16 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
                 yv[g4 & 1][u] = old[g4 & 1][u];
                 mb[g4 & 1][u] = 0xfu;
                 if (m < a.M) {
-                    if (HO) old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
+                    if (HO) {
+                        if (resm) {
+                            float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.res_dz) + (int64_t)m * a.res_ld + c0);
+                            const uint32_t rb = a.res_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
+                            t.x = (rb & 1u) ? t.x : 0.f; t.y = (rb & 2u) ? t.y : 0.f; t.z = (rb & 4u) ? t.z : 0.f; t.w = (rb & 8u) ? t.w : 0.f;
+                            old[g4 & 1][u] = t;
+                        } else {
+                            old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
+                        }
+                    }
                     if (BNR) {
                         yv[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + (int64_t)m * a.bnr_ldy + c0);
                         if (a.bnr_relu) mb[g4 & 1][u] = a.bnr_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
@@ -3146,11 +3158,16 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     }
     if (d->res_dz) {
         // masked residual gradient in the epilogue: the 16-byte-vector bf16 path of the data gradient only
-        if (d->mode != 1 || d->dtype != DML_BF16 || d->y_f32 || d->accum || !d->res_mask) return DML_EINVAL;
-        if (d->N % 8 || d->ldy % 8 || d->res_ld % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
-            (reinterpret_cast<uintptr_t>(d->res_dz) & 15) || d->N <= 32)
+        // (fp32: the two-plane kernel's row epilogue, 4-channel mask bytes; checked against the launch below)
+        if (d->mode != 1 || d->y_f32 || d->accum || !d->res_mask) return DML_EINVAL;
+        if (d->dtype == DML_BF16) {
+            if (d->N % 8 || d->ldy % 8 || d->res_ld % 8 || (reinterpret_cast<uintptr_t>(d->y) & 15) ||
+                (reinterpret_cast<uintptr_t>(d->res_dz) & 15) || d->N <= 32)
+                return DML_EALIGN;
+            if ((d->N & 63) == 0 && (reinterpret_cast<uintptr_t>(d->res_mask) & 7)) return DML_EALIGN;      // 8-byte mask rows
+        } else if (d->N % 64 || d->res_ld % 4 || (reinterpret_cast<uintptr_t>(d->res_dz) & 15)) {
             return DML_EALIGN;
-        if ((d->N & 63) == 0 && (reinterpret_cast<uintptr_t>(d->res_mask) & 7)) return DML_EALIGN;      // 8-byte mask rows
+        }
         a.res_dz = d->res_dz; a.res_mask = d->res_mask; a.res_ld = d->res_ld;
     }
     if (d->tail_ws && d->tail_counters && d->tail_ws_elems > 0 && d->tail_counters_len > 0) {
@@ -3199,7 +3216,8 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if (a.acc32) return launch_conv<bf16_t, 2>(a, st);
     if (d->dtype == DML_BF16)
         return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
-    if (a.bnr_partials && !conv_ws_planes_eligible(a)) return DML_EUNSUPPORTED;      // fp32: only the two-plane kernel writes the sums
+    // fp32: only the two-plane kernel writes the BN-backward sums / adds the masked identity-branch gradient
+    if ((a.bnr_partials || a.res_dz) && !conv_ws_planes_eligible(a)) return DML_EUNSUPPORTED;
     return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
 }
 

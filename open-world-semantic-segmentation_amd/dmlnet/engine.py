@@ -895,9 +895,16 @@ class Plan:
             dres = self.grad_of(ud.z)
             self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
             ud.z.grad_init = True
-        elif (self.fuse_res_grad and self.dtype == torch.bfloat16 and not xb.root.grad_init and xb is xb.root
+        elif (self.fuse_res_grad and not xb.root.grad_init and xb is xb.root
               and u3.relu and u3.mask is not None and u3.drop is None and xb.C % 8 == 0 and xb.C > 32
-              and dz.ld == xb.C and self.conv_geom(u1.conv, xb)[:3] == (1, 1, 1)):
+              and dz.ld == xb.C and self.conv_geom(u1.conv, xb)[:3] == (1, 1, 1)
+              and (self.dtype == torch.bfloat16
+                   # f16x2 (conv1's data gradient on the two-plane kernel takes res_* too): OFF unless DML_FUSE_RES_GRAD=2 -- the
+                   # persistent kernel's consumers read the extra operand at 7-10 B/clk/CU with the matrix cores idle, the BatchNorm
+                   # apply kernel writes the masked copy at 5.7 TB/s beside the weight gradients: 183.5 images/s without, 179.0 with
+                   or (os.environ.get("DML_FUSE_RES_GRAD") == "2" and self.h2_direct_on
+                       and self.h2_ok(u1.conv.out_channels, xb.C, 1) and xb.C % 64 == 0
+                       and self.planes_fit(u1.y.M, u1.conv.out_channels)))):
             # The masked output gradient is this block's contribution to d(xb) through the identity branch.  Instead
             # of having the BN-backward apply write that copy (75 MB per layer3 block) for conv1's data gradient to
             # accumulate onto, conv1's data gradient reads dz and the mask itself (DmlConvDesc.res_*).

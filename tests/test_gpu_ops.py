@@ -1426,7 +1426,7 @@ def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
         assert a_ <= max(4.0 * b_, 2e-6), errs
 
 
-@pytest.mark.parametrize("accum,relu", [(0, 1), (1, 1), (1, 0)])
+@pytest.mark.parametrize("accum,relu", [(0, 1), (1, 1), (1, 0), (2, 1)])
 def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
     """DmlConvDesc.bnr_* on fp32 tensors (the two-plane kernel's row epilogue): the data gradient writes the BN-backward sums of
     the tensor it stores per 48 rows -- what dml_bn_bwd_reduce computes from that tensor -- and raises max |g| in bnr_gmax; a
@@ -1443,7 +1443,10 @@ def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
     G = (M + 47) // 48
     part = torch.full((G * Cin * 2,), 7.0, device="cuda")
     gmax = torch.zeros(1024, device="cuda")
-    d = make_desc(lib, gyd, wt, dx, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, 1, 1, 0, mode=1, accum=accum)
+    d = make_desc(lib, gyd, wt, dx, B, Hh, Ww, Cout, Hh, Ww, Cin, k, 1, 1, 1, 0, mode=1, accum=1 if accum == 1 else 0)
+    rbits = torch.randint(0, 16, (M * Cin // 4,), device="cuda", dtype=torch.uint8)
+    if accum == 2:      # DmlConvDesc.res_*: the identity branch's gradient (dx0 under its own ReLU mask) added in the epilogue
+        d.res_dz, d.res_mask, d.res_ld = dx0.data_ptr(), rbits.data_ptr(), Cin
     ap, aw = h2_planes(lib, gyd.view(-1, Cout), 0)
     wp, ww = h2_planes(lib, wt.view(Cin, -1), 1)
     d.f32_split = 2
@@ -1456,7 +1459,12 @@ def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
     torch.cuda.synchronize()
     # the stored tensor itself: conv (+ the earlier value)
     ref = torch.nn.functional.conv_transpose2d(gyd.permute(0, 3, 1, 2).double(), wt.permute(3, 0, 1, 2).double(), padding=1)
-    ref = ref.permute(0, 2, 3, 1) + (dx0.double() if accum else 0.0)
+    ref = ref.permute(0, 2, 3, 1)
+    if accum == 1:
+        ref = ref + dx0.double()
+    elif accum == 2:
+        rmk = ((rbits.view(M, Cin // 4, 1) >> torch.arange(4, device="cuda").view(1, 1, 4)) & 1).reshape(B, Hh, Ww, Cin).double()
+        ref = ref + dx0.double() * rmk
     assert (dx.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     g = dx.view(M, Cin).double()
     if relu:
