@@ -331,6 +331,17 @@ int dml_h2_bound_bn(const float* gamma, const float* beta, int N, int64_t count,
                     float* work, void* stream);
 int dml_h2_bound_bn_bwd(const float* coef, const float* save_invstd, int N, int64_t count, const float* g_amax,
                         float* work, void* stream);
+/* dml_h2_bound_bn for `count` residual-free BatchNorms in one launch (`table_device`: DEVICE array; root_count = sqrt(elements per
+ * channel) * 1.0001, as the single call computes it). */
+typedef struct DmlH2BoundDesc {
+    const float* gamma;
+    const float* beta;
+    float* work;
+    int32_t N;
+    float root_count, mult;
+    int32_t reserved;
+} DmlH2BoundDesc;
+int dml_h2_bound_bn_table(const DmlH2BoundDesc* table_device, int count, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling (network/backbone/resnet.py:143; network/utils.py:320,326-329).

@@ -900,6 +900,40 @@ __global__ __launch_bounds__(256) void h2_bound_kernel(const float* __restrict__
 }
 }  // namespace
 
+// every residual-free BatchNorm of a plan in one launch (their bounds depend on gamma / beta / count only): one workgroup per entry
+namespace {
+__global__ __launch_bounds__(256) void h2_bound_table_kernel(const DmlH2BoundDesc* __restrict__ table) {
+    const DmlH2BoundDesc d = table[blockIdx.x];
+    __shared__ float sh[4];
+    float b = 0.f;
+    for (int n = threadIdx.x; n < d.N; n += 256)
+        b = fmaxf(b, fabsf(d.gamma ? d.gamma[n] : 1.f) * d.root_count + fabsf(d.beta ? d.beta[n] : 0.f));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    b = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3])) * d.mult * 1.0009765625f;
+    const uint32_t m = __float_as_uint(b);
+    float s = 1.0f;
+    if (m != 0) {
+        int se = 14 - ((int)(m >> 23) - 127);
+        se = se > 127 ? 127 : (se < -126 ? -126 : se);
+        s = __uint_as_float((uint32_t)(se + 127) << 23);
+        if (m >= 0x7f800000u) s = 1.0f;
+    }
+    d.work[1024] = 1.0f / s;
+}
+}  // namespace
+
+extern "C" int dml_h2_bound_bn_table(const DmlH2BoundDesc* table_device, int count, void* stream) {
+    if (count == 0) return 0;
+    if (!table_device || count < 0) return DML_EINVAL;
+    hipLaunchKernelGGL(h2_bound_table_kernel, dim3(count), dim3(256), 0, static_cast<hipStream_t>(stream), table_device);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dml_h2_bound_bn(const float* gamma, const float* beta, int N, int64_t count, float mult, const float* res_amax,
                                float* work, void* stream) {
     if (!work || N <= 0 || count <= 0 || !(mult > 0.f)) return DML_EINVAL;

@@ -109,6 +109,7 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_h2_split),
     DML_ENTRY(dml_h2_bound_bn),
     DML_ENTRY(dml_h2_bound_bn_bwd),
+    DML_ENTRY(dml_h2_bound_bn_table),
 };
 constexpr int kNumEntries = (int)(sizeof(kEntries) / sizeof(kEntries[0]));
 

@@ -84,6 +84,12 @@ class H2Desc(C.Structure):
                 ("C", C.c_int32), ("ld", C.c_int32), ("ldp", C.c_int32), ("layout", C.c_int32)]
 
 
+class H2BoundDesc(C.Structure):
+    """DmlH2BoundDesc: one BatchNorm of a dml_h2_bound_bn_table launch"""
+    _fields_ = [("gamma", c_p), ("beta", c_p), ("work", c_p), ("N", C.c_int32), ("root_count", C.c_float), ("mult", C.c_float),
+                ("reserved", C.c_int32)]
+
+
 class AugSample(C.Structure):
     _fields_ = [("i", C.c_int32), ("j", C.c_int32), ("flip", C.c_int32), ("n_ops", C.c_int32),
                 ("op", C.c_int32 * 3), ("factor", C.c_float * 3)]
@@ -119,6 +125,7 @@ _PROTOS = {
     "dml_bn_bwd_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_f,
                                c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
     "dml_h2_bound_bn": (c_i, [c_p, c_p, c_i, c_i64, c_f, c_p, c_p, c_p]),
+    "dml_h2_bound_bn_table": (c_i, [c_p, c_i, c_p]),
     "dml_h2_bound_bn_bwd": (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p]),
     "dml_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -20,6 +20,7 @@ import struct
 import weakref
 from typing import List, Optional
 
+import numpy as np
 import torch
 import torch.distributed as dist
 import torch.nn as nn
@@ -768,8 +769,12 @@ class Plan:
         pl = (None, 0, 0, None)
         if direct:
             planes, work = u.z.h2
-            self.call(self.fwd, lib.dml_h2_bound_bn, g_ptr, b_ptr, N, M * self.world, 1.0,
-                      res.amax.data_ptr() if res is not None else None, work.data_ptr())
+            if res is None and self.h2_bound_args is not None:
+                self.h2_bound_tab.append(_lib.H2BoundDesc(g_ptr, b_ptr, work.data_ptr(), N,
+                                                          float(np.float32(np.sqrt(np.float32(M * self.world))) * np.float32(1.0001)), 1.0, 0))
+            else:
+                self.call(self.fwd, lib.dml_h2_bound_bn, g_ptr, b_ptr, N, M * self.world, 1.0,
+                          res.amax.data_ptr() if res is not None else None, work.data_ptr())
             pl = (planes.data_ptr(), M * N, N, work.data_ptr() + 4096)
         only = direct and planes_only
         u.apply_args = self.call(self.fwd, lib.dml_bn_apply, u.y.ptr, res.ptr if res is not None else None,
@@ -934,9 +939,13 @@ class Plan:
                 n_fixed += 0 if mod.training else 1
 
         self.bn_eval = []
+        self.h2_bound_tab, self.h2_bound_args = [], None
         if self.h2_slots is not None and self.training:
             # every amax word of the step starts from zero (Plan.amax_of; the backward's words are raised after the forward)
             self.call(self.fwd, lib.dml_fill_f32, self.h2_slots.data_ptr(), self.h2_slots.numel(), 0.0)
+            # the plane scales of every residual-free BatchNorm output (they depend on gamma / beta / count only): one launch,
+            # table filled in at the end of the forward build
+            self.h2_bound_args = self.call(self.fwd, lib.dml_h2_bound_bn_table, 0, 0)
         if n_fixed:
             self.bn_eval_args = self.call(self.fwd, lib.dml_bn_eval_coeffs_table, 0, 0)      # filled in below
         # input packing NCHW fp32 -> NHWC (8 ch)
@@ -966,6 +975,10 @@ class Plan:
 
         # heads: one for the DMLNet model, several (shared backbone) for the self-distillation model (utils.py:120-193)
         self.heads = [self._head_fwd(h, low, out) for h in head_modules]
+        if self.h2_bound_args is not None and self.h2_bound_tab:
+            arr = (_lib.H2BoundDesc * len(self.h2_bound_tab))(*self.h2_bound_tab)
+            self.h2_bound_table = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(self.device)
+            self.h2_bound_args[0], self.h2_bound_args[1] = self.h2_bound_table.data_ptr(), len(self.h2_bound_tab)
         self.K, self.Kp = self.heads[0].K, self.heads[0].Kp
         self.nbt_inc = None
         if self.training and n_fixed:

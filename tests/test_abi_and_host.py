@@ -167,12 +167,15 @@ def test_committed_bench_line_carries_the_contract_fields():
     files = [f for f in glob.glob(os.path.join(H.ROOT, "profiles", "r*_bench_v*.json")) if re.search(r"r\d+_bench_v\d+\.json$", f)]
     newest = max(files, key=lambda f: tuple(int(x) for x in re.findall(r"r(\d+)_bench_v(\d+)", f)[0]))
     d = json.load(open(newest))
-    assert os.path.basename(newest).startswith("r03"), newest
+    assert os.path.basename(newest).startswith("r04"), newest
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
-              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "fp32_companion", "hbm_kernel"):
+              "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "bf16_companion", "fp32_exact_companion",
+              "hbm_kernel"):
         assert k in d, k
     assert d["unit"] == "images/sec" and d["n_gpus"] == 1 and d["higher_is_better"] is True and d["vs_baseline"] is None
     assert d["config"]["workload"] and "model" not in d["config"] and d["config"]["rccl_ranks"] == 1
+    # the headline is the fp32-accurate step: fp32 tensors, products of two fp16 planes (MFMA roof 2.5 PF / 3)
+    assert d["dtype"] == "f32" and "fp16" in d["config"]["arithmetic"] and abs(d["roofline"]["peak"] - 2500.0 / 3) < 1e-6
     assert abs(d["value"] - d["config"]["global_batch"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-9
@@ -184,11 +187,14 @@ def test_committed_bench_line_carries_the_contract_fields():
     assert all(row[8] is None or row[8] > 0.9 for row in r["classes"][:12])          # PMC bytes never below the algorithmic ones
     assert abs(sum(row[3] for row in r["classes"]) - r["conv_ms_per_step"]) < 0.02 * r["conv_ms_per_step"]
     assert all(row[4] in ("mfma", "hbm") and 0 < row[6] <= 1.0 for row in r["classes"])
-    assert len(json.dumps(d)) < 8000          # the driver keeps the tail of stdout: the line stays a few KB
-    f = d["fp32_companion"]
+    assert len(json.dumps(d)) < 9000          # the driver keeps the tail of stdout: the line stays a few KB
+    f = d["fp32_exact_companion"]
     assert f["dtype"] == "f32" and f["value"] > 0 and abs(f["roofline"]["frac"] - f["roofline"]["achieved"] / 157.3) < 1e-6
-    assert f["steps"] == d["steps"] and f["warmup"] == d["warmup"]          # first-class: the headline's K and W
+    assert f["steps"] >= 10 and f["warmup"] >= 2          # (the fp32-accurate mode is the headline now; the exact one rides along)
     assert f["roofline"]["traffic"] is None or f["roofline"]["traffic"] > 0.5 * f["roofline"]["algorithmic_bytes"]
+    assert f["three_term_split"]["dtype"] == "f32x3" and f["value"] < f["three_term_split"]["value"] < d["value"]
+    b = d["bf16_companion"]
+    assert b["dtype"] == "bf16" and b["value"] > d["value"] and abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / 2500.0) < 1e-6
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and str(c["cores"]) in c["by_threads"]
     h = d["hbm_kernel"]
