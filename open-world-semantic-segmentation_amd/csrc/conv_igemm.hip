@@ -1452,6 +1452,151 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
     }
 }
 
+// The same through 2 KB of LDS that belong to the wave alone (the 144 x 256 configuration leaves 10 KB beside its ring): chunks of
+// 16 rows x 32 channels, a store instruction = 8 rows x 128 contiguous bytes (whole cache lines).  No consumer barrier and no held-back
+// ring slot: with the staging area inside the ring (conv_epilogue_rows) the loaders prefetch one stage less across the tile boundary
+// and the consumers wait for each other -- 8-10 % of a launch with four tiles of eight K steps per CU (profiles/r04_h2_ablations.txt).
+// DS operations of one wave execute in order: chunk q + 1 is written right behind the reads of chunk q, whose data the stores then
+// wait for with the newer writes still outstanding.
+template <int NT, int MODE>
+__device__ __forceinline__ void conv_epilogue_rows8(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
+                                                    const int lane, char* stage) {
+    static_assert(NT == 4, "64-channel wave tile");
+    const int lr = lane & 15, lq = lane >> 4;
+    if (MODE == 0 && a.stats != nullptr) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
+    const int rr = lane >> 3, cc = lane & 7;                     // row side: row within 8, 16-byte chunk within the 128-byte half row
+    const bool resm = MODE == 1 && a.res_dz != nullptr;
+    const bool has_old = a.accum != 0 || resm;
+    const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
+    float* const yb = static_cast<float*>(a.y);
+    // chunk q = (fragment j = q >> 1, channel half = q & 1): tiles i = 2 half, 2 half + 1 of fragment j
+    auto wr = [&](auto qc) {
+        constexpr int q = decltype(qc)::value, j = q >> 1, hf = q & 1;
+#pragma unroll
+        for (int ii = 0; ii < 2; ++ii)
+            *reinterpret_cast<f32x4*>(stage + lr * 128 + (((lq * 2 + ii) ^ (lr & 7)) << 4)) = acc[2 * hf + ii][j];
+    };
+    auto rd = [&](float4 (&o)[2]) {
+        asm volatile("" ::: "memory");
+#pragma unroll
+        for (int k = 0; k < 2; ++k) {
+            const int r = k * 8 + rr;
+            o[k] = *reinterpret_cast<const float4*>(stage + r * 128 + ((cc ^ (r & 7)) << 4));
+        }
+        asm volatile("" ::: "memory");
+    };
+    auto body = [&](auto ho, auto bn) {
+        constexpr bool HO = decltype(ho)::value, BNR = decltype(bn)::value;
+        float4 o[2][2], old[2][2], yv[2][2];
+        uint32_t mb[2][2];
+        float4 r1[2], r2[2], mu[2], is[2];
+        uint32_t gmx = 0;
+#pragma unroll
+        for (int hf = 0; hf < 2; ++hf) {
+            r1[hf] = make_float4(0.f, 0.f, 0.f, 0.f);
+            r2[hf] = r1[hf]; mu[hf] = r1[hf]; is[hf] = r1[hf];
+            const int c0 = nw0 + hf * 32 + cc * 4;
+            if (BNR && c0 < a.N) {
+                mu[hf] = *reinterpret_cast<const float4*>(a.bnr_mean + c0);
+                is[hf] = *reinterpret_cast<const float4*>(a.bnr_invstd + c0);
+            }
+        }
+        auto load_ops = [&](const int q) {
+            const int j = q >> 1, hf = q & 1, c0 = nw0 + hf * 32 + cc * 4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int m = mw0 + j * 16 + k * 8 + rr;
+                old[q & 1][k] = make_float4(0.f, 0.f, 0.f, 0.f);
+                yv[q & 1][k] = old[q & 1][k];
+                mb[q & 1][k] = 0xfu;
+                if (m < a.M && c0 < a.N) {
+                    if (HO) {
+                        if (resm) {
+                            float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.res_dz) + (int64_t)m * a.res_ld + c0);
+                            const uint32_t rb = a.res_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
+                            t.x = (rb & 1u) ? t.x : 0.f; t.y = (rb & 2u) ? t.y : 0.f; t.z = (rb & 4u) ? t.z : 0.f; t.w = (rb & 8u) ? t.w : 0.f;
+                            old[q & 1][k] = t;
+                        } else {
+                            old[q & 1][k] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
+                        }
+                    }
+                    if (BNR) {
+                        yv[q & 1][k] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + (int64_t)m * a.bnr_ldy + c0);
+                        if (a.bnr_relu) mb[q & 1][k] = a.bnr_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
+                    }
+                }
+            }
+        };
+        auto chunk = [&](auto qc) {
+            constexpr int q = decltype(qc)::value, j = q >> 1, hf = q & 1;
+            if constexpr (q + 1 < 6) {
+                wr(std::integral_constant<int, (q + 1 < 6 ? q + 1 : 0)>{});      // behind the reads of chunk q (in-order DS)
+                if (HO || BNR) load_ops(q + 1);
+            }
+            const int c0 = nw0 + hf * 32 + cc * 4;
+#pragma unroll
+            for (int k = 0; k < 2; ++k) {
+                const int m = mw0 + j * 16 + k * 8 + rr;
+                if (m >= a.M || c0 >= a.N) continue;
+                float4 v = o[q & 1][k];
+                if (HO) { v.x += old[q & 1][k].x; v.y += old[q & 1][k].y; v.z += old[q & 1][k].z; v.w += old[q & 1][k].w; }
+                st16f(yb + (int64_t)m * a.ldy + c0, v.x, v.y, v.z, v.w, (a.nt_out & 1) != 0);
+                if (BNR) {
+                    const uint32_t bits = mb[q & 1][k];
+                    const float4 y4 = yv[q & 1][k];
+                    const float g0 = (bits & 1u) ? v.x : 0.f, g1 = (bits & 2u) ? v.y : 0.f, g2 = (bits & 4u) ? v.z : 0.f,
+                                g3 = (bits & 8u) ? v.w : 0.f;
+                    r1[hf].x += g0; r1[hf].y += g1; r1[hf].z += g2; r1[hf].w += g3;
+                    r2[hf].x += g0 * (y4.x - mu[hf].x) * is[hf].x; r2[hf].y += g1 * (y4.y - mu[hf].y) * is[hf].y;
+                    r2[hf].z += g2 * (y4.z - mu[hf].z) * is[hf].z; r2[hf].w += g3 * (y4.w - mu[hf].w) * is[hf].w;
+                    gmx = max(max(gmx, __float_as_uint(g0) & 0x7fffffffu), max(__float_as_uint(g1) & 0x7fffffffu,
+                              max(__float_as_uint(g2) & 0x7fffffffu, __float_as_uint(g3) & 0x7fffffffu)));
+                }
+            }
+            if constexpr (q + 1 < 6) rd(o[(q + 1) & 1]);
+        };
+        wr(std::integral_constant<int, 0>{});
+        if (HO || BNR) load_ops(0);
+        rd(o[0]);
+        chunk(std::integral_constant<int, 0>{});
+        chunk(std::integral_constant<int, 1>{});
+        chunk(std::integral_constant<int, 2>{});
+        chunk(std::integral_constant<int, 3>{});
+        chunk(std::integral_constant<int, 4>{});
+        chunk(std::integral_constant<int, 5>{});
+        if (BNR) {
+            // the eight row groups (lane >> 3) hold the same channels: fold, then lanes 0 .. 7 write their channels' pairs
+#pragma unroll
+            for (int hf = 0; hf < 2; ++hf) {
+                float v[8] = {r1[hf].x, r2[hf].x, r1[hf].y, r2[hf].y, r1[hf].z, r2[hf].z, r1[hf].w, r2[hf].w};
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    v[e] += __shfl_xor(v[e], 8, 64);
+                    v[e] += __shfl_xor(v[e], 16, 64);
+                    v[e] += __shfl_xor(v[e], 32, 64);
+                }
+                const int c0 = nw0 + hf * 32 + cc * 4;
+                if (lane < 8 && mw0 < a.M && c0 < a.N) {
+                    float* pp = a.bnr_partials + ((int64_t)(mw0 / WS_STAT_ROWS_C) * a.N + c0) * 2;
+                    st16f(pp, v[0], v[1], v[2], v[3], false);
+                    st16f(pp + 4, v[4], v[5], v[6], v[7], false);
+                }
+            }
+            if (a.bnr_gmax != nullptr) {
+#pragma unroll
+                for (int o_ = 32; o_ > 0; o_ >>= 1) gmx = max(gmx, (uint32_t)__shfl_xor((int)gmx, o_, 64));
+                if (lane == 0 && gmx != 0)
+                    atomicMax(reinterpret_cast<uint32_t*>(a.bnr_gmax) + ((blockIdx.x * 16u + (uint32_t)(mw0 / WS_STAT_ROWS_C) + (uint32_t)(nw0 >> 6)) & 1023u), gmx);
+            }
+        }
+    };
+    // (launches with an accumulate / residual operand or the fused BN-backward sums stay on conv_epilogue_rows: eight rows of operand
+    // loads in flight per lane there against four here, and those epilogues are bound by exactly that -- measured: the data gradients
+    // of the step +2 % with this function, the forward launches -11 %.  The variants are kept compiled out of the kernels.)
+    (void)has_old; (void)bnr;
+    body(std::false_type{}, std::false_type{});
+}
+
 typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
 constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
 constexpr int WS_STAT_ROWS = 48;               // rows per statistics group of this kernel
@@ -1624,7 +1769,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     constexpr int NCW = 4, NT = 4, MT = WS_MT, NST = PL == 1 ? WS_NST : 3;
     constexpr int BM = 16 * MT * MW, BN = 64 * NW;
     constexpr int SB = PL * (BM + BN) * BK * 2;
-    __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64];
+    // two planes, 144 x 256: 2 KB of private staging per consumer wave behind the flags (conv_epilogue_rows8); the 288 x 128
+    // configuration has no room for it and stages in the slot of the tile's last K stage (conv_epilogue_rows)
+    // (forward only: nearly every data gradient of a plan carries epilogue operands -- accumulate, fused BN-backward sums -- whose
+    // loads want the deeper row groups of conv_epilogue_rows, and both epilogues in one kernel spill 300 bytes per lane)
+    constexpr bool PRIV_STAGE = PL == 2 && MW == 1 && MODE == 0;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64 + (PRIV_STAGE ? NCW * 2048 : 0)];
     uint32_t* const ready = reinterpret_cast<uint32_t*>(smem + NST * SB);          // [NLD] stages landed, per loader
     uint32_t* const consumed = ready + 4;                                          // [4] stages whose reads were issued
 
@@ -1649,6 +1799,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     // ---------------------------------------------------------------------- consumer
     const int wm = wave / NW, wn = wave % NW;
     const int lr = lane & 15, lq = lane >> 4;
+    constexpr bool priv = PRIV_STAGE;
     uint32_t g = 0, rflag = 0, tiles_done = 0;
     uint32_t* const edone = consumed + 4;                  // [4] tiles whose last fragment reads were issued, per consumer wave
     auto read_ready = [&]() -> uint32_t {
@@ -1764,7 +1915,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                         asm volatile("" ::: "memory");
                         // every read of stage g has been issued (the tile's LAST stage is announced after the epilogue, which
                         // stages the output rows in its slot)
-                        if (has_next) ws_st(consumed + wave, g + 1);
+                        if (has_next || priv) ws_st(consumed + wave, g + 1);
                         ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
                         al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
                     }
@@ -1818,7 +1969,8 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         // (three explicit copies: hipcc does not unroll a loop around the inlined epilogue, and a run-time index into acc
         // sends all 36 accumulator fragments through scratch memory -- 37 MB written and read back per launch, +25 us)
         char* rows_stage = nullptr;
-        if constexpr (PL == 2) {
+        if (priv) rows_stage = smem + NST * SB + 64 + wave * 2048;
+        if (PL == 2 && !priv) {
             // the slot of the tile's last K step becomes the staging area of conv_epilogue_rows (12 KB per wave): every consumer
             // wave must have issued its last fragment reads first
             ++tiles_done;
@@ -1845,6 +1997,8 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             if constexpr (PL == 1) conv_epilogue<bf16_t, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);
             else if (MODE == 0 && (a.bias != nullptr || a.post_scale != nullptr)) {
                 conv_epilogue<float, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);      // (inference epilogue, bias: scattered stores)
+            } else if (priv) {
+                if constexpr (PRIV_STAGE) conv_epilogue_rows8<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
             } else {
                 conv_epilogue_rows<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // its reads of the staging area, before the next group's writes
@@ -1860,7 +2014,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                 }
         }
 #undef ACC
-        if constexpr (PL == 2) {
+        if (PL == 2 && !priv) {
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             ws_st(consumed + wave, g);                  // the tile's last stage: its slot is free again
         }
