@@ -136,7 +136,12 @@ def _statistical_equivalence(shape, seeds, tag):
                             r_emu.max() - r_emu.min()))
         # per seed: nothing mis-wired or mis-scaled (a wrong gradient is O(1) on these), running statistics equivalent
         assert c_hip.max() <= 2.0 * c_emu.max() + 2e-2, names[int(np.argmax(c_hip))]
-        assert 0.6 <= r_hip.min() and r_hip.max() <= 1.5, (r_hip.min(), r_hip.max())
+        # norm ratio of every tensor, per seed, relative to what the emulation shows on the same seed (measured on eight seeds:
+        # spread hip / emulation <= 1.5, largest deviation from 1 <= 1.3x the emulation's + 0.1): a gradient mis-scaled by 1.4x on a
+        # single tensor deviates by 0.4 and fails this on most seeds (bars 0.2-0.55)
+        dev_hip, dev_emu = max(1 - r_hip.min(), r_hip.max() - 1), max(1 - r_emu.min(), r_emu.max() - 1)
+        assert r_hip.max() - r_hip.min() <= 2.0 * (r_emu.max() - r_emu.min()) + 0.05, (r_hip.min(), r_hip.max(), r_emu.min(), r_emu.max())
+        assert dev_hip <= 2.0 * dev_emu + 0.05, (dev_hip, dev_emu)
         bufs, obufs = dict(m.named_buffers()), dict(oemu.named_buffers())
         for k in ("backbone.bn1.running_var", "backbone.layer3.11.bn2.running_mean", "backbone.layer4.2.bn3.running_var",
                   "classifier.classifier.1.running_var"):
