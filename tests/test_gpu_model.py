@@ -160,10 +160,12 @@ def test_g8_sgd_polylr_trajectory(products):
     relclose(sd["backbone.bn1.running_mean"], T(t["rm_stem"]), 2e-3 * wide, "stem running mean after 6 steps")
 
 
-def test_g5b_eval_forward_config1():
-    """BASELINE config #1 shape (1x3x256x256 eval forward) on the HIP path."""
+@pytest.mark.parametrize("products", ["exact", "f16x2"])
+def test_g5b_eval_forward_config1(products):
+    """BASELINE config #1 shape (1x3x256x256 eval forward) on the HIP path; also in the two-plane mode, whose eval plan splits every
+    activation with dml_h2_split (running-statistics BatchNorm has no bound) and runs BN + residual + ReLU in the conv epilogues."""
     g = H.load_golden("g5b_full_eval")
-    m = build(train=False)
+    m = build(train=False, fp32_products=products)
     flat, off = T(g["bn_stats"]), 0
     sd = m.state_dict()
     for k, v in sd.items():
