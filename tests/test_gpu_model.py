@@ -549,25 +549,26 @@ def test_a_dropped_model_frees_its_plans():
     assert torch.cuda.memory_allocated() - base < 50e6, torch.cuda.memory_allocated() - base
 
 
-def _multihead(dtype=torch.float32):
+def _multihead(dtype=torch.float32, fp32_products=None):
     import network
     m = network.deeplabv3plus_embedding_self_distillation_resnet101(num_classes=16, output_stride=16,
                                                                     pretrained_backbone=False)
     m.load_state_dict(H.synth_state_dict(H.shapes_of(m), seed=12))
     m.cuda()
-    m.set_compute_dtype(dtype)
+    m.set_compute_dtype(dtype, fp32_products=fp32_products)
     m.train()
     m.classifier.aspp.project[3].eval()
     m.classifier_1.aspp.project[3].eval()
     return m
 
 
-def test_g12_self_distillation_model_matches_reference():
+@pytest.mark.parametrize("products", [None, "f16x2"])
+def test_g12_self_distillation_model_matches_reference(products):
     """network.deeplabv3plus_embedding_self_distillation_resnet101: lists out, loss on the last head only (the base
     head's backward segment is skipped), against the fixture minted from the reference model."""
     import utils
     g = H.load_golden("g12_multihead")
-    m = _multihead()
+    m = _multihead(fp32_products=products)
     assert len(m.state_dict()) == int(g["n_keys"]) and list(m.state_dict().keys())[-4:] == [str(k) for k in g["keys"]]
     img = H.synth_tensor(12, "g12.img", (2, 3, 64, 64)).cuda()
     lab = H.synth_labels(12, "g12.lab", (2, 64, 64), 17, 255, ignore_rows=3).cuda()
