@@ -47,15 +47,17 @@ def test_every_unit_locally_exact_through_the_wave_specialised_kernel():
     assert "3 passed" in r.stdout
 
 
-def test_sync_batchnorm_two_ranks_match_one_process():
+@pytest.mark.parametrize("products", ["exact", "f16x2"])
+def test_sync_batchnorm_two_ranks_match_one_process(products):
     """set_sync_batchnorm(True): two ranks (gloo, sharing this GPU) with half a batch each reproduce the single-process
-    whole-batch logits, loss, running statistics and reduced gradients (tools/check_syncbn.py)."""
+    whole-batch logits, loss, running statistics and reduced gradients (tools/check_syncbn.py) -- also in the two-plane mode,
+    whose plane scales come from bounds over the GLOBAL element count (dml_h2_bound_bn with count = M x ranks)."""
     import socket
     s = socket.socket()
     s.bind(("127.0.0.1", 0))
     port = s.getsockname()[1]
     s.close()
-    env = dict(os.environ, DML_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, DML_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", DML_F32_PRODUCTS=products)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(port), os.path.join(H.ROOT, "tools", "check_syncbn.py")], env=env,
                        capture_output=True, text=True, cwd=H.ROOT, timeout=900)
@@ -72,11 +74,12 @@ def _free_port():
     return port
 
 
-def test_data_parallel_reducer_two_ranks():
+@pytest.mark.parametrize("products", ["exact", "f16x2"])
+def test_data_parallel_reducer_two_ranks(products):
     """The product's N > 1 path (GradReducer.run_backward on the real ParamStore: reverse-order buckets launched from
     Plan.param_last_op on the comm stream while the backward plan and the weight-gradient side stream keep running),
     two gloo ranks sharing this GPU with UNEVEN shards: tools/check_ddp.py."""
-    env = dict(os.environ, DML_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    env = dict(os.environ, DML_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0", DML_F32_PRODUCTS=products)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr",
                         "127.0.0.1", "--master-port", str(_free_port()), os.path.join(H.ROOT, "tools", "check_ddp.py")],
                        env=env, capture_output=True, text=True, cwd=H.ROOT, timeout=1200)
