@@ -138,7 +138,7 @@ typedef struct DmlConvDesc {
      * f32_split == 1.  x_planes / w_planes: [2][...] fp16, the hi plane then the lo plane `*_plane_stride` elements further, the
      * activation planes with the geometry (pitch ldx) of `x`, the weight planes tile-major ([N / 64][K / 32][64][32] per plane);
      * x_unscale / w_unscale: device scalars 1 / s and 1 / t (dml_h2_split).  Shapes the planes kernel does not take (C % 32,
-     * N % 128, more than 32 taps) run the three-term split on x / w, which must therefore be valid as well. */
+     * N % 64, more than 32 taps, misaligned y) run the three-term split on x / w, which must therefore be valid as well. */
     const void* x_planes;
     const void* w_planes;
     const float* x_unscale;

@@ -455,7 +455,7 @@ class Plan:
     # ---- fp32 plans with fp32_products = "f16x2": fp16 hi / lo planes of a conv operand (DmlConvDesc.x_planes)
     def h2_ok(self, C, N, taps):
         """shapes the planes kernel takes (conv_ws_planes_eligible); the others run the three-term split on the fp32 tensors"""
-        return self.f32_split == 2 and self.dtype == torch.float32 and C % 32 == 0 and N % 64 == 0 and N >= 128 and taps <= 32
+        return self.f32_split == 2 and self.dtype == torch.float32 and C % 32 == 0 and N % 64 == 0 and taps <= 32
 
     @staticmethod
     def planes_fit(M, ld):

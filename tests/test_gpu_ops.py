@@ -1350,7 +1350,8 @@ def test_h2_split_table_equals_the_single_tensor_calls(lib):
 
 
 H2_CASES = [("h2_1x1", 2, 24, 20, 64, 128, 1, 1, 1), ("h2_3x3", 2, 19, 23, 64, 256, 3, 1, 1), ("h2_3x3_d2", 2, 16, 16, 128, 256, 3, 1, 2),
-            ("h2_3x3_s2", 2, 22, 18, 128, 128, 3, 2, 1), ("h2_rows", 3, 40, 40, 256, 256, 3, 1, 1), ("h2_1x1_n384", 2, 13, 29, 96, 384, 1, 1, 1)]
+            ("h2_3x3_s2", 2, 22, 18, 128, 128, 3, 2, 1), ("h2_rows", 3, 40, 40, 256, 256, 3, 1, 1), ("h2_1x1_n384", 2, 13, 29, 96, 384, 1, 1, 1),
+            ("h2_3x3_n64", 2, 21, 17, 64, 64, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("case", H2_CASES, ids=lambda c: c[0])
@@ -1380,7 +1381,7 @@ def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
         keep = []
         if split:
             for desc, act, wmat, rows_w in ((d, xd, wd, Cout), (dd, gyd, wtd, Cin)):
-                if rows_w % 128:                     # not a shape of the planes kernel: the three-term split takes it
+                if rows_w % 64:                      # not a shape of the planes kernel: the three-term split takes it
                     desc.f32_split = 1
                     continue
                 ap, aw = h2_planes(lib, act.view(-1, act.shape[-1]), 0)
@@ -1390,7 +1391,7 @@ def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
                 desc.x_planes, desc.x_unscale, desc.x_plane_stride = ap.data_ptr(), aw.data_ptr() + 4096, ap.shape[1]
                 desc.w_planes, desc.w_unscale, desc.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
         rows = lib.dml_conv_stat_rows(C.byref(d))
-        assert rows == (48 if (split and Cout % 128 == 0) else 64)
+        assert rows == (48 if (split and Cout % 64 == 0) else 64)      # (64 output channels: the 288 x 128 tile, half of it empty)
         stats = torch.zeros((M + rows - 1) // rows * Cout * 2, device="cuda")
         d.stats = stats.data_ptr()
         chk(lib.dml_conv_igemm(C.byref(d), st()))
