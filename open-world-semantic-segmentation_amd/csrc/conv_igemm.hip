@@ -1457,17 +1457,16 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
 // ring slot: with the staging area inside the ring (conv_epilogue_rows) the loaders prefetch one stage less across the tile boundary
 // and the consumers wait for each other -- 8-10 % of a launch with four tiles of eight K steps per CU (profiles/r04_h2_ablations.txt).
 // DS operations of one wave execute in order: chunk q + 1 is written right behind the reads of chunk q, whose data the stores then
-// wait for with the newer writes still outstanding.
+// wait for with the newer writes still outstanding.  Forward launches only: a version with the data gradients' epilogue operands
+// (accumulate, fused BN-backward sums) had four rows of operand loads in flight per lane against the eight of conv_epilogue_rows, and
+// those epilogues are bound by exactly that (+2 % on the step's data gradients); both versions in one kernel spill 300 bytes per lane.
 template <int NT, int MODE>
 __device__ __forceinline__ void conv_epilogue_rows8(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
                                                     const int lane, char* stage) {
-    static_assert(NT == 4, "64-channel wave tile");
+    static_assert(NT == 4 && MODE == 0, "64-channel wave tile, forward launches");
     const int lr = lane & 15, lq = lane >> 4;
-    if (MODE == 0 && a.stats != nullptr) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
+    if (a.stats != nullptr) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
     const int rr = lane >> 3, cc = lane & 7;                     // row side: row within 8, 16-byte chunk within the 128-byte half row
-    const bool resm = MODE == 1 && a.res_dz != nullptr;
-    const bool has_old = a.accum != 0 || resm;
-    const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
     float* const yb = static_cast<float*>(a.y);
     // chunk q = (fragment j = q >> 1, channel half = q & 1): tiles i = 2 half, 2 half + 1 of fragment j
     auto wr = [&](auto qc) {
@@ -1485,116 +1484,27 @@ __device__ __forceinline__ void conv_epilogue_rows8(f32x4 (&acc)[NT][3], const C
         }
         asm volatile("" ::: "memory");
     };
-    auto body = [&](auto ho, auto bn) {
-        constexpr bool HO = decltype(ho)::value, BNR = decltype(bn)::value;
-        float4 o[2][2], old[2][2], yv[2][2];
-        uint32_t mb[2][2];
-        float4 r1[2], r2[2], mu[2], is[2];
-        uint32_t gmx = 0;
+    float4 o[2][2];
+    auto chunk = [&](auto qc) {
+        constexpr int q = decltype(qc)::value, j = q >> 1, hf = q & 1;
+        if constexpr (q + 1 < 6) wr(std::integral_constant<int, (q + 1 < 6 ? q + 1 : 0)>{});      // behind the reads of chunk q (in-order DS)
+        const int c0 = nw0 + hf * 32 + cc * 4;
 #pragma unroll
-        for (int hf = 0; hf < 2; ++hf) {
-            r1[hf] = make_float4(0.f, 0.f, 0.f, 0.f);
-            r2[hf] = r1[hf]; mu[hf] = r1[hf]; is[hf] = r1[hf];
-            const int c0 = nw0 + hf * 32 + cc * 4;
-            if (BNR && c0 < a.N) {
-                mu[hf] = *reinterpret_cast<const float4*>(a.bnr_mean + c0);
-                is[hf] = *reinterpret_cast<const float4*>(a.bnr_invstd + c0);
-            }
+        for (int k = 0; k < 2; ++k) {
+            const int m = mw0 + j * 16 + k * 8 + rr;
+            if (m < a.M && c0 < a.N)
+                st16f(yb + (int64_t)m * a.ldy + c0, o[q & 1][k].x, o[q & 1][k].y, o[q & 1][k].z, o[q & 1][k].w, (a.nt_out & 1) != 0);
         }
-        auto load_ops = [&](const int q) {
-            const int j = q >> 1, hf = q & 1, c0 = nw0 + hf * 32 + cc * 4;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int m = mw0 + j * 16 + k * 8 + rr;
-                old[q & 1][k] = make_float4(0.f, 0.f, 0.f, 0.f);
-                yv[q & 1][k] = old[q & 1][k];
-                mb[q & 1][k] = 0xfu;
-                if (m < a.M && c0 < a.N) {
-                    if (HO) {
-                        if (resm) {
-                            float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.res_dz) + (int64_t)m * a.res_ld + c0);
-                            const uint32_t rb = a.res_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
-                            t.x = (rb & 1u) ? t.x : 0.f; t.y = (rb & 2u) ? t.y : 0.f; t.z = (rb & 4u) ? t.z : 0.f; t.w = (rb & 8u) ? t.w : 0.f;
-                            old[q & 1][k] = t;
-                        } else {
-                            old[q & 1][k] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
-                        }
-                    }
-                    if (BNR) {
-                        yv[q & 1][k] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + (int64_t)m * a.bnr_ldy + c0);
-                        if (a.bnr_relu) mb[q & 1][k] = a.bnr_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
-                    }
-                }
-            }
-        };
-        auto chunk = [&](auto qc) {
-            constexpr int q = decltype(qc)::value, j = q >> 1, hf = q & 1;
-            if constexpr (q + 1 < 6) {
-                wr(std::integral_constant<int, (q + 1 < 6 ? q + 1 : 0)>{});      // behind the reads of chunk q (in-order DS)
-                if (HO || BNR) load_ops(q + 1);
-            }
-            const int c0 = nw0 + hf * 32 + cc * 4;
-#pragma unroll
-            for (int k = 0; k < 2; ++k) {
-                const int m = mw0 + j * 16 + k * 8 + rr;
-                if (m >= a.M || c0 >= a.N) continue;
-                float4 v = o[q & 1][k];
-                if (HO) { v.x += old[q & 1][k].x; v.y += old[q & 1][k].y; v.z += old[q & 1][k].z; v.w += old[q & 1][k].w; }
-                st16f(yb + (int64_t)m * a.ldy + c0, v.x, v.y, v.z, v.w, (a.nt_out & 1) != 0);
-                if (BNR) {
-                    const uint32_t bits = mb[q & 1][k];
-                    const float4 y4 = yv[q & 1][k];
-                    const float g0 = (bits & 1u) ? v.x : 0.f, g1 = (bits & 2u) ? v.y : 0.f, g2 = (bits & 4u) ? v.z : 0.f,
-                                g3 = (bits & 8u) ? v.w : 0.f;
-                    r1[hf].x += g0; r1[hf].y += g1; r1[hf].z += g2; r1[hf].w += g3;
-                    r2[hf].x += g0 * (y4.x - mu[hf].x) * is[hf].x; r2[hf].y += g1 * (y4.y - mu[hf].y) * is[hf].y;
-                    r2[hf].z += g2 * (y4.z - mu[hf].z) * is[hf].z; r2[hf].w += g3 * (y4.w - mu[hf].w) * is[hf].w;
-                    gmx = max(max(gmx, __float_as_uint(g0) & 0x7fffffffu), max(__float_as_uint(g1) & 0x7fffffffu,
-                              max(__float_as_uint(g2) & 0x7fffffffu, __float_as_uint(g3) & 0x7fffffffu)));
-                }
-            }
-            if constexpr (q + 1 < 6) rd(o[(q + 1) & 1]);
-        };
-        wr(std::integral_constant<int, 0>{});
-        if (HO || BNR) load_ops(0);
-        rd(o[0]);
-        chunk(std::integral_constant<int, 0>{});
-        chunk(std::integral_constant<int, 1>{});
-        chunk(std::integral_constant<int, 2>{});
-        chunk(std::integral_constant<int, 3>{});
-        chunk(std::integral_constant<int, 4>{});
-        chunk(std::integral_constant<int, 5>{});
-        if (BNR) {
-            // the eight row groups (lane >> 3) hold the same channels: fold, then lanes 0 .. 7 write their channels' pairs
-#pragma unroll
-            for (int hf = 0; hf < 2; ++hf) {
-                float v[8] = {r1[hf].x, r2[hf].x, r1[hf].y, r2[hf].y, r1[hf].z, r2[hf].z, r1[hf].w, r2[hf].w};
-#pragma unroll
-                for (int e = 0; e < 8; ++e) {
-                    v[e] += __shfl_xor(v[e], 8, 64);
-                    v[e] += __shfl_xor(v[e], 16, 64);
-                    v[e] += __shfl_xor(v[e], 32, 64);
-                }
-                const int c0 = nw0 + hf * 32 + cc * 4;
-                if (lane < 8 && mw0 < a.M && c0 < a.N) {
-                    float* pp = a.bnr_partials + ((int64_t)(mw0 / WS_STAT_ROWS_C) * a.N + c0) * 2;
-                    st16f(pp, v[0], v[1], v[2], v[3], false);
-                    st16f(pp + 4, v[4], v[5], v[6], v[7], false);
-                }
-            }
-            if (a.bnr_gmax != nullptr) {
-#pragma unroll
-                for (int o_ = 32; o_ > 0; o_ >>= 1) gmx = max(gmx, (uint32_t)__shfl_xor((int)gmx, o_, 64));
-                if (lane == 0 && gmx != 0)
-                    atomicMax(reinterpret_cast<uint32_t*>(a.bnr_gmax) + ((blockIdx.x * 16u + (uint32_t)(mw0 / WS_STAT_ROWS_C) + (uint32_t)(nw0 >> 6)) & 1023u), gmx);
-            }
-        }
+        if constexpr (q + 1 < 6) rd(o[(q + 1) & 1]);
     };
-    // (launches with an accumulate / residual operand or the fused BN-backward sums stay on conv_epilogue_rows: eight rows of operand
-    // loads in flight per lane there against four here, and those epilogues are bound by exactly that -- measured: the data gradients
-    // of the step +2 % with this function, the forward launches -11 %.  The variants are kept compiled out of the kernels.)
-    (void)has_old; (void)bnr;
-    body(std::false_type{}, std::false_type{});
+    wr(std::integral_constant<int, 0>{});
+    rd(o[0]);
+    chunk(std::integral_constant<int, 0>{});
+    chunk(std::integral_constant<int, 1>{});
+    chunk(std::integral_constant<int, 2>{});
+    chunk(std::integral_constant<int, 3>{});
+    chunk(std::integral_constant<int, 4>{});
+    chunk(std::integral_constant<int, 5>{});
 }
 
 typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
@@ -2045,7 +1955,8 @@ static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t 
 }
 // the same kernel on two fp16 planes per operand (fp32 tensors, f32_split == 2): every shape it can address -- the alternative
 // is the three-term split kernel at a third of its rate
-static bool conv_ws_planes_eligible(const ConvArgs& a) {
+static bool conv_ws_planes_eligible(const ConvArgs& a, const int mode) {
+    if (mode == 0 && a.accum) return false;      // (an accumulating FORWARD launch: no plan issues one; the forward epilogue has no such path)
     if (a.f32_split != 2 || !a.x_planes || !a.w_planes || !a.x_unscale || !a.w_unscale) return false;
     // (N = 320: the decoder's data gradient.  N = 64 -- layer1's 3x3 and the 256 -> 64 1x1 -- runs the 288 x 128 configuration with
     // half of every tile empty: zero weight rows through the descriptor's range check, no stores; still ahead of the three-term
@@ -3181,7 +3092,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
     }
     if (a.w_tiled) return DML_EUNSUPPORTED;      // tile-major weights: only the LDS-DMA kernels above read them
     if constexpr (sizeof(T) == 4 && MODE != 2) {
-        if (conv_ws_planes_eligible(a)) {
+        if (conv_ws_planes_eligible(a, MODE)) {
             // fp32 tensors, products of two fp16 planes per operand on the matrix cores (DmlConvDesc.x_planes ...)
             constexpr int CUS = 256, NLD = DML_WS_PLANES_NLD;
             const bool wide = (a.N % 256) == 0;
@@ -3250,14 +3161,14 @@ extern "C" int dml_conv_stat_rows(const DmlConvDesc* d) {
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.ldx = d->ldx;
     a.M = d->B * d->Ho * d->Wo;
     a.Ktot = d->R * d->S * d->C;
-    a.y = d->y; a.ldy = d->ldy; a.bias = d->bias;
+    a.y = d->y; a.ldy = d->ldy; a.bias = d->bias; a.accum = d->accum;
     a.post_scale = d->post_scale; a.post_shift = d->post_shift; a.post_mean = d->post_mean; a.post_res = d->post_res;
     a.post_ldres = d->post_ldres;
     if (d->dtype == DML_F32) {
         a.f32_split = d->f32_split; a.x_planes = d->x_planes; a.w_planes = d->w_planes;
         a.x_unscale = d->x_unscale; a.w_unscale = d->w_unscale;
         a.x_plane_bytes = (uint32_t)(d->x_plane_stride * 2); a.w_plane_bytes = (uint32_t)(d->w_plane_stride * 2);
-        return (d->x_plane_stride < (1ll << 30) && d->w_plane_stride < (1ll << 30) && conv_ws_planes_eligible(a)) ? WS_STAT_ROWS
+        return (d->x_plane_stride < (1ll << 30) && d->w_plane_stride < (1ll << 30) && conv_ws_planes_eligible(a, d->mode)) ? WS_STAT_ROWS
                                                                                                                    : DML_STAT_ROWS;
     }
     if (d->dtype != DML_BF16 || !d->w_tiled) return DML_STAT_ROWS;
@@ -3374,7 +3285,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     if (d->dtype == DML_BF16)
         return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
     // fp32: only the two-plane kernel writes the BN-backward sums / adds the masked identity-branch gradient
-    if ((a.bnr_partials || a.res_dz) && !conv_ws_planes_eligible(a)) return DML_EUNSUPPORTED;
+    if ((a.bnr_partials || a.res_dz) && !conv_ws_planes_eligible(a, d->mode)) return DML_EUNSUPPORTED;
     return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
 }
 

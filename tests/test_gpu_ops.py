@@ -1283,6 +1283,29 @@ def test_split_products_keep_a_non_finite_input_visible(lib):
     assert (ys[1][~hit] - ys[0][~hit]).abs().max().item() <= 1e-5 * ys[0][~hit].abs().max().item()
 
 
+def test_two_plane_forward_with_accumulate_falls_back_and_accumulates(lib):
+    """mode 0 + accum + planes: the two-plane forward epilogue has no accumulate path, so the launch is NOT eligible for that kernel
+    (dml_conv_stat_rows says 64) and runs the three-term split on x / w -- the sum is still what comes out."""
+    B, Hh, Ww, Cin, Cout = 2, 12, 12, 64, 128
+    x = torch.randn(B, Hh, Ww, Cin, device="cuda")
+    w = (torch.randn(Cout, 1, 1, Cin, device="cuda") * 0.1).contiguous()
+    y0 = torch.randn(B, Hh, Ww, Cout, device="cuda")
+    y = y0.clone()
+    d = make_desc(lib, x, w, y, B, Hh, Ww, Cin, Hh, Ww, Cout, 1, 1, 1, 0, 0, accum=1)
+    xp, xw = h2_planes(lib, x.view(-1, Cin), 0)
+    wp, ww = h2_planes(lib, w.view(Cout, -1), 1)
+    d.f32_split = 2
+    d.x_planes, d.x_unscale, d.x_plane_stride = xp.data_ptr(), xw.data_ptr() + 4096, xp.shape[1]
+    d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
+    assert lib.dml_conv_stat_rows(C.byref(d)) == 64
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    torch.cuda.synchronize()
+    ref = y0.double() + torch.einsum("bhwc,nc->bhwn", x.double(), w.view(Cout, Cin).double())
+    assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    d.accum = 0
+    assert lib.dml_conv_stat_rows(C.byref(d)) == 48
+
+
 def h2_planes(lib, t2d, layout=0, amax=None):
     """dml_h2_split of an fp32 [rows][C] cuda tensor -> (planes fp16 [2][rows * C], work) ; work[1024] = 1 / scale"""
     rows, Cc = t2d.shape
