@@ -2358,6 +2358,260 @@ __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) v
 // planes were written once by the producer of the tensor.  Double-buffered LDS (68 KB: two workgroups per CU), loads of step
 // t + 1 in registers while step t computes.  Same split-K / workspace scheme as the other weight-gradient kernels.
 // ------------------------------------------------------------------------------------------------
+// ------------------------------------------------------------------------------------------------
+// Weight gradient on fp16 planes, wave-specialised (the structure of conv_ws_kernel): three loader waves bring a K step -- 32
+// pixels of dy [32][128] and of the gathered x [32][256], hi and lo plane each, 48 KB -- into a 3-stage LDS ring with LDS-DMA
+// (whole 256 / 512-byte pixel rows per piece: the operands are pixel-major in memory), four consumer waves (2 x 2, wave tile
+// 64 n x 128 kc = 32 accumulator fragments) read transposed fragments (ds_read_b64_tr_b16 on the row-major image, 16-byte chunk
+// index XOR 2 (row & 7): conflict-free) and issue 96 MFMAs per K step.  Persistent workgroups walk the (output tile, pixel slab)
+// list; slabs go to the workspace and wgrad_reduce_kernel folds them as for the other kernels.
+// ------------------------------------------------------------------------------------------------
+constexpr int WGW_NST = 3, WGW_NLD = 3;
+constexpr int WGW_TN = 128, WGW_TK = 256;
+constexpr int WGW_YROW = WGW_TN * 2, WGW_XROW = WGW_TK * 2;                  // bytes per pixel row and plane
+constexpr int WGW_YPL = 32 * WGW_YROW, WGW_XPL = 32 * WGW_XROW;              // bytes per plane and stage
+constexpr int WGW_SB = 2 * WGW_YPL + 2 * WGW_XPL;                            // [dy hi | dy lo | x hi | x lo] = 48 KB
+
+template <bool LIN, int LW>
+__device__ __forceinline__ void wgrad_ws_loader(const WgradArgs& a, const uint32_t x_bytes, const uint32_t dy_bytes, char* smem,
+                                                uint32_t* ready, uint32_t* consumed, const int lane, const int nitems, const int ntile) {
+    constexpr int NLD = WGW_NLD, NST = WGW_NST, NG = 24, MYG = NG / NLD;         // row groups: 8 of dy (4 rows), 16 of x (2 rows)
+    constexpr uint32_t OOB = 0x80000000u;
+    const u32x4_ws rs_x = ws_make_rsrc(a.x_planes, x_bytes + a.x_plane_bytes), rs_y = ws_make_rsrc(a.dy_planes, dy_bytes + a.dy_plane_bytes);
+    const uint32_t lds0 = (uint32_t)(uintptr_t)smem;
+    const int tiles_total = (a.M + BK - 1) / BK;
+    uint32_t g = 0, pub = 0;
+    for (int item = xcd_remap(blockIdx.x, gridDim.x); item < nitems; item += (int)gridDim.x) {      // (neighbouring items -- the tiles of one pixel slab -- on one XCD: they share dy and x rows in its L2)
+        const int split = item / ntile, tile_id = item - split * ntile;
+        const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
+        const int n0 = blk_n * WGW_TN, kc0 = blk_k * WGW_TK;
+        const int tile_beg = split * a.slab_tiles, tile_end = min(tiles_total, tile_beg + a.slab_tiles);
+        const int m_end = min(a.M, tile_end * BK);
+        int row[MYG], colb[MYG], dyo[MYG], dxo[MYG];
+        bool cok[MYG];
+#pragma unroll
+        for (int q = 0; q < MYG; ++q) {
+            const int gi = q * NLD + LW;
+            if (gi < 8) {
+                row[q] = gi * 4 + (lane >> 4);
+                const int gch = (lane & 15) ^ (2 * (row[q] & 7));
+                const int n = n0 + gch * 8;
+                cok[q] = n < a.N;
+                colb[q] = n * 2;
+                dyo[q] = dxo[q] = 0;
+            } else {
+                row[q] = (gi - 8) * 2 + (lane >> 5);
+                const int gch = (lane & 31) ^ (2 * (row[q] & 7));
+                const int kc = kc0 + gch * 8;
+                cok[q] = kc < a.Ktot;
+                const uint32_t tap = fdiv((uint32_t)(cok[q] ? kc : 0), a.div_c);
+                const int xc = (cok[q] ? kc : 0) - (int)tap * a.C;
+                const int tr = (int)tap / a.S, ts = (int)tap - tr * a.S;
+                dyo[q] = tr * a.dil - a.pad;
+                dxo[q] = ts * a.dil - a.pad;
+                colb[q] = xc * 2;
+            }
+        }
+        for (int t = tile_beg; t < tile_end; ++t) {
+            if (g >= (uint32_t)NST) {
+                const uint32_t need = g - NST + 1;
+                bool drained = false;
+                for (;;) {
+                    uint32_t mn = ws_ld(consumed);
+#pragma unroll
+                    for (int w = 1; w < 4; ++w) mn = min(mn, ws_ld(consumed + w));
+                    if (mn >= need) break;
+                    if (!drained) {
+                        wait_vmcnt<0>();
+                        ws_st(ready + LW, g);
+                        pub = g;
+                        drained = true;
+                    }
+                    __builtin_amdgcn_s_sleep(1);
+                }
+                asm volatile("" ::: "memory");
+            }
+            const uint32_t sbase = lds0 + (g % NST) * WGW_SB;
+#pragma unroll
+            for (int q = 0; q < MYG; ++q) {
+                const int gi = q * NLD + LW;
+                const int m = t * BK + row[q];
+                bool ok = cok[q] && m < m_end;
+                uint32_t voff;
+                if (gi < 8) {
+                    voff = (uint32_t)m * (uint32_t)(a.ldy * 2) + (uint32_t)colb[q];
+                    ws_dma16(rs_y, sbase + gi * 1024, ok ? voff : OOB, 0u);
+                    ws_dma16(rs_y, sbase + WGW_YPL + gi * 1024, ok ? voff : OOB, a.dy_plane_bytes);
+                } else {
+                    if (LIN) {
+                        voff = (uint32_t)m * (uint32_t)(a.ldx * 2) + (uint32_t)colb[q];
+                    } else {
+                        const uint32_t mm = ok ? (uint32_t)m : 0u;
+                        const uint32_t b = fdiv(mm, a.div_howo);
+                        const uint32_t rem = mm - b * (uint32_t)(a.Ho * a.Wo);
+                        const uint32_t yo = fdiv(rem, a.div_wo);
+                        const uint32_t xo = rem - yo * (uint32_t)a.Wo;
+                        const int ys = (int)yo * a.stride + dyo[q], xs = (int)xo * a.stride + dxo[q];
+                        ok = ok && (unsigned)ys < (unsigned)a.Hi && (unsigned)xs < (unsigned)a.Wi;
+                        voff = (uint32_t)(((int)b * a.Hi + ys) * a.Wi + xs) * (uint32_t)(a.ldx * 2) + (uint32_t)colb[q];
+                    }
+                    const int xi = gi - 8;
+                    ws_dma16(rs_x, sbase + 2 * WGW_YPL + xi * 1024, ok ? voff : OOB, 0u);
+                    ws_dma16(rs_x, sbase + 2 * WGW_YPL + WGW_XPL + xi * 1024, ok ? voff : OOB, a.x_plane_bytes);
+                }
+            }
+            ++g;
+            if (g > 1u + pub) {
+                wait_vmcnt<2 * MYG>();             // one stage of this wave's pieces in flight behind the one it publishes
+                pub = g - 1;
+                ws_st(ready + LW, pub);
+            }
+        }
+    }
+    wait_vmcnt<0>();
+    ws_st(ready + LW, g);
+}
+
+template <bool LIN>
+__global__ __launch_bounds__((4 + WGW_NLD) * 64) void conv_wgrad_ws_kernel(const WgradArgs a, const uint32_t x_bytes, const uint32_t dy_bytes,
+                                                                          const int nitems) {
+    constexpr int NST = WGW_NST, NLD = WGW_NLD, NT = 4, MT = 8;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * WGW_SB + 64];
+    uint32_t* const ready = reinterpret_cast<uint32_t*>(smem + NST * WGW_SB);
+    uint32_t* const consumed = ready + 4;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    if (tid < 16) reinterpret_cast<uint32_t*>(smem + NST * WGW_SB)[tid] = 0;
+    __syncthreads();
+    const int ntile = a.nblk_n * a.nblk_k;
+    if (wave >= 4) {
+        const int lw = wave - 4;
+        if (lw == 0) wgrad_ws_loader<LIN, 0>(a, x_bytes, dy_bytes, smem, ready, consumed, lane, nitems, ntile);
+        if (lw == 1) wgrad_ws_loader<LIN, 1>(a, x_bytes, dy_bytes, smem, ready, consumed, lane, nitems, ntile);
+        if (lw == 2) wgrad_ws_loader<LIN, 2>(a, x_bytes, dy_bytes, smem, ready, consumed, lane, nitems, ntile);
+        return;
+    }
+    // ---------------------------------------------------------------------- consumer
+    const int wn = wave >> 1, wk = wave & 1;
+    const int lr = lane & 15, lq = lane >> 4;
+    const int tiles_total = (a.M + BK - 1) / BK;
+    uint32_t g = 0, rflag = 0;
+    auto wait_ready = [&](const uint32_t need) {
+        while (rflag < need) {
+            __builtin_amdgcn_s_sleep(1);
+            uint32_t v = ws_ld(ready);
+#pragma unroll
+            for (int w = 1; w < NLD; ++w) v = min(v, ws_ld(ready + w));
+            rflag = v;
+        }
+        asm volatile("" ::: "memory");
+    };
+    // transposed fragment = two ds_read_b64_tr_b16 (pixel rows r, r + 8 of the lane's row group) of four channels
+    const int row_lo = (lr >> 2) | ((lq & 1) << 2) | ((lq >> 1) << 4);
+    const int sw = 2 * (row_lo & 7), sub = ((lr & 3) & 1) * 8;
+    int y_off[NT], x_off[MT];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) y_off[i] = row_lo * WGW_YROW + (((wn * 8 + i * 2 + ((lr & 3) >> 1)) ^ sw) << 4) + sub;
+#pragma unroll
+    for (int j = 0; j < MT; ++j) x_off[j] = 2 * WGW_YPL + row_lo * WGW_XROW + (((wk * 16 + j * 2 + ((lr & 3) >> 1)) ^ sw) << 4) + sub;
+    auto frag = [&](const char* p, const int rowb) -> mfma_f16x8 {
+        const bf16x4 lo = lds_tr16_b64(reinterpret_cast<const bf16_t*>(p));
+        const bf16x4 hi = lds_tr16_b64(reinterpret_cast<const bf16_t*>(p + 8 * rowb));
+        const bf16x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+        return __builtin_bit_cast(mfma_f16x8, v);
+    };
+    for (int item = xcd_remap(blockIdx.x, gridDim.x); item < nitems; item += (int)gridDim.x) {      // (neighbouring items -- the tiles of one pixel slab -- on one XCD: they share dy and x rows in its L2)
+        const int split = item / ntile, tile_id = item - split * ntile;
+        const int blk_n = tile_id % a.nblk_n, blk_k = tile_id / a.nblk_n;
+        const int n0 = blk_n * WGW_TN, kc0 = blk_k * WGW_TK;
+        const int tile_beg = split * a.slab_tiles, tile_end = min(tiles_total, tile_beg + a.slab_tiles);
+        const int KT = tile_end - tile_beg;
+        f32x4 acc[NT][MT];
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        mfma_f16x8 yh[NT], yhn[NT], yl[NT], xh[2], xl[2];
+        uint32_t pl[NLD];
+        if (KT > 0) {
+            wait_ready(g + 1);
+            const char* sb = smem + (g % NST) * WGW_SB;
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                yh[i] = frag(sb + y_off[i], WGW_YROW);
+                yl[i] = frag(sb + y_off[i] + WGW_YPL, WGW_YROW);
+            }
+            xh[0] = frag(sb + x_off[0], WGW_XROW);
+            xl[0] = frag(sb + x_off[0] + WGW_XPL, WGW_XROW);
+        }
+        for (int kt = 0; kt < KT; ++kt) {
+            const bool has_next = kt + 1 < KT;
+            const char* sb = smem + (g % NST) * WGW_SB;
+            const char* sn = has_next ? smem + ((g + 1) % NST) * WGW_SB : sb;
+#pragma unroll
+            for (int j = 0; j < MT; ++j) {
+                if (j + 1 < MT) {
+                    xh[(j + 1) & 1] = frag(sb + x_off[j + 1], WGW_XROW);
+                    xl[(j + 1) & 1] = frag(sb + x_off[j + 1] + WGW_XPL, WGW_XROW);
+                } else {
+                    asm volatile("" ::: "memory");
+                    ws_st(consumed + wave, g + 1);      // every read of stage g has been issued
+                    xh[0] = frag(sn + x_off[0], WGW_XROW);
+                    xl[0] = frag(sn + x_off[0] + WGW_XPL, WGW_XROW);
+                }
+                if (j == 1) {
+#pragma unroll
+                    for (int w = 0; w < NLD; ++w) pl[w] = ws_ld(ready + w);
+                }
+                if (j == 3) {
+                    rflag = pl[0];
+#pragma unroll
+                    for (int w = 1; w < NLD; ++w) rflag = min(rflag, pl[w]);
+                    if (has_next) wait_ready(g + 2);
+                }
+                if (j == 4) {
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) yhn[i] = frag(sn + y_off[i], WGW_YROW);
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh[i], xh[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh[i], xl[j & 1], acc[i][j], 0, 0, 0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl[i], xh[j & 1], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int i = 0; i < NT; ++i) {
+                yl[i] = frag(sn + y_off[i] + WGW_YPL, WGW_YROW);
+                yh[i] = yhn[i];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            ++g;
+        }
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
+        const float un = a.x_unscale[0] * a.dy_unscale[0];
+        // acc[i][j][q] = dw[n = n0 + wn*64 + i*16 + lq*4 + q][kc = kc0 + wk*128 + j*16 + lr]
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int n = n0 + wn * 64 + i * 16 + lq * 4 + q;
+                if (n >= a.N) continue;
+                float* wrow = a.ws + ((int64_t)split * a.N + n) * a.Ktot;
+#pragma unroll
+                for (int j = 0; j < MT; ++j) {
+                    const int k = kc0 + wk * 128 + j * 16 + lr;
+                    if (k < a.Ktot) wrow[k] = acc[i][j][q] * un;
+                }
+            }
+    }
+}
+
 template <bool LIN>      // LIN: 1x1, stride 1, no padding -- pixel row m of x is output row m
 __global__ __launch_bounds__(NTHREADS) __attribute__((amdgpu_waves_per_eu(2))) void conv_wgrad_h2_kernel(
     const WgradArgs a, const uint32_t x_bytes, const uint32_t dy_bytes) {
@@ -3437,6 +3691,51 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         a.slab_tiles = (tiles + sk - 1) / sk;
         sk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
         hipLaunchKernelGGL(conv_wgrad_big_kernel<WGRAD_DEPTH>, dim3(base * sk), dim3(WB_THREADS), 0, st, a, (uint32_t)xb64, (uint32_t)yb64);
+        const int64_t nrs = (int64_t)a.N * a.R * a.S;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), 1), dim3(256), 0, st, d->ws, d->dw, sk, nrs,
+                           cm, d->C, 1, 0);
+        DML_LAUNCH_CHECK();
+        return 0;
+    }
+    if (planes && use_ws && a.N % WGW_TN == 0 && tiles >= 16) {
+        // wave-specialised kernel on planes: 128 x 256 output tiles, persistent workgroups over (tile, slab) items.  Against
+        // conv_wgrad_h2_kernel in isolation (same box, tools/bench_h2.py wgrad): 3x3 256 -> 256 167-176 -> 149 us, 1x1 1024 <-> 256
+        // 76-83 -> 69-71, ASPP 3x3 1070-1147 -> 939, 3x3 512 -> 512 563 -> 473, decoder 3x3 2614-2724 -> 2532; in the train step,
+        // where the weight gradients share the chip with the main stream, the step is unchanged (183.6 vs 183.2 images/s, three
+        // interleaved pairs): DESIGN.md section 5, round 4
+        a.nblk_n = a.N / WGW_TN;
+        a.nblk_k = (a.Ktot + WGW_TK - 1) / WGW_TK;
+        const int base = a.nblk_n * a.nblk_k;
+        int sk = d->splitk;
+        if (sk <= 0) {
+            // the split count that fills whole rounds of 256 workgroups best, fewest splits on ties; >= 16 K steps per item
+            int smax = tiles / 16;
+            if (smax > 256) smax = 256;
+            if ((int64_t)smax * plane > d->ws_elems) smax = (int)(d->ws_elems / plane);
+            if (smax < 1) smax = 1;
+            double best = -1.0;
+            sk = 1;
+            for (int c = 1; c <= smax; ++c) {
+                const int slab = (tiles + c - 1) / c;
+                const int real = (tiles + slab - 1) / slab;
+                const int items = base * real;
+                const double eff = (double)items / (double)(((items + 255) / 256) * 256);
+                if (eff > best + 1e-9) { best = eff; sk = real; }
+            }
+        }
+        if ((int64_t)sk * plane > d->ws_elems) sk = (int)(d->ws_elems / plane);
+        if (sk < 1) return DML_EINVAL;
+        if (sk > tiles) sk = tiles;
+        a.ws = d->ws;
+        a.slab_tiles = (tiles + sk - 1) / sk;
+        sk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
+        const int nitems = base * sk;
+        const uint32_t xpb = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2), ypb = (uint32_t)((((int64_t)a.M - 1) * a.ldy + a.N) * 2);
+        const dim3 wgrid(nitems < 256 ? nitems : 256), wblock((4 + WGW_NLD) * 64);
+        if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0)
+            hipLaunchKernelGGL(conv_wgrad_ws_kernel<true>, wgrid, wblock, 0, st, a, xpb, ypb, nitems);
+        else
+            hipLaunchKernelGGL(conv_wgrad_ws_kernel<false>, wgrid, wblock, 0, st, a, xpb, ypb, nitems);
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), 1), dim3(256), 0, st, d->ws, d->dw, sk, nrs,
                            cm, d->C, 1, 0);
