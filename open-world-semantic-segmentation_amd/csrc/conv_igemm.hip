@@ -2575,11 +2575,11 @@ __global__ __launch_bounds__((4 + WGW_NLD) * 64) void conv_wgrad_ws_kernel(const
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh[i], xh[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[j & 1], yh[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yh[i], xl[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[j & 1], yh[i], acc[i][j], 0, 0, 0);
 #pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(yl[i], xh[j & 1], acc[i][j], 0, 0, 0);
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[j & 1], yl[i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
 #pragma unroll
@@ -2595,20 +2595,19 @@ __global__ __launch_bounds__((4 + WGW_NLD) * 64) void conv_wgrad_ws_kernel(const
 #pragma unroll
             for (int j = 0; j < MT; ++j) asm volatile("" : "+v"(acc[i][j]));
         const float un = a.x_unscale[0] * a.dy_unscale[0];
-        // acc[i][j][q] = dw[n = n0 + wn*64 + i*16 + lq*4 + q][kc = kc0 + wk*128 + j*16 + lr]
+        // the x fragment is the MFMA's row operand: acc[i][j][q] = dw[n = n0 + wn*64 + i*16 + lr][kc = kc0 + wk*128 + j*16 + lq*4 + q],
+        // four consecutive kc per lane -> 16-byte slab stores (Ktot % 8 == 0)
 #pragma unroll
-        for (int i = 0; i < NT; ++i)
+        for (int i = 0; i < NT; ++i) {
+            const int n = n0 + wn * 64 + i * 16 + lr;
+            if (n >= a.N) continue;
+            float* wrow = a.ws + ((int64_t)split * a.N + n) * a.Ktot;
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const int n = n0 + wn * 64 + i * 16 + lq * 4 + q;
-                if (n >= a.N) continue;
-                float* wrow = a.ws + ((int64_t)split * a.N + n) * a.Ktot;
-#pragma unroll
-                for (int j = 0; j < MT; ++j) {
-                    const int k = kc0 + wk * 128 + j * 16 + lr;
-                    if (k < a.Ktot) wrow[k] = acc[i][j][q] * un;
-                }
+            for (int j = 0; j < MT; ++j) {
+                const int k = kc0 + wk * 128 + j * 16 + lq * 4;
+                if (k < a.Ktot) *reinterpret_cast<f32x4*>(wrow + k) = acc[i][j] * un;
             }
+        }
     }
 }
 
@@ -3697,7 +3696,7 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         DML_LAUNCH_CHECK();
         return 0;
     }
-    if (planes && use_ws && a.N % WGW_TN == 0 && tiles >= 16) {
+    if (planes && use_ws && a.N % WGW_TN == 0 && tiles >= 16 && (reinterpret_cast<uintptr_t>(d->ws) & 15) == 0) {
         // wave-specialised kernel on planes: 128 x 256 output tiles, persistent workgroups over (tile, slab) items.  Against
         // conv_wgrad_h2_kernel in isolation (same box, tools/bench_h2.py wgrad): 3x3 256 -> 256 167-176 -> 149 us, 1x1 1024 <-> 256
         // 76-83 -> 69-71, ASPP 3x3 1070-1147 -> 939, 3x3 512 -> 512 563 -> 473, decoder 3x3 2614-2724 -> 2532; in the train step,
