@@ -1511,6 +1511,12 @@ typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
 constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
 constexpr int WS_STAT_ROWS = 48;               // rows per statistics group of this kernel
 constexpr int WS_NST = 6, WS_D = 2;            // ring stages; stages in flight per loader behind the published one
+#ifndef DML_WS_TAP_INNER
+#define DML_WS_TAP_INNER 1                     // K order of the two-plane instantiation: channel groups outermost, taps inside
+#endif
+#ifndef DML_WS_N_FASTEST
+#define DML_WS_N_FASTEST 1                     // tile walk of the two-plane instantiation: column blocks fastest
+#endif
 #ifndef DML_WS_PLANES_NLD
 #define DML_WS_PLANES_NLD 3                    // loader waves of the two-plane instantiation
 #endif
@@ -1535,6 +1541,19 @@ __device__ __forceinline__ u32x4_ws ws_make_rsrc(const void* base, const uint32_
 }
 __device__ __forceinline__ uint32_t ws_ld(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ void ws_st(uint32_t* p, const uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+
+// Tile walk.  One plane: row blocks fastest (the workgroups of an XCD share weight rows).  Two planes: column blocks fastest --
+// the 32 workgroups of an XCD then hold 32 / nblk_n neighbouring row blocks x all their column blocks AT THE SAME TIME and the
+// activation rows are fetched over the fabric once, not once per column block (row blocks fastest: the column blocks of a row
+// block run rounds apart; PMC: 1x1 256 -> 1024 at 48 x 48 read its input 4.2 x).
+template <int PL>
+__device__ __forceinline__ int ws_tile_m(const int tile, const ConvArgs& a) {
+    return (PL == 2 && DML_WS_N_FASTEST != 0) ? tile / a.nblk_n : tile % a.nblk_m;
+}
+template <int PL>
+__device__ __forceinline__ int ws_tile_n(const int tile, const ConvArgs& a) {
+    return (PL == 2 && DML_WS_N_FASTEST != 0) ? tile % a.nblk_n : tile / a.nblk_m;
+}
 
 // loader wave LW of NLD: compile-time piece ownership (no branches in the issue loop)
 // PL = 2: every operand tile is two planes (hi, lo fp16 of the scaled fp32 tensor); a stage = [A hi | A lo | B hi | B lo]
@@ -1564,7 +1583,7 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
     uint32_t mask[MYP];
     int prev_blk_m = -1;
     for (int tile = first_tile; tile < ntiles; tile += (int)gridDim.x) {
-        const int blk_m = tile % a.nblk_m, blk_n = tile / a.nblk_m;
+        const int blk_m = ws_tile_m<PL>(tile, a), blk_n = ws_tile_n<PL>(tile, a);
         const int m0 = blk_m * BM, n0 = blk_n * BN;
         // per owned piece and lane: A -- signed byte offset of the row's tap-(0,0) pixel (+ swizzled chunk) and one validity
         // bit per filter tap; B -- byte offset into the tile-major weights at K step 0 (see conv_igemm_dma_kernel).  The A part
@@ -1614,7 +1633,15 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
         // same weight rows; letting each start at its own K step, to spread their simultaneous requests over the L2 channels, LOSES:
         // the weight working set of the moment grows from one K step to the whole matrix and falls out of the 4 MB L2 (ASPP 3x3
         // 278 -> 389 us in bf16, 732 -> 870 us on two planes; gpurun_out/r04 h2_krot).)
-        int ir = 0, is = 0, ic0 = 0;
+        // Two planes: K walks 64-channel groups outermost and the filter taps inside a group.  The workgroups of an XCD hold
+        // neighbouring row blocks and move through K together, so at any moment they read ONE channel group of one contiguous
+        // row range (+- the halo) whatever the tap: ~1 MB that stays in the XCD's 4 MB L2 across the nine taps.  With the taps
+        // outermost a tap sweeps all C channels of that range (4.7 MB at C = 256) before the next tap comes back to the same
+        // lines, and every tap was a miss (PMC: 3x3 256 -> 256 at 48 x 48 fetched 4.4 x its algorithmic bytes, the decoder's
+        // data gradient 12.6 x).  64 channels = the two K steps that share a 128-byte line.
+        constexpr bool TAPIN = PL == 2 && DML_WS_TAP_INNER != 0;
+        const int ksteps_c = a.C / BK;
+        int ir = 0, is = 0, ic0 = 0, cg0 = 0;
         for (int kt = 0; kt < KT; ++kt) {
             if (g >= (uint32_t)NST) {
                 // the stage this K step overwrites must have been read by every consumer wave
@@ -1640,6 +1667,7 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
             }
             const uint32_t sbase = lds0 + (g % NST) * SB;
             const uint32_t tapbit = 1u << (ir * a.S + is);
+            const int ktw = TAPIN ? (ir * a.S + is) * ksteps_c + ic0 / BK : kt;      // the K step's tile in the (tap-major) weight copy
             const int soff = (MODE == 0 ? ((ir * a.dil) * a.Wi + is * a.dil) * a.ldx
                                         : -((((ir * a.dil) >> sh2) * a.Wi + ((is * a.dil) >> sh2)) * a.ldx)) * 2 + ic0 * 2;
 #pragma unroll
@@ -1650,11 +1678,19 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
                     ws_dma16(rs_x, sbase + p * 1024, voff, p < PA ? 0u : a.x_plane_bytes);
                 } else {
                     ws_dma16(rs_w, sbase + p * 1024, (uint32_t)base[q],
-                             (uint32_t)kt * 4096u + ((p - PL * PA) < PB ? 0u : a.w_plane_bytes));
+                             (uint32_t)ktw * 4096u + ((p - PL * PA) < PB ? 0u : a.w_plane_bytes));
                 }
             }
             ic0 += BK;
-            if (ic0 >= a.C) {
+            if (TAPIN) {
+                if (ic0 >= a.C || ic0 >= cg0 + 64) {             // this tap's share of the channel group is done
+                    ic0 = cg0;
+                    if (++is == a.S) {
+                        is = 0;
+                        if (++ir == a.R) { ir = 0; cg0 += 64; ic0 = cg0; }
+                    }
+                }
+            } else if (ic0 >= a.C) {
                 ic0 = 0;
                 if (++is == a.S) { is = 0; ++ir; }
             }
@@ -1728,7 +1764,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     constexpr int A_PLANE = BM * BK * 2, B_PLANE = BN * BK * 2;      // bytes from the hi plane to the lo plane inside a stage
 
     for (int tile = first_tile; tile < ntiles; tile += (int)gridDim.x) {
-        const int blk_m = tile % a.nblk_m, blk_n = tile / a.nblk_m;
+        const int blk_m = ws_tile_m<PL>(tile, a), blk_n = ws_tile_n<PL>(tile, a);
         // fragment byte offsets inside a stage (hi plane; the lo plane is BM / BN rows further).  Recomputed per tile from a lane
         // index the optimiser cannot see through: hoisted out of the tile loop these 13 registers stay live across the epilogue,
         // where the 144 accumulator registers leave no room for them (spills, and a scratch reload waits vmcnt(0) -- for every
