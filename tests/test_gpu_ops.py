@@ -1374,7 +1374,11 @@ def test_h2_split_table_equals_the_single_tensor_calls(lib):
 
 H2_CASES = [("h2_1x1", 2, 24, 20, 64, 128, 1, 1, 1), ("h2_3x3", 2, 19, 23, 64, 256, 3, 1, 1), ("h2_3x3_d2", 2, 16, 16, 128, 256, 3, 1, 2),
             ("h2_3x3_s2", 2, 22, 18, 128, 128, 3, 2, 1), ("h2_rows", 3, 40, 40, 256, 256, 3, 1, 1), ("h2_1x1_n384", 2, 13, 29, 96, 384, 1, 1, 1),
-            ("h2_3x3_n64", 2, 21, 17, 64, 64, 3, 1, 1)]
+            ("h2_3x3_n64", 2, 21, 17, 64, 64, 3, 1, 1),
+            # K order of the two-plane kernel (64-channel groups outermost, taps inside): a last group of 32 channels (C = 96), five
+            # groups (C = 320); three column blocks, the last one half empty, walked fastest (N = 320: forward of the first case and
+            # data gradient of the second, the shape of the decoder's 3x3)
+            ("h2_3x3_c96_n320", 2, 17, 21, 96, 320, 3, 1, 1), ("h2_3x3_c320_n192", 2, 15, 14, 320, 192, 3, 1, 1)]
 
 
 @pytest.mark.parametrize("case", H2_CASES, ids=lambda c: c[0])
