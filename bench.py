@@ -36,13 +36,17 @@ HBM_PEAK = 8.0e12
 DTYPE_FIELD = {"f16x2": "f32", "f32x3": "f32", "f32": "f32", "bf16": "bf16"}
 ARITHMETIC = {
     "f16x2": "fp32 tensors, fp32 accumulation; convolution products on the fp16 matrix cores through a two-term split of the "
-             "power-of-two-scaled operands (22 significand bits per element, three MFMAs per block); passes the unchanged 1e-3 "
-             "fixtures (G5, G8, 768x768 vs the oracle)",
+             "power-of-two-scaled operands (22 significand bits per element, three MFMAs per block: NOT the reference's literal fp32 "
+             "products).  Gates it passes, same bars as the exact-fp32 mode, no mode-dependent branch in tests/: the reference-minted "
+             "conditioned fixtures g5l / g8l / g12l (2x3x128x128, every ReLU input proved >= 64 eps32 sum|terms| from zero: logits / loss "
+             "1e-3, all gradient checksums 2e-3), 2x768x768 vs the oracle, 1024x2048 eval vs the oracle; 16x768x768 against the "
+             "exact-fp32 step of this library.  The unconditioned 64x64 fixtures g5 / g8 / g12 gate the exact-fp32 mode only",
     "f32x3": "fp32 tensors, fp32 accumulation; convolution products on the bf16 matrix cores through a three-term split (six MFMAs "
-             "per block); passes the unchanged 1e-3 fixtures",
+             "per block); same gates as f16x2",
     "f32": "exact fp32 MFMA (v_mfma_f32_16x16x4_f32): the reference's arithmetic",
     "bf16": "bf16 storage of activations / compute weights, fp32 accumulation and statistics (statistically gated, not a 1e-3 mode)"}
-ROUND = "r04"
+FP32_PRODUCTS = {"f32": "exact", "f32x3": "bf16x3", "f16x2": "f16x2"}      # model.set_compute_dtype(torch.float32, fp32_products=...)
+ROUND = "r05"
 
 
 def csrc_sha():
@@ -490,22 +494,30 @@ def cpu_baseline(size, threads):
         return time.perf_counter() - t0
 
     # more threads is not faster for this size on a 2-socket host (128 threads: 14.4 s/step, 8 threads: 4.95 s on the
-    # 2 x EPYC 9575F box): time a few thread counts, one step each after a warm-up, and quote the best
+    # 2 x EPYC 9575F box): ONE probe step per thread count after a warm-up picks the best count, then the protocol of
+    # BASELINE.md section 4 on that count -- 1 warm-up + 3 timed steps, mean quoted
     counts = [threads] if threads != phys else sorted({c for c in (8, 32, phys) if c <= logical})
     torch.set_num_threads(min(32, logical))
     one(0)                                                   # warm-up (allocator, thread pool)
     by_threads = {}
-    for i, c in enumerate(counts):
+    it = 1
+    for c in counts:
         torch.set_num_threads(c)
-        by_threads[c] = one(1 + i)
+        by_threads[c] = one(it)
+        it += 1
+        if by_threads[c] > 12.0 and len(by_threads) > 1:      # (bounded sample: a count that is far off is not probed further)
+            break
     best = min(by_threads, key=by_threads.get)
-    sec = by_threads[best]
+    torch.set_num_threads(best)
+    timed = [one(it + k) for k in range(3)]                  # (the probe step on this count was its warm-up)
+    sec = sum(timed) / len(timed)
     out = {"value": bs / sec, "unit": "images/sec", "cores": best, "kind": "port",
            "host": "%d physical cores / %d logical CPUs" % (phys, logical),
-           "by_threads": {str(c): bs / t for c, t in by_threads.items()},
-           "sample": "oracle (PyTorch CPU fp32 restatement of the reference) train step, %dx%d bs=%d, one step per thread "
-                     "count after one warm-up step: %s" % (size, size, bs, ", ".join("%d threads %.2f s" % (c, t)
-                                                                                    for c, t in by_threads.items()))}
+           "probe_by_threads": {str(c): bs / t for c, t in by_threads.items()},
+           "timed_steps_s": [round(t, 3) for t in timed],
+           "sample": "oracle (PyTorch CPU fp32 restatement of the reference) train step, %dx%d bs=%d: 3 timed steps on %d threads "
+                     "(mean %.2f s/step) after a warm-up step and one probe step per thread count, whose best it is (%s)"
+                     % (size, size, bs, best, sec, ", ".join("%d threads %.2f s" % (c, t) for c, t in by_threads.items()))}
     if 8 in by_threads:
         out["value_8_threads"] = bs / by_threads[8]
     return out
@@ -524,7 +536,8 @@ def infer_bench(args):
     torch.manual_seed(1)
     model = network.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16, pretrained_backbone=False)
     model.to(device).eval()
-    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32,
+                            fp32_products=None if args.dtype == "bf16" else FP32_PRODUCTS[args.dtype])
     batch = args.batch if args.batch != 16 else 1
     g = torch.Generator().manual_seed(4321 + rank)
     img = torch.randn(batch, 3, args.height, args.width, generator=g).to(device)
@@ -560,9 +573,10 @@ def infer_bench(args):
             "metric": "images/sec open-world inference (eval forward + argmax/msp + dissum + novel relabel), DeepLabV3+R101",
             "value": batch * world * args.steps / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+            "vs_baseline": None, "dtype": DTYPE_FIELD[args.dtype], "data": "synthetic",
             "config": {"workload": "open-world inference %dx%d, %d image(s)/GPU/step, 16 prototypes, random-init weights"
-                                   % (args.height, args.width, batch), "parallelism": "dp%d" % world}}))
+                                   % (args.height, args.width, batch), "parallelism": "dp%d" % world,
+                       "arithmetic": ARITHMETIC[args.dtype]}}))
     if world > 1:
         dist.destroy_process_group()
 
@@ -581,7 +595,8 @@ def ood_bench(args):
     enc = models.ModelBuilder.build_encoder("resnet50dilated", fc_dim=2048)
     dec = models.ModelBuilder.build_decoder("ppm_deepsup_embedding", fc_dim=2048, num_class=13, use_softmax=True)
     m = models.SegmentationModuleOOD(enc, dec, None).to(device).eval()
-    m.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32)
+    m.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32,
+                        fp32_products=None if args.dtype == "bf16" else FP32_PRODUCTS[args.dtype])
     Hs, Ws = 720, 1280
     g = torch.Generator().manual_seed(99)
     imgs = []
@@ -609,9 +624,10 @@ def ood_bench(args):
         "metric": "images/sec open-set evaluation (5-scale ResNet-50-dilated + PPM embedding decoder, dissum, AUROC/AUPR/FPR95)",
         "value": args.steps / elapsed, "unit": "images/sec", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.dtype, "data": "synthetic",
+        "dtype": DTYPE_FIELD[args.dtype], "data": "synthetic",
         "config": {"workload": "one 720x1280 frame, inputs %s, segSize 720x1280, 13 prototypes, random-init weights"
-                               % ", ".join("%dx%d" % (t.shape[2], t.shape[3]) for t in imgs), "parallelism": "dp1"}}))
+                               % ", ".join("%dx%d" % (t.shape[2], t.shape[3]) for t in imgs), "parallelism": "dp1",
+                   "arithmetic": ARITHMETIC[args.dtype]}}))
 
 
 def main():
@@ -621,8 +637,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--dtype", default="f16x2", choices=["f16x2", "bf16", "f32", "f32x3"],
                     help="f16x2 (headline): fp32 storage and accumulation, the convolutions' products on the fp16 matrix cores "
-                         "through a two-term split of the scaled operands -- the fastest mode that passes the unchanged 1e-3 "
-                         "fixtures; f32 = exact fp32 MFMA (the reference's arithmetic bit for bit); f32x3 = the three-term bf16 "
+                         "through a two-term split of the scaled operands -- the fastest mode that passes the reference-minted "
+                         "conditioned fixtures (g5l / g8l / g12l) at the exact mode's bars; f32 = exact fp32 MFMA (the reference's arithmetic bit for bit); f32x3 = the three-term bf16 "
                          "split; bf16 = bf16 storage (the throughput mode: statistically gated, not a 1e-3 mode)")
     ap.add_argument("--batch", type=int, default=16, help="images per GPU")
     ap.add_argument("--size", type=int, default=768)
@@ -677,6 +693,8 @@ def main():
         for k in ("allreduce_32mb_ms", "allreduce_32mb_busbw_GBps"):
             if k in res:
                 out["config"][k] = res[k]
+        if "allreduce_32mb_ms" in res:
+            out["config"]["allreduce_backend"] = backend      # (gloo: host copies, says nothing about the fabric)
         if "roofline" in res:
             out["roofline"] = res["roofline"]
     if world == 1 and not args.no_profile:
@@ -709,10 +727,10 @@ def main():
             # the reference's arithmetic bit for bit (network/utils.py:84-118 computes in fp32): exact fp32 MFMAs
             # (v_mfma_f32_16x16x4_f32, 1/16 of the 16-bit matrix rate)
             torch.cuda.empty_cache()
-            f = train_pass(args, "f32", device, rank, world, steps=max(4, args.steps // 2), warmup=2, profile=True,
+            f = train_pass(args, "f32", device, rank, world, steps=args.steps, warmup=args.warmup, profile=True,
                            dump_conv=(args.dump_conv + ".fp32") if args.dump_conv else None)
             out["fp32_exact_companion"] = {"dtype": "f32", "value": f["value"], "unit": "images/sec", "ms_per_step": f["ms_per_step"],
-                                           "steps": max(4, args.steps // 2), "warmup": 2, "final_loss": f["final_loss"],
+                                           "steps": args.steps, "warmup": args.warmup, "final_loss": f["final_loss"],
                                            "roofline": {k: f["roofline"][k] for k in keep if k in f["roofline"] and k != "classes"}}
             # the three-term bf16 split (six MFMAs per block; round 3's fp32-accurate mode)
             torch.cuda.empty_cache()
@@ -777,9 +795,10 @@ def train_pass(args, dtype, device, rank, world, steps, warmup, profile, dump_co
         # xGMI, a few GB/s says it fell back to host memory (DESIGN.md section 6 states what the step should then look like)
         red = model._engine.reducer
         cs = getattr(red, "comm_stream", None) or torch.cuda.current_stream(device)
-        buf = torch.zeros(32 * (1 << 20) // 4, dtype=torch.float32, device=device)
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        cs.wait_stream(torch.cuda.current_stream(device))
         with torch.cuda.stream(cs):
+            buf = torch.zeros(32 * (1 << 20) // 4, dtype=torch.float32, device=device)      # allocated and filled on the stream that uses it
             for _ in range(2):
                 dist.all_reduce(buf)
             e0.record(cs)

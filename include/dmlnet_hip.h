@@ -138,7 +138,9 @@ typedef struct DmlConvDesc {
      * f32_split == 1.  x_planes / w_planes: [2][...] fp16, the hi plane then the lo plane `*_plane_stride` elements further, the
      * activation planes with the geometry (pitch ldx) of `x`, the weight planes tile-major ([N / 64][K / 32][64][32] per plane);
      * x_unscale / w_unscale: device scalars 1 / s and 1 / t (dml_h2_split).  Shapes the planes kernel does not take (C % 32,
-     * N % 64, more than 32 taps, misaligned y) run the three-term split on x / w, which must therefore be valid as well. */
+     * N % 64, more than 32 taps, misaligned y) run the three-term split on x / w, which must therefore be valid as well --
+     * UNLESS the caller keeps the activation as planes only and says so by passing x == x_planes: such a launch returns
+     * DML_EUNSUPPORTED when the planes kernel cannot take it (never a fallback that would read the planes as floats). */
     const void* x_planes;
     const void* w_planes;
     const float* x_unscale;
@@ -196,7 +198,8 @@ typedef struct DmlWgradDesc {
     int32_t reserved;
     /* f32_split == 2 (dtype DML_F32): both operands as two fp16 planes of the scaled tensors (dml_h2_split, layout 0, the pitches
      * of x / dy), three MFMAs per block on the fp16 matrix cores (DmlConvDesc.x_planes has the arithmetic); NULL planes or
-     * misaligned shapes: the three-term split on x / dy. */
+     * misaligned shapes: the three-term split on x / dy -- except that x == x_planes (dy == dy_planes) declares the operand
+     * planes-only: DML_EUNSUPPORTED instead of the fallback, as for DmlConvDesc. */
     const void* x_planes;
     const void* dy_planes;
     const float* x_unscale;

@@ -3575,6 +3575,9 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
         return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
     // fp32: only the two-plane kernel writes the BN-backward sums / adds the masked identity-branch gradient
     if ((a.bnr_partials || a.res_dz) && !conv_ws_planes_eligible(a, d->mode)) return DML_EUNSUPPORTED;
+    // x == x_planes: the caller keeps this operand as fp16 planes ONLY (no fp32 tensor behind `x`).  Every other fp32 kernel would
+    // read the planes as floats: refuse instead of falling back
+    if (d->f32_split == 2 && d->x_planes && d->x == d->x_planes && !conv_ws_planes_eligible(a, d->mode)) return DML_EUNSUPPORTED;
     return d->mode == 0 ? launch_conv<float, 0>(a, st) : launch_conv<float, 1>(a, st);
 }
 
@@ -3658,6 +3661,8 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
             a.x_plane_bytes = (uint32_t)(d->x_plane_stride * 2); a.dy_plane_bytes = (uint32_t)(d->dy_plane_stride * 2);
         }
     }
+    // x == x_planes / dy == dy_planes: that operand exists as fp16 planes ONLY -- the fp32 kernels below must not read it as floats
+    if (!planes && ((d->x_planes && d->x == d->x_planes) || (d->dy_planes && d->dy == d->dy_planes))) return DML_EUNSUPPORTED;
     const int tiles = (a.M + BK - 1) / BK;
     const int cm = d->Cm > 0 ? d->Cm : d->C;
     if (cm > d->C) return DML_EINVAL;

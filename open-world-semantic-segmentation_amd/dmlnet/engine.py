@@ -1042,6 +1042,12 @@ class Plan:
         aspp = head.aspp
         cat1 = self.new(B, out.H, out.W, 5 * 256)
         branches = []
+        # f16x2: the planes of `out` are shared by all four conv branches.  h2_of appends a tensor's split at its FIRST consumer,
+        # which would be branch 0 -- inside the first fork range of an inference plan (run_forward: every range on its own
+        # stream, each waiting for the main stream only), so branches 1-3 would read planes and the unscale word that
+        # branch 0's stream is still writing.  Issue the split here, on the main stream, before the fork point.
+        if self.h2_ok(out.C, aspp.convs[0][0].out_channels, 1):
+            self.h2_of(out, self.fwd)
         marks = [len(self.fwd)]
         for i in range(4):
             branches.append(self.cbr(out, aspp.convs[i][0], aspp.convs[i][1], out=cat1.slice(256 * i, 256)))
@@ -1078,6 +1084,9 @@ class Plan:
             # they may overlap (training keeps them in line: its units share the statistics scratch)
             if not hasattr(self, "fwd_forks"):
                 self.fwd_forks = []
+            # nothing inside a fork range may write a tensor another range reads: the only shared input is `out` (split above)
+            assert not any(fn is lib.dml_h2_split and args[0] == out.root.ptr for fn, args in self.fwd[marks[0]:marks[5]]), \
+                "the split of the fork's shared input must run before the fork point"
             self.fwd_forks.append([(marks[k], marks[k + 1]) for k in range(5)])
         uproj = self.cbr(cat1, aspp.project[0], aspp.project[1], drop=aspp.project[3])
         up_slice = cat2.slice(48, 256)

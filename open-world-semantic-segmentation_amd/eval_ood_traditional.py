@@ -83,7 +83,8 @@ def main():
     p.add_argument("--width", type=int, default=1280)
     p.add_argument("--encoder_weights", default="")
     p.add_argument("--decoder_weights", default="")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16x2", "f32x3"],
+                   help="bf16: bf16 storage (throughput mode); f32: exact fp32 MFMA (the reference's arithmetic); f16x2 / f32x3: fp32 tensors with the convolution products on the fp16 / bf16 matrix cores (fp32-accurate splits, bench.py's headline is f16x2)")
     p.add_argument("--synthetic", action="store_true")
     opts = p.parse_args()
     if not opts.synthetic:
@@ -95,7 +96,8 @@ def main():
     dec = models.ModelBuilder.build_decoder("ppm_deepsup_embedding", fc_dim=2048, num_class=13,
                                             weights=opts.decoder_weights, use_softmax=True)
     seg = models.SegmentationModuleOOD(enc, dec, None).to(device).eval()
-    seg.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32)
+    seg.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32,
+                            fp32_products={"f32": "exact", "f32x3": "bf16x3", "f16x2": "f16x2"}.get(opts.dtype))
     g = torch.Generator().manual_seed(7)
     shapes = resized_shapes(opts.height, opts.width)
 

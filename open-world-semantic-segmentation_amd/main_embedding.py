@@ -44,7 +44,8 @@ def get_argparser():
     p.add_argument("--val_images", type=int, default=2, help="synthetic frames scored at every --val_interval")
     p.add_argument("--frame_height", type=int, default=1024, help="synthetic source frames (Cityscapes: 1024 x 2048)")
     p.add_argument("--frame_width", type=int, default=2048)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16x2", "f32x3"],
+                   help="bf16: bf16 storage (throughput mode); f32: exact fp32 MFMA (the reference's arithmetic); f16x2 / f32x3: fp32 tensors with the convolution products on the fp16 / bf16 matrix cores (fp32-accurate splits, bench.py's headline is f16x2)")
     # the rest of the reference's surface (main_embedding.py:27-99 there): accepted so that its command lines keep
     # working; what they select lives outside the hot path (dataset IO, visdom, result dumps) or is fixed here
     p.add_argument("--data_root", default="./datasets/data", help="accepted; dataset file IO is out of scope (use --synthetic)")
@@ -80,7 +81,8 @@ def main():
     if opts.separable_conv and "plus" in opts.model:                               # :377-378
         network.convert_to_separable_conv(model.classifier)
     utils.set_bn_momentum(model.backbone, momentum=0.01)                           # :379
-    model.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32)
+    model.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32,
+                            fp32_products={"f32": "exact", "f32x3": "bf16x3", "f16x2": "f16x2"}.get(opts.dtype))
     optimizer = FusedSGD([{"params": model.backbone.parameters(), "lr": 0.1 * opts.lr},
                           {"params": model.classifier.parameters(), "lr": opts.lr}],
                          lr=opts.lr, momentum=0.9, weight_decay=opts.weight_decay).bind(model)   # :385-388

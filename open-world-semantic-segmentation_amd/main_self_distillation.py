@@ -48,7 +48,8 @@ def get_argparser():
     p.add_argument("--synthetic", action="store_true")
     p.add_argument("--frame_height", type=int, default=1024)
     p.add_argument("--frame_width", type=int, default=2048)
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16x2", "f32x3"],
+                   help="bf16: bf16 storage (throughput mode); f32: exact fp32 MFMA (the reference's arithmetic); f16x2 / f32x3: fp32 tensors with the convolution products on the fp16 / bf16 matrix cores (fp32-accurate splits, bench.py's headline is f16x2)")
     return p
 
 
@@ -76,7 +77,8 @@ def main():
     model = getattr(network, opts.model)(num_classes=opts.num_classes, output_stride=opts.output_stride,
                                          pretrained_backbone=False)
     utils.set_bn_momentum(model.backbone, momentum=0.01)                           # :345
-    model.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32)
+    model.set_compute_dtype(torch.bfloat16 if opts.dtype == "bf16" else torch.float32,
+                            fp32_products={"f32": "exact", "f32x3": "bf16x3", "f16x2": "f16x2"}.get(opts.dtype))
     groups = [{"params": model.classifier_1.parameters(), "lr": opts.lr}]          # :354-357
     if opts.train_backbone:
         groups.insert(0, {"params": model.backbone.parameters(), "lr": 0.1 * opts.lr})

@@ -162,10 +162,15 @@ class SegmentationModuleOOD(nn.Module):
         object.__setattr__(self, "_engine", PPMEngine(_EnginePair(net_enc, net_dec)))
         self._dtype = torch.bfloat16 if os.environ.get("DMLNET_DTYPE", "").lower() in ("bf16", "bfloat16") else torch.float32
 
-    def set_compute_dtype(self, dtype):
+    def set_compute_dtype(self, dtype, fp32_products=None):
+        """as network.modeling's: torch.float32 (fp32_products "exact" | "bf16x3" | "f16x2") or torch.bfloat16"""
         if dtype not in (torch.float32, torch.bfloat16):
             raise ValueError("compute dtype is float32 or bfloat16")
+        if fp32_products not in (None, "exact", "bf16x3", "f16x2"):
+            raise ValueError("fp32_products must be 'exact', 'bf16x3' or 'f16x2'")
         self._dtype = dtype
+        if fp32_products is not None:
+            self._engine.f32_split = {"exact": 0, "bf16x3": 1, "f16x2": 2}[fp32_products]
         return self
 
     def _accumulate(self, img, segSize, scores, feats, alpha):

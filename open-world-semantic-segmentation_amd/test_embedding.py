@@ -32,7 +32,8 @@ def main():
     p.add_argument("--width", type=int, default=2048)
     p.add_argument("--num_images", type=int, default=4)
     p.add_argument("--synthetic", action="store_true")
-    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32"])
+    p.add_argument("--dtype", default="bf16", choices=["bf16", "f32", "f16x2", "f32x3"],
+                   help="bf16: bf16 storage (throughput mode); f32: exact fp32 MFMA (the reference's arithmetic); f16x2 / f32x3: fp32 tensors with the convolution products on the fp16 / bf16 matrix cores (fp32-accurate splits, bench.py's headline is f16x2)")
     o = p.parse_args()
     if not o.synthetic:
         raise SystemExit("only --synthetic data is available (datasets are outside the hot path)")
@@ -45,7 +46,8 @@ def main():
     if o.ckpt:
         model.load_state_dict(torch.load(o.ckpt, map_location="cpu")["model_state"])    # :748-749
     model.to(dev).eval()                                                                # :773
-    model.set_compute_dtype(torch.bfloat16 if o.dtype == "bf16" else torch.float32)
+    model.set_compute_dtype(torch.bfloat16 if o.dtype == "bf16" else torch.float32,
+                            fp32_products={"f32": "exact", "f32x3": "bf16x3", "f16x2": "f16x2"}.get(o.dtype))
     if o.prototype_json:
         proto = utils.mean_prototype(json.load(open(o.prototype_json)))                 # :245-258
     else:

@@ -76,6 +76,22 @@ def synth_state_dict(shapes: "OrderedDict[str, tuple]", seed: int = 1) -> "Order
     return out
 
 
+def conditioned_state_dict(shapes: "OrderedDict[str, tuple]", seed: int, beta_idx, beta_val) -> "OrderedDict[str, torch.Tensor]":
+    """synth_state_dict with the BatchNorm betas a large fixture moved (tests/tools/mint_golden_large.py: no ReLU input of the
+    network within 64 * eps32 * sum|terms| of zero).  `beta_idx` indexes the concatenation of all BatchNorm biases in state_dict
+    order, `beta_val` holds the fp32 values that replace them."""
+    sd = synth_state_dict(shapes, seed)
+    keys = [k for k in sd if k.endswith(".bias") and (k[:-4] + "running_mean") in sd]
+    flat = torch.cat([sd[k].flatten() for k in keys])
+    flat[torch.as_tensor(np.asarray(beta_idx), dtype=torch.long)] = torch.as_tensor(np.asarray(beta_val), dtype=torch.float32)
+    off = 0
+    for k in keys:
+        n = sd[k].numel()
+        sd[k] = flat[off:off + n].clone().view(sd[k].shape)
+        off += n
+    return sd
+
+
 def shapes_of(module: torch.nn.Module) -> "OrderedDict[str, tuple]":
     return OrderedDict((k, tuple(v.shape)) for k, v in module.state_dict().items())
 

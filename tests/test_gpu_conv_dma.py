@@ -187,7 +187,7 @@ def test_bench_gpus_flag_launches_ranks_itself():
     assert d["n_gpus"] == 2 and d["config"]["rccl_ranks"] == 2 and d["config"]["backend"] == "gloo"
     assert d["config"]["global_batch"] == 4 and d["value"] > 0
     # self-diagnosis of the first real multi-GPU run: one 32 MB all-reduce on the comm stream, time and bus bandwidth on the line
-    assert d["config"]["allreduce_32mb_ms"] > 0 and d["config"]["allreduce_32mb_busbw_GBps"] > 0
+    assert d["config"]["allreduce_32mb_ms"] > 0 and d["config"]["allreduce_32mb_busbw_GBps"] > 0 and d["config"]["allreduce_backend"] == "gloo"
 
 
 def test_bench_script_default_path_small():
@@ -213,13 +213,15 @@ def test_bench_script_default_path_small():
     assert json.loads(r.stdout.strip().splitlines()[-1])["value"] > 0
 
 
-def test_train_driver_synthetic_with_raw_label_ids(tmp_path):
+@pytest.mark.parametrize("dtype", ["bf16", "f16x2"])
+def test_train_driver_synthetic_with_raw_label_ids(tmp_path, dtype):
     """main_embedding.py end to end at a small size: raw-id label frames -> crop / jitter / flip / encode_target in one
-    kernel -> train steps -> validation (device confusion matrix) -> checkpoint."""
+    kernel -> train steps -> validation (device confusion matrix) -> checkpoint; in the throughput mode and in bench.py's headline
+    arithmetic (--dtype f16x2: reachable from the entry point north_star names)."""
     drv = os.path.join(H.PKG, "main_embedding.py")
     r = subprocess.run([sys.executable, drv, "--synthetic", "--crop_size", "128", "--batch_size", "4", "--total_itrs", "4",
                         "--print_interval", "2", "--val_interval", "4", "--val_images", "1", "--frame_height", "160",
-                        "--frame_width", "224", "--loss_type", "dml", "--save_dir", str(tmp_path)],
+                        "--frame_width", "224", "--loss_type", "dml", "--dtype", dtype, "--save_dir", str(tmp_path)],
                        capture_output=True, text=True, cwd=H.PKG, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "Itrs 4/4, Loss=" in r.stdout and "Mean IoU" in r.stdout
@@ -254,12 +256,12 @@ def test_incremental_head_driver_synthetic(tmp_path):
     assert torch.equal(out["backbone.bn1.running_mean"], sd["backbone.bn1.running_mean"])
 
 
-@pytest.mark.parametrize("ood", ["dissum", "msp", "maxlogit"])
-def test_open_set_evaluation_driver_synthetic(ood):
+@pytest.mark.parametrize("ood,dtype", [("dissum", "bf16"), ("msp", "bf16"), ("maxlogit", "bf16"), ("dissum", "f16x2")])
+def test_open_set_evaluation_driver_synthetic(ood, dtype):
     """eval_ood_traditional.py end to end at a small frame size (five concurrent scales, graphs, device scores / AUROC)."""
     drv = os.path.join(H.PKG, "eval_ood_traditional.py")
     r = subprocess.run([sys.executable, drv, "--synthetic", "--ood", ood, "--num_images", "2", "--height", "360", "--width",
-                        "640"], capture_output=True, text=True, cwd=H.PKG, timeout=900)
+                        "640", "--dtype", dtype], capture_output=True, text=True, cwd=H.PKG, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
     assert "mean auroc = " in r.stdout and "Mean IoU:" in r.stdout
     auroc = float(r.stdout.split("mean auroc = ")[1].split()[0])

@@ -1454,6 +1454,39 @@ def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
         assert a_ <= max(4.0 * b_, 2e-6), errs
 
 
+def test_planes_only_operand_is_refused_where_the_planes_kernels_cannot_take_it(lib):
+    """x == x_planes (dy == dy_planes) declares an operand that exists as fp16 planes ONLY (the plan drops the fp32 copy of tensors only
+    convolutions read).  A launch the planes kernels cannot take must then fail with DML_EUNSUPPORTED -- the fallback kernels would read
+    the planes as floats -- while the same launch with a real fp32 tensor behind `x` still falls back silently."""
+    from dmlnet._lib import WgradDesc
+    B, Hh, Ww, Cin, Cout, k = 2, 9, 7, 64, 24, 1                 # 24 output channels: no shape of the planes kernel
+    xd = torch.randn(B, Hh, Ww, Cin, device="cuda")
+    wd = torch.randn(Cout, k, k, Cin, device="cuda") * 0.1
+    yd = torch.empty(B, Hh, Ww, Cout, device="cuda")
+    ap, aw = h2_planes(lib, xd.view(-1, Cin), 0)
+    wp, ww = h2_planes(lib, torch.randn(64, Cin, device="cuda"), 1)          # (any valid weight planes: never read)
+    d = make_desc(lib, xd, wd, yd, B, Hh, Ww, Cin, Hh, Ww, Cout, k, 1, 1, 0, 0)
+    d.f32_split = 2
+    d.x_planes, d.x_unscale, d.x_plane_stride = ap.data_ptr(), aw.data_ptr() + 4096, ap.shape[1]
+    d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
+    chk(lib.dml_conv_igemm(C.byref(d), st()))                  # fp32 tensor behind x: the three-term kernel takes it
+    torch.cuda.synchronize()
+    ref = torch.nn.functional.conv2d(xd.permute(0, 3, 1, 2).double(), wd.permute(0, 3, 1, 2).double()).permute(0, 2, 3, 1)
+    assert (yd.double() - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    d.x = ap.data_ptr()                                        # planes only
+    assert lib.dml_conv_igemm(C.byref(d), st()) == -3          # DML_EUNSUPPORTED
+    gyd = torch.randn(B, Hh, Ww, 20, device="cuda")            # 20 channels: no fp16 vectors of 8 -> the planes weight gradient declines
+    yp, yw = h2_planes(lib, torch.randn(B * Hh * Ww, 24, device="cuda"), 0)
+    ws = torch.empty(8 * 20 * Cin, device="cuda")
+    dw = torch.zeros(20, Cin, device="cuda")
+    wg = WgradDesc(x=ap.data_ptr(), dy=gyd.data_ptr(), dw=dw.data_ptr(), B=B, Hi=Hh, Wi=Ww, C=Cin, ldx=Cin, Ho=Hh, Wo=Ww, N=20, ldy=20,
+                   R=1, S=1, stride=1, dil=1, pad=0, dtype=0, splitk=2, f32_split=2, ws=ws.data_ptr(), ws_elems=ws.numel())
+    wg.x_planes, wg.x_unscale, wg.x_plane_stride = ap.data_ptr(), aw.data_ptr() + 4096, ap.shape[1]
+    wg.dy_planes, wg.dy_unscale, wg.dy_plane_stride = yp.data_ptr(), yw.data_ptr() + 4096, yp.shape[1]
+    assert lib.dml_conv_wgrad(C.byref(wg), st()) == -3
+    torch.cuda.synchronize()
+
+
 @pytest.mark.parametrize("accum,relu", [(0, 1), (1, 1), (1, 0), (2, 1)])
 def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
     """DmlConvDesc.bnr_* on fp32 tensors (the two-plane kernel's row epilogue): the data gradient writes the BN-backward sums of

@@ -160,6 +160,76 @@ def test_g5_full_train_and_g8_trajectory():
     close(m.state_dict()["backbone.conv1.weight"], T(t["w_stem"]), 1e-3)
 
 
+def test_large_conditioned_fixtures_g5l_g8l_g12l():
+    """The well-conditioned 128 x 128 fixtures (tests/tools/mint_golden_large.py: every ReLU input of the network at least
+    64 x eps32 x sum|terms| -- and 6 x the reference's own fp32-vs-fp64 noise -- away from zero): the oracle reproduces them, and the
+    proof numbers the mint script stored are the ones it asserts."""
+    g = H.load_golden("g5l_full_train")
+    assert float(g["relu_margin"]) >= 64.0 and float(g["relu_margin_over_noise"]) >= 6.0 and int(g["relu_elems"]) > 11_000_000
+    assert (g["relu_margins"] >= np.maximum(64.0, 6.0 * g["relu_fp32_noise"])).all() and int(g["beta_moved"]) == g["beta_idx"].size
+    m = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    sd = H.conditioned_state_dict(H.shapes_of(m), 1, g["beta_idx"], g["beta_val"])
+    plain = H.synth_state_dict(H.shapes_of(m), seed=1)
+    moved = [k for k in sd if not torch.equal(sd[k], plain[k])]
+    assert moved and all(k.endswith(".bias") and k[:-4] + "running_mean" in sd for k in moved)       # only BatchNorm betas
+    assert max(float((sd[k] - plain[k]).abs().max()) for k in moved) <= float(g["beta_max_delta"]) + 1e-12
+    m.load_state_dict(sd)
+    m.train()
+    m.classifier.aspp.project[3].eval()
+    O.set_bn_momentum(m.backbone, 0.01)
+    img = H.synth_tensor(5, "g5l.img", (2, 3, 128, 128))
+    lab = H.synth_labels(5, "g5l.lab", (2, 128, 128), 16, 255, ignore_rows=5)
+    lg, ctr, ft = m(img)
+    loss = O.ce_over_n(lg, lab, 255)
+    loss.backward()
+    close(lg[:, :, ::4, ::4], T(g["logits_sub"]), 1e-4)
+    close(lg[:, :, ::4, ::4], T(g["logits64_sub"]), 1e-4)
+    close(loss, T(g["loss"]), 1e-5)
+    grads = OrderedDict((k, p.grad) for k, p in m.named_parameters())
+    assert [str(n) for n in g["grad_names"]] == list(grads.keys())
+    for (k, gr), cs in zip(grads.items(), g["grad_checksums"]):
+        assert np.allclose(H.checksum(gr)[1:], cs[1:], rtol=3e-4), k
+    # G8L: six SGD / PolyLR steps from the same weights, bars stored in the fixture (8 x the reference's own run-to-run deviation)
+    t = H.load_golden("g8l_trajectory")
+    assert np.array_equal(t["beta_idx"], g["beta_idx"]) and np.array_equal(t["beta_val"], g["beta_val"])
+    m.load_state_dict(sd)
+    for p in m.parameters():
+        p.grad = None
+    lr, total = float(t["lr"]), int(t["total_itrs"])
+    opt = O.make_optimizer(m, lr=lr, weight_decay=1e-4)
+    losses = np.array([float(O.train_step(m, opt, img, lab, it, total, [0.1 * lr, lr], lambda a, b: O.ce_over_n(a, b, 255)))
+                       for it in range(6)])
+    assert (np.abs(losses - t["losses"]) <= t["bars"] * np.abs(t["losses"])).all(), (losses, t["losses"])
+    assert np.allclose([gp["lr"] for gp in opt.param_groups], t["lrs"][-1], rtol=1e-6)
+    fin = m.state_dict()
+    for i, (k, bar) in enumerate(zip([str(k) for k in t["wkeys"]], t["wbars"])):
+        got = fin[k].float() if fin[k].numel() < 70000 else fin[k].float().flatten()[::61]
+        ref = T(t["w_%d" % i])
+        assert float((got.reshape(ref.shape) - ref).abs().max()) <= bar * float(ref.abs().max()), k
+    # G12L: the two-head model
+    g2 = H.load_golden("g12l_multihead")
+    assert float(g2["relu_margin"]) >= 64.0 and float(g2["relu_margin_over_noise"]) >= 6.0
+    m2 = O.deeplabv3plus_embedding_self_distillation_resnet101(output_stride=16)
+    sd2 = H.conditioned_state_dict(H.shapes_of(m2), 12, g2["beta_idx"], g2["beta_val"])
+    assert len(sd2) == int(g2["n_keys"]) and list(sd2.keys())[-4:] == [str(k) for k in g2["keys"]]
+    m2.load_state_dict(sd2)
+    m2.train()
+    m2.classifier.aspp.project[3].eval()
+    m2.classifier_1.aspp.project[3].eval()
+    img2 = H.synth_tensor(12, "g12l.img", (2, 3, 128, 128))
+    lab2 = H.synth_labels(12, "g12l.lab", (2, 128, 128), 17, 255, ignore_rows=5)
+    logits, centers, feats = m2(img2)
+    loss2 = O.ce_over_n(logits[-1], lab2, 255)
+    loss2.backward()
+    close(logits[0][:, :, ::4, ::4], T(g2["logits0_sub"]), 1e-5)
+    close(logits[1][:, :, ::4, ::4], T(g2["logits1_sub"]), 1e-5)
+    close(loss2, T(g2["loss"]), 1e-6)
+    live = OrderedDict((k, p.grad) for k, p in m2.named_parameters() if p.grad is not None)
+    assert [str(n) for n in g2["grad_names"]] == list(live.keys())
+    for (k, gr), cs in zip(live.items(), g2["grad_checksums"]):
+        assert np.allclose(H.checksum(gr)[1:], cs[1:], rtol=3e-4), k
+
+
 def load_bn_stats(model, flat):
     off = 0
     sd = model.state_dict()

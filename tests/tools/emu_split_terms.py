@@ -6,6 +6,7 @@ gradient) see operands truncated to `terms` bf16 terms; everything else stays fp
 reference-minted g5_full_train fixture exactly as tests/test_gpu_model.py::test_g5_full_train_step_matches_reference does.
 
     python tests/tools/emu_split_terms.py 2      (or 3, or h2: two fp16 terms of the power-of-two-scaled tensor)
+    python tests/tools/emu_split_terms.py h2 g5l (the conditioned 128 x 128 fixture of tests/tools/mint_golden_large.py)
 """
 import os
 import sys
@@ -66,7 +67,42 @@ def patch(model):
             m.forward = (lambda mod: lambda x: SplitConv.apply(x, mod.weight, mod.bias, mod.stride, mod.padding, mod.dilation))(m)
 
 
+def main_large():
+    """the conditioned fixture: same checks as tests/test_gpu_model.py::test_g5l_full_train_step_matches_reference"""
+    torch.manual_seed(0)
+    g = H.load_golden("g5l_full_train")
+    m = R.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    m.load_state_dict(H.conditioned_state_dict(H.shapes_of(m), 1, g["beta_idx"], g["beta_val"]))
+    m.train()
+    m.classifier.aspp.project[3].eval()
+    R.set_bn_momentum(m.backbone, 0.01)
+    patch(m)
+    img = H.synth_tensor(5, "g5l.img", (2, 3, 128, 128))
+    lab = H.synth_labels(5, "g5l.lab", (2, 128, 128), 16, 255, ignore_rows=5)
+    lg, ctr, ft = m(img)
+    loss = R.ce_over_n(lg, lab, 255)
+    loss.backward()
+    T = torch.from_numpy
+    print("mode", MODE, "fixture g5l")
+    print("logits rel err vs fp32 ref %.3e (bar 1e-3)" % H.rel_err(lg[:, :, ::4, ::4], T(g["logits_sub"])))
+    print("loss rel %.3e" % (abs(loss.item() - float(g["loss"])) / abs(float(g["loss"]))))
+    grads = OrderedDict((k, p.grad) for k, p in m.named_parameters())
+    rels = []
+    for (k, gr), cs in zip(grads.items(), g["grad_checksums"]):
+        got = H.checksum(gr)
+        rels.append((np.abs(got[1:] - cs[1:]) / (np.abs(cs[1:]) + 1e-300)).max())
+    rels = np.array(rels)
+    print("gradient checksums: worst rel %.3e median %.3e, %d of %d beyond 2e-3" % (rels.max(), np.median(rels), (rels > 2e-3).sum(), len(rels)))
+    for key in [str(k) for k in g["grad_keep"]]:
+        ref = T(g["grad__" + key.replace(".", "_")])
+        got = grads[key].detach()
+        got = got if got.numel() < 70000 else got.contiguous().flatten()[::61]
+        print("  grad %-40s rel %.3e (bar 2e-3)" % (key, H.rel_err(got.reshape(ref.shape), ref)))
+
+
 def main():
+    if len(sys.argv) > 2 and sys.argv[2] == "g5l":
+        return main_large()
     torch.manual_seed(0)
     g = H.load_golden("g5_full_train")
     m = R.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
