@@ -1322,7 +1322,7 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
 constexpr int WS_STAT_ROWS_C = 48;             // (= WS_STAT_ROWS, declared below)
 template <int NT, int MODE>
 __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
-                                                   const int lane, char* stage) {
+                                                   const int lane, char* stage, char* mstage) {
     static_assert(NT == 4, "64-channel wave tile");
     const int lr = lane & 15, lq = lane >> 4;
     if (MODE == 0 && a.stats != nullptr) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
@@ -1367,12 +1367,40 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
     auto body = [&](auto ho, auto bn) {
         constexpr bool HO = decltype(ho)::value, BNR = decltype(bn)::value;
         float4 old[2][4], yv[2][4];
-        uint32_t mb[2][4];
         float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1, mu = r1, is = r1;
         uint32_t gmx = 0;
         if (BNR) {
             mu = *reinterpret_cast<const float4*>(a.bnr_mean + c0);
             is = *reinterpret_cast<const float4*>(a.bnr_invstd + c0);
+        }
+        // ReLU masks of the sub-tile (one byte per four channels, low nibble): lane L < 48 fetches row L's 16 mask bytes -- this wave's
+        // 64 channels -- of each mask with ONE 16-byte load, packs them (identity-branch mask: low nibble, BatchNorm mask: high
+        // nibble) and parks the 768 bytes in the wave's mask area behind the ring; the row loop reads its byte back.  Per-lane byte
+        // loads were one VMEM instruction per mask and four rows -- 24 of the ~60 of a sub-tile -- and the texture addresser pays
+        // per instruction, not per byte.
+        const bool use_rm = HO && resm, use_bm = BNR && a.bnr_relu != 0;
+        // byte of row (4 c + (lane >> 4)), chunk (lane & 15) = mstage[64 c + lane]: one base, compile-time offsets (computed here, from
+        // a lane index the optimiser cannot see through -- hoisted to the head of the kernel the twelve row offsets get spilled, and a
+        // scratch reload inside the row loop waits vmcnt(0), i.e. for every store in flight)
+        int lane_m = lane;
+        asm volatile("" : "+v"(lane_m));
+        const char* const mrd = mstage + lane_m;
+        if (use_rm || use_bm) {
+            if (lane < WS_STAT_ROWS_C) {
+                const int m = mw0 + lane;
+                uint4 rv = make_uint4(0x0f0f0f0fu, 0x0f0f0f0fu, 0x0f0f0f0fu, 0x0f0f0f0fu), bv = rv;
+                if (m < a.M) {
+                    const int64_t mo = (int64_t)m * (a.N >> 2) + (nw0 >> 2);
+                    if (use_rm) rv = *reinterpret_cast<const uint4*>(a.res_mask + mo);
+                    if (use_bm) bv = *reinterpret_cast<const uint4*>(a.bnr_mask + mo);
+                }
+                uint4 pk;
+                pk.x = (rv.x & 0x0f0f0f0fu) | ((bv.x & 0x0f0f0f0fu) << 4);
+                pk.y = (rv.y & 0x0f0f0f0fu) | ((bv.y & 0x0f0f0f0fu) << 4);
+                pk.z = (rv.z & 0x0f0f0f0fu) | ((bv.z & 0x0f0f0f0fu) << 4);
+                pk.w = (rv.w & 0x0f0f0f0fu) | ((bv.w & 0x0f0f0f0fu) << 4);
+                *reinterpret_cast<uint4*>(mstage + lane * 16) = pk;
+            }
         }
         auto load_ops = [&](const int g4) {
 #pragma unroll
@@ -1380,22 +1408,12 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
                 const int m = mw0 + (g4 * 4 + u) * 4 + (lane >> 4);
                 old[g4 & 1][u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 yv[g4 & 1][u] = old[g4 & 1][u];
-                mb[g4 & 1][u] = 0xfu;
                 if (m < a.M) {
                     if (HO) {
-                        if (resm) {
-                            float4 t = *reinterpret_cast<const float4*>(static_cast<const float*>(a.res_dz) + (int64_t)m * a.res_ld + c0);
-                            const uint32_t rb = a.res_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
-                            t.x = (rb & 1u) ? t.x : 0.f; t.y = (rb & 2u) ? t.y : 0.f; t.z = (rb & 4u) ? t.z : 0.f; t.w = (rb & 8u) ? t.w : 0.f;
-                            old[g4 & 1][u] = t;
-                        } else {
-                            old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
-                        }
+                        if (resm) old[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.res_dz) + (int64_t)m * a.res_ld + c0);
+                        else old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
                     }
-                    if (BNR) {
-                        yv[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + (int64_t)m * a.bnr_ldy + c0);
-                        if (a.bnr_relu) mb[g4 & 1][u] = a.bnr_mask[(int64_t)m * (a.N >> 2) + (c0 >> 2)];
-                    }
+                    if (BNR) yv[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + (int64_t)m * a.bnr_ldy + c0);
                 }
             }
         };
@@ -1408,10 +1426,18 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
                 const int r = (g4 * 4 + u) * 4 + (lane >> 4), m = mw0 + r;
                 if (m >= a.M) continue;
                 float4 o = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
-                if (HO) { o.x += old[g4 & 1][u].x; o.y += old[g4 & 1][u].y; o.z += old[g4 & 1][u].z; o.w += old[g4 & 1][u].w; }
+                uint32_t pkb = 0xffu;
+                if (use_rm || use_bm) pkb = *reinterpret_cast<const uint8_t*>(mrd + (g4 * 4 + u) * 64);
+                if (HO) {
+                    float4 t = old[g4 & 1][u];
+                    if (resm) {
+                        t.x = (pkb & 1u) ? t.x : 0.f; t.y = (pkb & 2u) ? t.y : 0.f; t.z = (pkb & 4u) ? t.z : 0.f; t.w = (pkb & 8u) ? t.w : 0.f;
+                    }
+                    o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+                }
                 st16f(yb + (int64_t)m * a.ldy + c0, o.x, o.y, o.z, o.w, (a.nt_out & 1) != 0);
                 if (BNR) {
-                    const uint32_t bits = mb[g4 & 1][u];
+                    const uint32_t bits = pkb >> 4;
                     const float4 y4 = yv[g4 & 1][u];
                     const float g0 = (bits & 1u) ? o.x : 0.f, g1 = (bits & 2u) ? o.y : 0.f, g2 = (bits & 4u) ? o.z : 0.f,
                                 g3 = (bits & 8u) ? o.w : 0.f;
@@ -1720,7 +1746,10 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     // (forward only: nearly every data gradient of a plan carries epilogue operands -- accumulate, fused BN-backward sums -- whose
     // loads want the deeper row groups of conv_epilogue_rows, and both epilogues in one kernel spill 300 bytes per lane)
     constexpr bool PRIV_STAGE = PL == 2 && MW == 1 && MODE == 0;
-    __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64 + (PRIV_STAGE ? NCW * 2048 : 0)];
+    // (two planes, data gradient: 768 bytes per consumer wave for the ReLU masks of a 48-row sub-tile, conv_epilogue_rows)
+    constexpr int MASK_STAGE = (PL == 2 && !PRIV_STAGE) ? WS_STAT_ROWS * 16 : 0;
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64 + (PRIV_STAGE ? NCW * 2048 : NCW * MASK_STAGE)];
+    static_assert(sizeof(smem) <= 160 * 1024, "LDS of one CU");
     uint32_t* const ready = reinterpret_cast<uint32_t*>(smem + NST * SB);          // [NLD] stages landed, per loader
     uint32_t* const consumed = ready + 4;                                          // [4] stages whose reads were issued
 
@@ -1946,7 +1975,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             } else if (priv) {
                 if constexpr (PRIV_STAGE) conv_epilogue_rows8<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
             } else {
-                conv_epilogue_rows<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
+                conv_epilogue_rows<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage, smem + NST * SB + 64 + wave * MASK_STAGE);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // its reads of the staging area, before the next group's writes
             }
 #pragma unroll
@@ -3522,8 +3551,8 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
                 (reinterpret_cast<uintptr_t>(d->res_dz) & 15) || d->N <= 32)
                 return DML_EALIGN;
             if ((d->N & 63) == 0 && (reinterpret_cast<uintptr_t>(d->res_mask) & 7)) return DML_EALIGN;      // 8-byte mask rows
-        } else if (d->N % 64 || d->res_ld % 4 || (reinterpret_cast<uintptr_t>(d->res_dz) & 15)) {
-            return DML_EALIGN;
+        } else if (d->N % 64 || d->res_ld % 4 || ((reinterpret_cast<uintptr_t>(d->res_dz) | reinterpret_cast<uintptr_t>(d->res_mask)) & 15)) {
+            return DML_EALIGN;      // (16 mask bytes per pixel row and 64 channels are one load)
         }
         a.res_dz = d->res_dz; a.res_mask = d->res_mask; a.res_ld = d->res_ld;
     }
@@ -3552,7 +3581,8 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
         } else {
             if (d->N % 64 || d->bnr_ldy % 4) return DML_EUNSUPPORTED;
             if (((reinterpret_cast<uintptr_t>(d->bnr_y) | reinterpret_cast<uintptr_t>(d->bnr_partials) |
-                  reinterpret_cast<uintptr_t>(d->bnr_mean) | reinterpret_cast<uintptr_t>(d->bnr_invstd)) & 15) != 0)
+                  reinterpret_cast<uintptr_t>(d->bnr_mean) | reinterpret_cast<uintptr_t>(d->bnr_invstd) |
+                  (d->bnr_relu ? reinterpret_cast<uintptr_t>(d->bnr_mask) : 0)) & 15) != 0)
                 return DML_EALIGN;
             a.bnr_gmax = d->bnr_gmax;
         }

@@ -904,11 +904,12 @@ class Plan:
               and u3.relu and u3.mask is not None and u3.drop is None and xb.C % 8 == 0 and xb.C > 32
               and dz.ld == xb.C and self.conv_geom(u1.conv, xb)[:3] == (1, 1, 1)
               and (self.dtype == torch.bfloat16
-                   # f16x2 (conv1's data gradient on the two-plane kernel takes res_* too): OFF unless DML_FUSE_RES_GRAD=2 -- the
-                   # persistent kernel's consumers read the extra operand at 7-10 B/clk/CU with the matrix cores idle, the BatchNorm
-                   # apply kernel writes the masked copy at 5.7 TB/s beside the weight gradients: 183.5 images/s without, 179.0 with
-                   or (os.environ.get("DML_FUSE_RES_GRAD") == "2" and self.h2_direct_on
-                       and self.h2_ok(u1.conv.out_channels, xb.C, 1) and xb.C % 64 == 0
+                   # f16x2: conv1's data gradient on the two-plane kernel takes res_* too.  (Round 4 measured this as a LOSS, 183.5 ->
+                   # 179.0 images/s: the row epilogue fetched its ReLU masks with one byte load per lane and four rows, a third of
+                   # its memory instructions.  With the masks of a sub-tile in one 16-byte load per row, conv_epilogue_rows, it wins:
+                   # 187.6 -> 190.1 images/s, three interleaved rounds, profiles/r05_ab_maskvec_res.txt; without the fusion that
+                   # change alone is +0.3 %.)  DML_FUSE_RES_GRAD=0: off
+                   or (self.h2_direct_on and self.h2_ok(u1.conv.out_channels, xb.C, 1) and xb.C % 64 == 0
                        and self.planes_fit(u1.y.M, u1.conv.out_channels)))):
             # The masked output gradient is this block's contribution to d(xb) through the identity branch.  Instead
             # of having the BN-backward apply write that copy (75 MB per layer3 block) for conv1's data gradient to
