@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DML_ABI_VERSION 3
+#define DML_ABI_VERSION 4
 
 enum { DML_F32 = 0, DML_BF16 = 1 };
 enum { DML_EINVAL = -1, DML_EALIGN = -2, DML_EUNSUPPORTED = -3 };
@@ -295,11 +295,13 @@ int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, void* stream
  * `planes` (optional, DML_F32): the output also as the two fp16 planes a conv of the f16x2 mode reads (dml_h2_split's arithmetic and
  * layout 0: hi at planes[m * ldp + c], lo `plane_stride` elements further), scaled by 1 / unscale[0], a power of two the caller
  * fixed BEFORE this launch from a bound on |z| (dml_h2_bound_bn) -- no dml_h2_split pass over z then; z may be NULL when nothing
- * reads the fp32 tensor. */
+ * reads the fp32 tensor.  `res_unscale` (optional, DML_F32; ABI 4): the residual operand exists as fp16 planes only -- `res` then
+ * points at its hi plane (pitch ldres, lo plane `res_plane_stride` elements further) and the value added is (hi + lo) *
+ * res_unscale[0], exactly what the convolutions reading those planes see. */
 int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
                  const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
                  int dtype, float drop_p, uint64_t drop_seed, float* amax, void* planes, int64_t plane_stride,
-                 int32_t ldp, const float* unscale, void* stream);
+                 int32_t ldp, const float* unscale, int64_t res_plane_stride, const float* res_unscale, void* stream);
 /* backward, pass 1: per-channel sums of g = dz*[z>0]*gscale and g*xhat -> partials[blocks][N][2]
  * ([z>0] from `mask` when given, else from z).
  * returns the number of partial rows through *nblocks (host int).  `gmax` (optional): 1024 zeroed floats, their maximum

@@ -180,9 +180,13 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
     const T* __restrict__ y, const T* __restrict__ res, T* __restrict__ z, const float* __restrict__ scale,
     const float* __restrict__ shift, const float* __restrict__ mean, uint8_t* __restrict__ mask, int64_t M, int N,
     int ldy, int ldres, int ldz, int relu, float drop_p, uint64_t drop_seed, int CB, int RB, int rows_per_block,
-    uint32_t* __restrict__ amax, _Float16* __restrict__ planes, int64_t plane_stride, int ldp, const float* __restrict__ unscale) {
+    uint32_t* __restrict__ amax, _Float16* __restrict__ planes, int64_t plane_stride, int ldp, const float* __restrict__ unscale,
+    const _Float16* __restrict__ res_planes, int64_t res_plane_stride, const float* __restrict__ res_unscale) {
     constexpr int V = Vec16<T>::N;
     const float h2s = planes != nullptr ? 1.0f / unscale[0] : 1.0f;      // exact: a power of two
+    // the residual operand as the two fp16 planes of a tensor that exists as planes only (pitch ldres): value = (hi + lo) / s,
+    // exact in fp32 (hi + lo has at most 23 significant bits, 1 / s is a power of two)
+    const float rsu = res_planes != nullptr ? res_unscale[0] : 1.0f;
     const int NV = N / V;
     const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
     const int vcol = blockIdx.y * CB + col;
@@ -205,6 +209,15 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
             if (m < r1) {
                 Vec16<T>::load(y + m * ldy + c, v[u]);
                 if (res != nullptr) Vec16<T>::load(res + m * ldres + c, r[u]);
+                if constexpr (V == 4) {
+                    if (res_planes != nullptr) {
+                        typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+                        const h4 rh = *reinterpret_cast<const h4*>(res_planes + m * ldres + c);
+                        const h4 rl4 = *reinterpret_cast<const h4*>(res_planes + res_plane_stride + m * ldres + c);
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) r[u][q] = ((float)rh[q] + (float)rl4[q]) * rsu;
+                    }
+                }
             }
         }
 #pragma unroll
@@ -213,7 +226,7 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
             if (m >= r1) continue;
 #pragma unroll
             for (int q = 0; q < V; ++q) v[u][q] = (v[u][q] - mu[q]) * sc[q] + sh[q];
-            if (res != nullptr) {
+            if (res != nullptr || res_planes != nullptr) {
 #pragma unroll
                 for (int q = 0; q < V; ++q) v[u][q] += r[u][q];
             }
@@ -237,6 +250,98 @@ __global__ __launch_bounds__(256) void bn_apply_cols_kernel(
             if (amax != nullptr) {
 #pragma unroll
                 for (int q = 0; q < V; ++q) amx = max(amx, __float_as_uint(v[u][q]) & 0x7fffffffu);
+            }
+        }
+    }
+    if (amax != nullptr) amax_publish(amx, amax);
+}
+
+// The same for the launches of an f16x2 plan whose output exists as planes ONLY (z == NULL: every conv1 / conv2 input and, since
+// round 5, the block outputs): EIGHT channels per thread, so that every access is a 16-byte vector -- y as two float4, the
+// planes (and a residual operand that is itself planes) as 8 x fp16 -- where the 4-channel kernel moves the planes in 8-byte
+// pieces (0.54-0.70 x the 16-byte rate per instruction, MI355X_MICROARCH.md).  The mask stays one byte per four channels: two
+// bytes per thread and row, one 2-byte store.
+template <int U>
+__global__ __launch_bounds__(256) void bn_apply_planes8_kernel(
+    const float* __restrict__ y, const float* __restrict__ res, const _Float16* __restrict__ res_planes, int64_t res_plane_stride,
+    const float* __restrict__ res_unscale, const float* __restrict__ scale, const float* __restrict__ shift,
+    const float* __restrict__ mean, uint8_t* __restrict__ mask, int64_t M, int N, int ldy, int ldres, int relu, int CB, int RB,
+    int rows_per_block, uint32_t* __restrict__ amax, _Float16* __restrict__ planes, int64_t plane_stride, int ldp,
+    const float* __restrict__ unscale) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int V = 8;
+    const float h2s = 1.0f / unscale[0];      // exact: a power of two
+    const float rsu = res_planes != nullptr ? res_unscale[0] : 1.0f;
+    const int NV = N / V;
+    const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
+    const int vcol = blockIdx.y * CB + col;
+    const bool act = rl < RB && vcol < NV;
+    if (!act && amax == nullptr) return;
+    const int c = act ? vcol * V : 0;
+    uint32_t amx = 0;
+    float sc[V], sh[V], mu[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) { sc[q] = scale[c + q]; sh[q] = shift[c + q]; mu[q] = mean[c + q]; }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = act ? min(M, r0 + rows_per_block) : 0;
+    for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)RB * U) {
+        float4 va[U], vb[U], ra[U], rb[U];
+        h8 rh[U], rlo[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            if (m < r1) {
+                va[u] = *reinterpret_cast<const float4*>(y + m * ldy + c);
+                vb[u] = *reinterpret_cast<const float4*>(y + m * ldy + c + 4);
+                if (res != nullptr) {
+                    ra[u] = *reinterpret_cast<const float4*>(res + m * ldres + c);
+                    rb[u] = *reinterpret_cast<const float4*>(res + m * ldres + c + 4);
+                }
+                if (res_planes != nullptr) {
+                    rh[u] = *reinterpret_cast<const h8*>(res_planes + m * ldres + c);
+                    rlo[u] = *reinterpret_cast<const h8*>(res_planes + res_plane_stride + m * ldres + c);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            if (m >= r1) continue;
+            float v[V] = {va[u].x, va[u].y, va[u].z, va[u].w, vb[u].x, vb[u].y, vb[u].z, vb[u].w};
+#pragma unroll
+            for (int q = 0; q < V; ++q) v[q] = (v[q] - mu[q]) * sc[q] + sh[q];
+            if (res != nullptr) {
+                const float r[V] = {ra[u].x, ra[u].y, ra[u].z, ra[u].w, rb[u].x, rb[u].y, rb[u].z, rb[u].w};
+#pragma unroll
+                for (int q = 0; q < V; ++q) v[q] += r[q];
+            }
+            if (res_planes != nullptr) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) v[q] += ((float)rh[u][q] + (float)rlo[u][q]) * rsu;
+            }
+            if (relu) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) v[q] = v[q] > 0.f ? v[q] : 0.f;
+            }
+            h8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const float xs = v[q] * h2s;
+                const _Float16 h = (_Float16)xs;
+                hi[q] = h;
+                lo[q] = (_Float16)(xs - (float)h);
+            }
+            *reinterpret_cast<h8*>(planes + m * ldp + c) = hi;
+            *reinterpret_cast<h8*>(planes + plane_stride + m * ldp + c) = lo;
+            if (mask != nullptr) {           // one byte per four channels (the fp32 plans' layout): two bytes per thread
+                uint32_t bits = 0;
+#pragma unroll
+                for (int q = 0; q < V; ++q) bits |= (v[q] > 0.f ? 1u : 0u) << (q + (q >= 4 ? 4 : 0));
+                *reinterpret_cast<uint16_t*>(mask + m * (N / 4) + vcol * 2) = (uint16_t)bits;
+            }
+            if (amax != nullptr) {
+#pragma unroll
+                for (int q = 0; q < V; ++q) amx = max(amx, __float_as_uint(v[q]) & 0x7fffffffu);
             }
         }
     }
@@ -655,8 +760,18 @@ extern "C" int dml_bn_eval_coeffs_table(const DmlBnEvalDesc* table, int count, v
 extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float* scale, const float* shift,
                             const float* mean, uint8_t* mask, int64_t M, int N, int ldy, int ldres, int ldz, int relu,
                             int dtype, float drop_p, uint64_t drop_seed, float* amax, void* planes, int64_t plane_stride,
-                            int32_t ldp, const float* unscale, void* stream) {
+                            int32_t ldp, const float* unscale, int64_t res_plane_stride, const float* res_unscale, void* stream) {
     if (!y || (!z && !planes) || !scale || !shift || !mean || M <= 0 || N <= 0) return DML_EINVAL;
+    // res_unscale != NULL: `res` points at the fp16 planes (hi, then lo `res_plane_stride` elements further, pitch ldres) of a
+    // residual tensor that exists as planes only
+    const void* res_pl = nullptr;
+    if (res_unscale) {
+        if (dtype != DML_F32 || !res || res_plane_stride <= 0 || (res_plane_stride & 3) || (ldres & 3) ||
+            (reinterpret_cast<uintptr_t>(res) & 7))
+            return DML_EINVAL;
+        res_pl = res;
+        res = nullptr;
+    }
     if (!vec_ok(dtype, N) || !vec_ok(dtype, ldy) || (z && !vec_ok(dtype, ldz)) || (res && !vec_ok(dtype, ldres)))
         return DML_EALIGN;
     if (M >= (1ll << 31)) return DML_EINVAL;
@@ -666,18 +781,31 @@ extern "C" int dml_bn_apply(const void* y, const void* res, void* z, const float
     }
     const int V = dtype == DML_BF16 ? 8 : 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_F32 && planes && !z && drop_p == 0.f && (N & 7) == 0 && (ldy & 3) == 0 && (ldp & 7) == 0 && (plane_stride & 7) == 0 &&
+        (reinterpret_cast<uintptr_t>(planes) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0 &&
+        (!res || ((ldres & 3) == 0 && (reinterpret_cast<uintptr_t>(res) & 15) == 0)) &&
+        (!res_pl || ((ldres & 7) == 0 && (res_plane_stride & 7) == 0 && (reinterpret_cast<uintptr_t>(res_pl) & 15) == 0))) {
+        // planes-only output: eight channels per thread, 16-byte accesses throughout
+        const ColGeom g8 = col_geom(M, N / 8, 2, stream_blocks(M, N, dtype));
+        hipLaunchKernelGGL((bn_apply_planes8_kernel<2>), dim3(g8.row_blocks, g8.col_chunks), dim3(256), 0, st, (const float*)y,
+                           (const float*)res, static_cast<const _Float16*>(res_pl), res_plane_stride, res_unscale, scale, shift, mean,
+                           mask, M, N, ldy, ldres, relu, g8.CB, g8.RB, g8.rows_per_block, reinterpret_cast<uint32_t*>(amax),
+                           static_cast<_Float16*>(planes), plane_stride, (int)ldp, unscale);
+        DML_LAUNCH_CHECK();
+        return 0;
+    }
     const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype));
     dim3 grid(g.row_blocks, g.col_chunks);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL((bn_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)y, (const bf16_t*)res,
                            (bf16_t*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
                            g.rows_per_block, reinterpret_cast<uint32_t*>(amax), (_Float16*)nullptr, (int64_t)0, 0,
-                           (const float*)nullptr);
+                           (const float*)nullptr, (const _Float16*)nullptr, (int64_t)0, (const float*)nullptr);
     else
         hipLaunchKernelGGL((bn_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)y, (const float*)res,
                            (float*)z, scale, shift, mean, mask, M, N, ldy, ldres, ldz, relu, drop_p, drop_seed, g.CB, g.RB,
                            g.rows_per_block, reinterpret_cast<uint32_t*>(amax), static_cast<_Float16*>(planes), plane_stride,
-                           (int)ldp, unscale);
+                           (int)ldp, unscale, static_cast<const _Float16*>(res_pl), res_plane_stride, res_unscale);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -1583,13 +1583,13 @@ __device__ __forceinline__ int ws_tile_n(const int tile, const ConvArgs& a) {
 
 // loader wave LW of NLD: compile-time piece ownership (no branches in the issue loop)
 // PL = 2: every operand tile is two planes (hi, lo fp16 of the scaled fp32 tensor); a stage = [A hi | A lo | B hi | B lo]
-template <int MW, int NW, int MODE, int NLD, int LW, int PL>
+template <int MW, int NW, int MODE, int NLD, int LW, int PL, int MT = WS_MT>
 __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t x_bytes, const uint32_t w_bytes, char* smem,
                                                uint32_t* ready, uint32_t* consumed, const int lane, const int ntiles,
                                                const int first_tile) {
     typedef bf16_t T;
     constexpr int NCW = 4, NT = 4;
-    constexpr int BM = 16 * WS_MT * MW, BN = 64 * NW;
+    constexpr int BM = 16 * MT * MW, BN = 64 * NW;
     constexpr int PA = BM / 16, PB = BN / 16, NP = PL * (PA + PB);
     constexpr int SB = PL * (BM + BN) * BK * 2;
     constexpr int MYP = (NP - LW + NLD - 1) / NLD;
@@ -1734,11 +1734,12 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
 
 typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
 
-template <int MW, int NW, int MODE, int NLD, int PL = 1>
+template <int MW, int NW, int MODE, int NLD, int PL = 1, int MT = WS_MT>
 __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs a, const uint32_t x_bytes, const uint32_t w_bytes) {
     typedef bf16_t T;
     static_assert(MW * NW == 4, "four consumer waves, one per SIMD");
-    constexpr int NCW = 4, NT = 4, MT = WS_MT, NST = PL == 1 ? WS_NST : 3;
+    static_assert(MT % 3 == 0 && MT >= 3, "48-row sub-tiles (statistics groups, row epilogue)");
+    constexpr int NCW = 4, NT = 4, NST = PL == 1 ? WS_NST : 3;
     constexpr int BM = 16 * MT * MW, BN = 64 * NW;
     constexpr int SB = PL * (BM + BN) * BK * 2;
     // two planes, 144 x 256: 2 KB of private staging per consumer wave behind the flags (conv_epilogue_rows8); the 288 x 128
@@ -1746,9 +1747,13 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     // (forward only: nearly every data gradient of a plan carries epilogue operands -- accumulate, fused BN-backward sums -- whose
     // loads want the deeper row groups of conv_epilogue_rows, and both epilogues in one kernel spill 300 bytes per lane)
     constexpr bool PRIV_STAGE = PL == 2 && MW == 1 && MODE == 0;
+    // two planes, 192 x 64 (MW = 4, MT = 3: the 64-channel layers; 48 x 64 wave tiles): its ring is 3 x 32 KB, so the row epilogue's
+    // 12 KB per wave sit BESIDE the ring in both directions -- no held-back slot, no consumer barrier (conv_epilogue_rows)
+    constexpr bool PRIV_ROWS = PL == 2 && MW == 4;
+    constexpr int ROWS_STAGE = PRIV_ROWS ? WS_STAT_ROWS * 256 : 0;
     // (two planes, data gradient: 768 bytes per consumer wave for the ReLU masks of a 48-row sub-tile, conv_epilogue_rows)
     constexpr int MASK_STAGE = (PL == 2 && !PRIV_STAGE) ? WS_STAT_ROWS * 16 : 0;
-    __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64 + (PRIV_STAGE ? NCW * 2048 : NCW * MASK_STAGE)];
+    __shared__ __attribute__((aligned(1024))) char smem[NST * SB + 64 + (PRIV_STAGE ? NCW * 2048 : NCW * (MASK_STAGE + ROWS_STAGE))];
     static_assert(sizeof(smem) <= 160 * 1024, "LDS of one CU");
     uint32_t* const ready = reinterpret_cast<uint32_t*>(smem + NST * SB);          // [NLD] stages landed, per loader
     uint32_t* const consumed = ready + 4;                                          // [4] stages whose reads were issued
@@ -1764,17 +1769,17 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 
     if (wave >= NCW) {
         const int lw = wave - NCW;
-        if (lw == 0) conv_ws_loader<MW, NW, MODE, NLD, 0, PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
-        if (NLD > 1 && lw == 1) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 1 ? 1 : 0), PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
-        if (NLD > 2 && lw == 2) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 2 ? 2 : 0), PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
-        if (NLD > 3 && lw == 3) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 3 ? 3 : 0), PL>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (lw == 0) conv_ws_loader<MW, NW, MODE, NLD, 0, PL, MT>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 1 && lw == 1) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 1 ? 1 : 0), PL, MT>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 2 && lw == 2) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 2 ? 2 : 0), PL, MT>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
+        if (NLD > 3 && lw == 3) conv_ws_loader<MW, NW, MODE, NLD, (NLD > 3 ? 3 : 0), PL, MT>(a, x_bytes, w_bytes, smem, ready, consumed, lane, ntiles, first_tile);
         return;
     }
 
     // ---------------------------------------------------------------------- consumer
     const int wm = wave / NW, wn = wave % NW;
     const int lr = lane & 15, lq = lane >> 4;
-    constexpr bool priv = PRIV_STAGE;
+    constexpr bool priv = PRIV_STAGE || PRIV_ROWS;      // the epilogue stages beside the ring: a tile's last stage is released like any other
     uint32_t g = 0, rflag = 0, tiles_done = 0;
     uint32_t* const edone = consumed + 4;                  // [4] tiles whose last fragment reads were issued, per consumer wave
     auto read_ready = [&]() -> uint32_t {
@@ -1806,7 +1811,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 #pragma unroll
         for (int i = 0; i < NT; ++i) b_off[i] = PL * BM * BK * 2 + (wn * 64 + b_row<NT>(i, lr_k)) * (BK * 2) + swz_chunk<T>(lr_k, lq_k) * 16;
         // accumulators by 48-row sub-tile: ACC(i, j) = acc3[j / 3][i][j % 3], so that the epilogue takes a sub-tile by reference
-        f32x4 acc3[3][NT][3];
+        f32x4 acc3[MT / 3][NT][3];
 #define ACC(i, j) acc3[(j) / 3][i][(j) % 3]
 #pragma unroll
         for (int i = 0; i < NT; ++i)
@@ -1894,17 +1899,19 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                         ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
                         al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
                     }
-                    if (j == 1) {                           // the next step's poll, answered under the MFMAs
+                    // (positions inside the step: row group 1 / 4 / 5 of the nine of a 144-row wave tile, 0 / 1 / 2 of a 48-row one)
+                    constexpr int JP = MT >= 9 ? 1 : 0, JW = MT >= 9 ? 4 : 1, JB = MT >= 9 ? 5 : MT - 1;
+                    if (j == JP) {                          // the next step's poll, answered under the MFMAs
 #pragma unroll
                         for (int w = 0; w < NLD; ++w) pl[w] = ws_ld(ready + w);
                     }
-                    if (j == 4) {
+                    if (j == JW) {
                         rflag = pl[0];
 #pragma unroll
                         for (int w = 1; w < NLD; ++w) rflag = min(rflag, pl[w]);
                         if (has_next) wait_ready(g + 2);
                     }
-                    if (j == 5) {
+                    if (j == JB) {
 #pragma unroll
                         for (int i = 0; i < NT; ++i) bn[i] = WS_FRAG(sn + b_off[i]);
                     }
@@ -1944,7 +1951,8 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         // (three explicit copies: hipcc does not unroll a loop around the inlined epilogue, and a run-time index into acc
         // sends all 36 accumulator fragments through scratch memory -- 37 MB written and read back per launch, +25 us)
         char* rows_stage = nullptr;
-        if (priv) rows_stage = smem + NST * SB + 64 + wave * 2048;
+        if (PRIV_STAGE) rows_stage = smem + NST * SB + 64 + wave * 2048;
+        if (PRIV_ROWS) rows_stage = smem + NST * SB + 64 + NCW * MASK_STAGE + wave * ROWS_STAGE;
         if (PL == 2 && !priv) {
             // the slot of the tile's last K step becomes the staging area of conv_epilogue_rows (12 KB per wave): every consumer
             // wave must have issued its last fragment reads first
@@ -1965,28 +1973,31 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         // between (2 x 96 register moves): three inlined copies -- what a compile-time sub-tile index costs; a run-time index into
         // acc would send all of it through scratch memory -- made these kernels 10-19 K instructions, more than the instruction
         // cache two CUs share.
-        static_assert(MT == 9, "three 48-row groups per wave tile");
 #pragma clang loop unroll(disable)
-        for (int h = 0; h < 3; ++h) {
+        for (int h = 0; h < MT / 3; ++h) {
             const int mw0 = blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, nw0 = blk_n * BN + wn * 64;
             if constexpr (PL == 1) conv_epilogue<bf16_t, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);
             else if (MODE == 0 && (a.bias != nullptr || a.post_scale != nullptr)) {
                 conv_epilogue<float, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);      // (inference epilogue, bias: scattered stores)
-            } else if (priv) {
+            } else if (PRIV_STAGE) {
                 if constexpr (PRIV_STAGE) conv_epilogue_rows8<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
             } else {
                 conv_epilogue_rows<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage, smem + NST * SB + 64 + wave * MASK_STAGE);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // its reads of the staging area, before the next group's writes
             }
+            if constexpr (MT == 9) {
 #pragma unroll
-            for (int i = 0; i < NT; ++i)
+                for (int i = 0; i < NT; ++i)
 #pragma unroll
-                for (int j = 0; j < 3; ++j) {
-                    acc3[0][i][j] = acc3[1][i][j];
-                    acc3[1][i][j] = acc3[2][i][j];
-                    // (keeps the loop a loop: the optimiser must not see through the rotation and re-specialise the three trips)
-                    asm volatile("" : "+v"(acc3[0][i][j]), "+v"(acc3[1][i][j]));
-                }
+                    for (int j = 0; j < 3; ++j) {
+                        acc3[0][i][j] = acc3[1][i][j];
+                        acc3[1][i][j] = acc3[2][i][j];
+                        // (keeps the loop a loop: the optimiser must not see through the rotation and re-specialise the three trips)
+                        asm volatile("" : "+v"(acc3[0][i][j]), "+v"(acc3[1][i][j]));
+                    }
+            } else {
+                static_assert(MT == 9 || MT == 3, "accumulator rotation of the sub-tile loop");
+            }
         }
 #undef ACC
         if (PL == 2 && !priv) {
@@ -3414,13 +3425,20 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // fp32 tensors, products of two fp16 planes per operand on the matrix cores (DmlConvDesc.x_planes ...)
             constexpr int CUS = 256, NLD = DML_WS_PLANES_NLD;
             const bool wide = (a.N % 256) == 0;
-            const int bm = wide ? 144 : 288;
+            // 64 output channels (layer1's 3x3, the 256 -> 64 1x1, the data gradients of the 64 -> 256 1x1): 192 x 64 tiles on four
+            // 48 x 64 wave tiles.  On the 288 x 128 configuration half of every tile -- MFMAs and DMA pieces -- was empty
+            // (r04: 0.16-0.17 of the class's own bound).  Same box, old -> new: 3x3 64 -> 64 at 192 x 192 forward 347 -> 286 us, 1x1
+            // 256 -> 64 244 -> 185, 1x1 128 -> 64 190 -> 132; whole step +0.8 % (profiles/r05_ab_n64.txt)
+            const bool n64 = a.N == 64;
+            const int bm = wide ? 144 : (n64 ? 192 : 288);
             a.nblk_m = (a.M + bm - 1) / bm;
-            a.nblk_n = wide ? a.N / 256 : (a.N + 127) / 128;      // (a last 128-wide block may be half empty: zero rows, no stores)
+            a.nblk_n = wide ? a.N / 256 : (n64 ? 1 : (a.N + 127) / 128);      // (a last 128-wide block may be half empty: zero rows, no stores)
             const int ntiles = a.nblk_m * a.nblk_n;
             const int grid = ntiles < CUS ? ntiles : CUS;
             const uint32_t xpb = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2), wpb = (uint32_t)((int64_t)a.N * a.Ktot * 2);
-            if (wide)
+            if (n64)
+                hipLaunchKernelGGL((conv_ws_kernel<4, 1, MODE, NLD, 2, 3>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+            else if (wide)
                 hipLaunchKernelGGL((conv_ws_kernel<1, 4, MODE, NLD, 2>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
             else
                 hipLaunchKernelGGL((conv_ws_kernel<2, 2, MODE, NLD, 2>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);

@@ -118,7 +118,7 @@ _PROTOS = {
     "dml_bn_eval_coeffs": (c_i, [c_p, c_p, c_p, c_p, c_f, c_p, c_p, c_i, c_p]),
     "dml_bn_eval_coeffs_table": (c_i, [c_p, c_i, c_p]),
     "dml_bn_apply": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_i, c_f, C.c_uint64, c_p,
-                           c_p, c_i64, c_i, c_p, c_p]),
+                           c_p, c_i64, c_i, c_p, c_i64, c_p, c_p]),
     "dml_bn_bwd_reduce": (c_i, [c_p, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_i, c_i, c_i, c_i, c_i, c_f, c_i,
                                 C.POINTER(c_i), c_p, c_p]),
     "dml_bn_bwd_finalize": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_p]),
@@ -193,7 +193,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.dml_abi_version() != 3:
+    if lib.dml_abi_version() != 4:
         raise DmlError("libdmlnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -343,6 +343,9 @@ class Plan:
         self.h2_direct_on = os.environ.get("DML_H2_DIRECT", "1") != "0"
         self.direct_planes = []        # (activation, argument list, index of its `planes` argument): cleared when nobody asks
         self.fuse_res_grad = os.environ.get("DML_FUSE_RES_GRAD", "1") != "0"
+        # f16x2 training: a block output that only convolutions and the NEXT block's residual add read exists as planes only -- the
+        # residual add takes (hi + lo) / s, the value those convolutions see (dml_bn_apply, res_unscale).  DML_RES_PLANES=0: off
+        self.res_planes_on = os.environ.get("DML_RES_PLANES", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
         # producer, as autograd does in the reference (resnet.py:112-113, network/utils.py:360).  Off by default: measured
@@ -704,7 +707,9 @@ class Plan:
         planes_only = planes_only and direct and self.planes_fit(x.B * Ho * Wo, N)
         if direct:
             u.z = self.h2_direct(x.B, Ho, Wo, N, fp32_too=not planes_only)
-            if not planes_only:
+            if not planes_only or res is not None:
+                # max |z| is published where something may ask for it: a conv reading the fp32 tensor through dml_h2_split, or the
+                # next block's residual unit (its plane scale: dml_h2_bound_bn) -- also when z itself exists as planes only
                 u.z.amax = u.z.h2[1]           # (the amax words and the scale word share the tensor's work buffer)
         else:
             u.z = out if out is not None else self.new(x.B, Ho, Wo, N)
@@ -777,10 +782,16 @@ class Plan:
                           res.amax.data_ptr() if res is not None else None, work.data_ptr())
             pl = (planes.data_ptr(), M * N, N, work.data_ptr() + 4096)
         only = direct and planes_only
+        # a residual operand that exists as planes only (the previous block's output, block_fwd): hi + lo, unscaled
+        res_pl = (0, None)
+        if res is not None and res.t.dtype == torch.float16:
+            assert res is res.root and res.h2 is not None and self.dtype == torch.float32
+            res_pl = (res.M * res.ld, res.h2[1].data_ptr() + 4096)
         u.apply_args = self.call(self.fwd, lib.dml_bn_apply, u.y.ptr, res.ptr if res is not None else None,
                                  None if only else u.z.ptr, u.scale.data_ptr(), u.shift.data_ptr(), mean_ptr, mask_ptr, M, N,
                                  u.y.ld, res.ld if res is not None else 0, u.z.ld, 1 if relu else 0, self.dt, 0.0, 0,
-                                 self.amax_of(u.z) if (self.training and not only) else None, *pl)
+                                 self.amax_of(u.z) if (self.training and (not only or u.z.amax is not None)) else None, *pl,
+                                 *res_pl)
         if direct and not only:
             self.direct_planes.append((u.z, u.apply_args, 17))
         if drop is not None and self.training:
@@ -876,8 +887,9 @@ class Plan:
         if need_dgrad:
             self.conv_dgrad(dy, u.conv, u.wt, u.x, final=final)
 
-    def block_fwd(self, x: Act, blk: nn.Module):
-        """one Bottleneck (resnet.py:95-115): 1x1 -> 3x3 -> 1x1, + identity or downsample branch, ReLU"""
+    def block_fwd(self, x: Act, blk: nn.Module, out_planes_only=False):
+        """one Bottleneck (resnet.py:95-115): 1x1 -> 3x3 -> 1x1, + identity or downsample branch, ReLU.
+        out_planes_only: the block output is read by planes convolutions and the next block's residual add only (build())."""
         # (f16x2: u1.z / u2.z feed one convolution each -- where that one reads planes, the fp32 tensors are never written)
         n1, n2, n3 = blk.conv1.out_channels, blk.conv2.out_channels, blk.conv3.out_channels
         kk = blk.conv2.kernel_size[0] * blk.conv2.kernel_size[1]
@@ -889,7 +901,7 @@ class Plan:
             idt = ud.z
         else:
             idt = x
-        u3 = self.cbr(u2.z, blk.conv3, blk.bn3, relu=True, res=idt)
+        u3 = self.cbr(u2.z, blk.conv3, blk.bn3, relu=True, res=idt, planes_only=out_planes_only)
         return (x, u1, u2, u3, ud)
 
     def block_bwd(self, rec):
@@ -966,11 +978,18 @@ class Plan:
         # bottlenecks (resnet.py:95-115)
         blocks = []
         x = p0
-        for layer in (bb.layer1, bb.layer2, bb.layer3, bb.layer4):
-            for blk in layer:
-                blocks.append(self.block_fwd(x, blk))
-                x = blocks[-1][3].z
-            if layer is bb.layer1:
+        seq = [(li, blk) for li, layer in enumerate((bb.layer1, bb.layer2, bb.layer3, bb.layer4)) for blk in layer]
+        for i, (li, blk) in enumerate(seq):
+            # the output as planes only: another block follows whose conv1 / downsample conv take planes, and it is neither `low`
+            # (the decoder's 48-channel projection reads the fp32 tensor) nor `out` (global average pooling does)
+            nxt = seq[i + 1] if i + 1 < len(seq) else None
+            c3 = blk.conv3.out_channels
+            po = (self.res_planes_on and nxt is not None and not (li == 0 and nxt[0] != 0)
+                  and nxt[1].conv1.kernel_size == (1, 1) and self.h2_ok(c3, nxt[1].conv1.out_channels, 1)
+                  and (nxt[1].downsample is None or self.h2_ok(c3, nxt[1].downsample[0].out_channels, 1)))
+            blocks.append(self.block_fwd(x, blk, out_planes_only=po))
+            x = blocks[-1][3].z
+            if li == 0 and (nxt is None or nxt[0] != 0):
                 low = x
         out = x
 

@@ -458,6 +458,43 @@ def test_bn_bwd_finalize_many_partial_rows(lib, Cc, G):
     relclose(dg.cpu(), s[:, 1], 2e-6, "dgamma")
 
 
+@pytest.mark.parametrize("res", ["none", "f32", "planes"])
+@pytest.mark.parametrize("shape", [(3 * 9 * 11, 48), (2 * 37 * 5, 264)])
+def test_bn_apply_planes_only_output_equals_the_fp32_path(lib, res, shape):
+    """dml_bn_apply with z == NULL (the output exists as fp16 planes only: bn_apply_planes8_kernel, eight channels per thread) against
+    the same launch that also writes the fp32 tensor (bn_apply_cols_kernel): planes, ReLU mask bytes and max |z| bit for bit; and the
+    residual operand given as the planes of a tensor (res_unscale, ABI 4) = the launch with that tensor's (hi + lo) / s as fp32."""
+    M, Cc = shape
+    g = torch.Generator(device="cpu").manual_seed(5)
+    yd = (torch.randn(M, Cc, generator=g) * 2 + 0.3).cuda()
+    sc, sh, mu = (torch.rand(Cc, generator=g) + 0.5).cuda(), (torch.randn(Cc, generator=g) * 0.1).cuda(), (torch.randn(Cc, generator=g) * 0.2).cuda()
+    rfull = (torch.randn(M, Cc, generator=g) * 1.5).cuda()
+    rp, rw = h2_planes(lib, rfull, 0)
+    r_from_planes = ((rp[0].float() + rp[1].float()) * rw[1024]).view(M, Cc).contiguous()      # what the planes represent, exactly
+    work = torch.zeros(1025, device="cuda")
+    work[1024] = 2.0 ** -9
+    out = {}
+    for only in (False, True):
+        pz = torch.zeros(2, M * Cc, device="cuda", dtype=torch.float16)
+        zd = torch.full((M, Cc), float("nan"), device="cuda")
+        mk = torch.zeros(M * Cc // 4, device="cuda", dtype=torch.uint8)
+        amax = torch.zeros(1024, device="cuda")
+        if res == "planes" and only:
+            rarg, rps, run = rp.data_ptr(), M * Cc, rw.data_ptr() + 4096
+        else:
+            rsrc = None if res == "none" else (rfull if res == "f32" else r_from_planes)
+            rarg, rps, run = (rsrc.data_ptr() if rsrc is not None else None), 0, None
+        chk(lib.dml_bn_apply(yd.data_ptr(), rarg, None if only else zd.data_ptr(), sc.data_ptr(), sh.data_ptr(), mu.data_ptr(),
+                             mk.data_ptr(), M, Cc, Cc, Cc, Cc, 1, 0, 0.0, 0, amax.data_ptr(), pz.data_ptr(), M * Cc, Cc,
+                             work.data_ptr() + 4096, rps, run, st()))
+        torch.cuda.synchronize()
+        out[only] = (pz, mk, amax.max().item(), zd)
+    ref = torch.relu((yd - mu) * sc + sh + (0 if res == "none" else (rfull if res == "f32" else r_from_planes)))
+    assert (out[False][3] - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
+    assert torch.equal(out[True][0], out[False][0]) and torch.equal(out[True][1], out[False][1]) and out[True][2] == out[False][2]
+    assert torch.isnan(out[True][3]).all()            # z really was not written
+
+
 @pytest.mark.parametrize("dname", ["f32", "bf16"])
 @pytest.mark.parametrize("relu,res,drop", [(1, False, 0.0), (1, True, 0.0), (0, False, 0.0), (1, False, 0.25)])
 def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
@@ -503,7 +540,7 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
                                 zwork.data_ptr(), st()))
     chk(lib.dml_bn_apply(yd.data_ptr(), rd.data_ptr() if res else None, zd.data_ptr(), sc.data_ptr(), sh.data_ptr(),
                          mu.data_ptr(), mk, M, Cc, Cc, Cc, Cc, relu, dt, drop, 1234, amax.data_ptr(),
-                         pz.data_ptr() if planes_ok else None, M * Cc, Cc, zwork.data_ptr() + 4096 if planes_ok else None, st()))
+                         pz.data_ptr() if planes_ok else None, M * Cc, Cc, zwork.data_ptr() + 4096 if planes_ok else None, 0, None, st()))
     torch.cuda.synchronize()
     if planes_ok:
         un = zwork[1024].item()
@@ -806,7 +843,7 @@ def test_rejects_bad_arguments(lib):
     assert lib.dml_conv_igemm(C.byref(d), None) == -1
     x = torch.zeros(64, device="cuda")
     assert lib.dml_bn_apply(x.data_ptr(), None, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), None, 4, 6, 6, 6,
-                            6, 1, 0, 0.0, 0, None, None, 0, 0, None, st()) == -2
+                            6, 1, 0, 0.0, 0, None, None, 0, 0, None, 0, None, st()) == -2
     assert lib.dml_proto_dist_fwd(x.data_ptr(), x.data_ptr(), None, None, None, None, 1, 64, 16, 1, 1, st()) == -3
 
 

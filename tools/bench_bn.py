@@ -42,7 +42,12 @@ for (M, N) in SHAPES:
         i = it[0] = (it[0] + 1) % nbuf
         _lib.check(lib.dml_bn_apply(ys[i].data_ptr(), rs[i % len(rs)].data_ptr() if res else None, zs[i].data_ptr() if z else None,
                                     sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), mk.data_ptr(), M, N, N, N, N, 1, dt_c, 0.0, 0, None,
-                                    *pl(i), st), "apply")
+                                    *pl(i), 0, None, st), "apply")
+    def apply_rp():          # residual from the planes of another tensor, output as planes only (round 5: block outputs)
+        i = it[0] = (it[0] + 1) % nbuf
+        _lib.check(lib.dml_bn_apply(ys[i].data_ptr(), pls[(i + 1) % nbuf].data_ptr(), None,
+                                    sc.data_ptr(), sh.data_ptr(), mu.data_ptr(), mk.data_ptr(), M, N, N, N, N, 1, dt_c, 0.0, 0, None,
+                                    *pl(i), E, work.data_ptr() + 4096, st), "apply")
     def reduce():
         i = it[0] = (it[0] + 1) % nbuf
         _lib.check(lib.dml_bn_bwd_reduce(zs[i].data_ptr(), ys[i].data_ptr(), None, mk.data_ptr(), mu.data_ptr(), inv.data_ptr(),
@@ -57,6 +62,7 @@ for (M, N) in SHAPES:
     m8 = 1.0 / (8 * V / 8) / es * 0 + 1.0 / V / es           # mask bytes per element, in units of es
     if mode == "planes":
         cases = (("apply->planes", lambda: apply(False, False), (2 + m8) * es * E), ("apply+res->z+planes", lambda: apply(True), (4 + m8) * es * E),
+                 ("apply+res(planes)->planes", apply_rp, (3 + m8) * es * E),
                  ("bwd_reduce", reduce, (2 + m8) * es * E), ("bwd_apply->planes", lambda: bapply(False, False), (3 + m8) * es * E),
                  ("bwd_apply+dres->planes", lambda: bapply(True, False), (4 + m8) * es * E))
     else:

@@ -66,7 +66,7 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
         yb = torch.empty_like(x); mk = torch.empty(x.numel() // 8, dtype=torch.uint8, device="cuda")
         mean0 = torch.zeros(Cc, device="cuda")
         t = timeit(lambda: lib.dml_bn_apply(x.data_ptr(), None, yb.data_ptr(), psc.data_ptr(), psh.data_ptr(), mean0.data_ptr(),
-                                            mk.data_ptr(), B * H * W, Cc, Cc, 0, Cc, 1, 1, 0.0, 0, None, None, 0, 0, None, st))
+                                            mk.data_ptr(), B * H * W, Cc, Cc, 0, Cc, 1, 1, 0.0, 0, None, None, 0, 0, None, 0, None, st))
         line += "bn_apply of the input %.1fus | " % (t * 1e6)
     if which == "phases":
         import ctypes
