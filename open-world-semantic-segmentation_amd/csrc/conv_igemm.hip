@@ -3796,19 +3796,22 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         const int base = a.nblk_n * a.nblk_k;
         int sk = d->splitk;
         if (sk <= 0) {
-            // the split count that fills whole rounds of 256 workgroups best, fewest splits on ties; >= 16 K steps per item
+            // the split count with the smallest modelled time: rounds of 256 workgroups x (K steps of an item x 1.45 us + 8 us for
+            // its 128 KB slab store and the restart of the K loop) + the fold pass over the slabs (written and read once, ~4 TB/s);
+            // >= 16 K steps per item.  (Round 4 maximised the filling of the rounds alone and took 71 slabs of 16 steps for 3x3
+            // 256 -> 256 -- five rounds, a third of each an epilogue, 335 MB of slabs -- where 14 slabs of 83 steps fill one round.)
             int smax = tiles / 16;
             if (smax > 256) smax = 256;
             if ((int64_t)smax * plane > d->ws_elems) smax = (int)(d->ws_elems / plane);
             if (smax < 1) smax = 1;
-            double best = -1.0;
+            double best = 1e30;
             sk = 1;
             for (int c = 1; c <= smax; ++c) {
                 const int slab = (tiles + c - 1) / c;
                 const int real = (tiles + slab - 1) / slab;
                 const int items = base * real;
-                const double eff = (double)items / (double)(((items + 255) / 256) * 256);
-                if (eff > best + 1e-9) { best = eff; sk = real; }
+                const double t = (double)((items + 255) / 256) * (slab * 1.45 + 8.0) + (double)real * (double)plane * 8.0 / 4.0e6;
+                if (t < best - 1e-9) { best = t; sk = real; }
             }
         }
         if ((int64_t)sk * plane > d->ws_elems) sk = (int)(d->ws_elems / plane);
