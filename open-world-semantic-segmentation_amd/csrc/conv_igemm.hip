@@ -1533,6 +1533,19 @@ __device__ __forceinline__ void conv_epilogue_rows8(f32x4 (&acc)[NT][3], const C
     chunk(std::integral_constant<int, 5>{});
 }
 
+// timing ablations of the two-plane K loop (tools/build_ablations.sh; never defined in the product build): 1 = no fragment reads in
+// the loop, 2 = no flag polls / waits, 4 = the loaders issue no DMA.  Results are garbage, durations are what is measured.
+#ifndef DML_WS_ABL
+#define DML_WS_ABL 0
+#endif
+#ifndef DML_WS_SPREAD
+#define DML_WS_SPREAD 1                        // fragment reads of the two-plane K loop between the MFMA quads (0: in front of them)
+#endif
+// (accumulators in the accumulator register file through inline-asm MFMAs were tried in round 5: hipcc splits the 256 registers of a
+// two-waves-per-SIMD kernel 128 / 128, the 144 accumulators of the 144 x 64 wave tile do not fit, and the K loop did not get faster:
+// 888 -> 944 us on the ASPP 3x3, profiles/r05_h2_kloop_ablations.txt)
+#define WS_MFMA_F16(ACCV, A_, B_) ACCV = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACCV, 0, 0, 0)
+
 typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
 constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
 constexpr int WS_STAT_ROWS = 48;               // rows per statistics group of this kernel
@@ -1699,6 +1712,7 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
 #pragma unroll
             for (int q = 0; q < MYP; ++q) {
                 const int p = q * NLD + LW;
+                if (PL == 2 && (DML_WS_ABL & 4)) continue;
                 if (p < PL * PA) {
                     const uint32_t voff = (mask[q] & tapbit) ? (uint32_t)(base[q] + soff) : OOB;
                     ws_dma16(rs_x, sbase + p * 1024, voff, p < PA ? 0u : a.x_plane_bytes);
@@ -1777,6 +1791,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     }
 
     // ---------------------------------------------------------------------- consumer
+    __builtin_amdgcn_s_setprio(3);      // the MFMA waves ahead of the loader wave that shares their SIMD (+0.15 % on the step)
     const int wm = wave / NW, wn = wave % NW;
     const int lr = lane & 15, lq = lane >> 4;
     constexpr bool priv = PRIV_STAGE || PRIV_ROWS;      // the epilogue stages beside the ring: a tile's last stage is released like any other
@@ -1888,30 +1903,85 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                 const char* sn = has_next ? smem + ((g + 1) % NST) * SB : sb;
 #pragma unroll
                 for (int j = 0; j < MT; ++j) {
+                    // (positions inside the step: row group 1 / 4 / 5.. of the nine of a 144-row wave tile, 0 / 1 / 2 of a 48-row one)
+                    constexpr int JP = MT >= 9 ? 1 : 0, JW = MT >= 9 ? 4 : 1, JB = MT >= 9 ? 5 : MT - 1;
+#if DML_WS_SPREAD
+                    // The non-MFMA instructions of a row group SPREAD between its three MFMA quads instead of clustered in front of
+                    // them: a wave issues in order, and a cluster of five or six of them (two fragment reads, waits, hazard nops)
+                    // outlasts the 16 cycles of the MFMA before it -- the ablations put 25-30 % of the K loop on the fragment reads
+                    // although the LDS itself is busy a fifth of the time (profiles/r05_h2_kloop_ablations.txt).
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bc[i], ah[(j + P) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
                     if (j + 1 < MT) {
-                        ah[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1]);
-                        al[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1] + A_PLANE);
+                        if (!(DML_WS_ABL & 1)) ah[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1]);
                     } else {
                         asm volatile("" ::: "memory");
+                        if (!(DML_WS_ABL & 1)) ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bc[i], al[(j + P) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j + 1 < MT) {
+                        if (!(DML_WS_ABL & 1)) al[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1] + A_PLANE);
+                    } else {
                         // every read of stage g has been issued (the tile's LAST stage is announced after the epilogue, which
                         // stages the output rows in its slot)
+                        asm volatile("" ::: "memory");
                         if (has_next || priv) ws_st(consumed + wave, g + 1);
-                        ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
-                        al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
+                        if (!(DML_WS_ABL & 1)) al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
                     }
-                    // (positions inside the step: row group 1 / 4 / 5 of the nine of a 144-row wave tile, 0 / 1 / 2 of a 48-row one)
-                    constexpr int JP = MT >= 9 ? 1 : 0, JW = MT >= 9 ? 4 : 1, JB = MT >= 9 ? 5 : MT - 1;
-                    if (j == JP) {                          // the next step's poll, answered under the MFMAs
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bl[i], ah[(j + P) & 1]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (j == JP && !(DML_WS_ABL & 2)) {     // the next step's poll, answered under the MFMAs
 #pragma unroll
                         for (int w = 0; w < NLD; ++w) pl[w] = ws_ld(ready + w);
                     }
-                    if (j == JW) {
+                    if (j == JW && !(DML_WS_ABL & 2)) {
                         rflag = pl[0];
 #pragma unroll
                         for (int w = 1; w < NLD; ++w) rflag = min(rflag, pl[w]);
                         if (has_next) wait_ready(g + 2);
                     }
-                    if (j == JB) {
+                    if (!(DML_WS_ABL & 1)) {
+                        if (MT >= 9) {                      // the next step's hi weight fragments, one per row group
+                            if (j >= JB && j < JB + NT) bn[j - JB] = WS_FRAG(sn + b_off[j - JB]);
+                        } else if (j == JB) {
+#pragma unroll
+                            for (int i = 0; i < NT; ++i) bn[i] = WS_FRAG(sn + b_off[i]);
+                        }
+                    }
+#else
+                    if (j + 1 < MT) {
+                        if (!(DML_WS_ABL & 1)) {
+                            ah[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1]);
+                            al[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1] + A_PLANE);
+                        }
+                    } else {
+                        asm volatile("" ::: "memory");
+                        // every read of stage g has been issued (the tile's LAST stage is announced after the epilogue, which
+                        // stages the output rows in its slot)
+                        if (has_next || priv) ws_st(consumed + wave, g + 1);
+                        if (!(DML_WS_ABL & 1)) {
+                            ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
+                            al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
+                        }
+                    }
+                    if (j == JP && !(DML_WS_ABL & 2)) {     // the next step's poll, answered under the MFMAs
+#pragma unroll
+                        for (int w = 0; w < NLD; ++w) pl[w] = ws_ld(ready + w);
+                    }
+                    if (j == JW && !(DML_WS_ABL & 2)) {
+                        rflag = pl[0];
+#pragma unroll
+                        for (int w = 1; w < NLD; ++w) rflag = min(rflag, pl[w]);
+                        if (has_next) wait_ready(g + 2);
+                    }
+                    if (j == JB && !(DML_WS_ABL & 1)) {
 #pragma unroll
                         for (int i = 0; i < NT; ++i) bn[i] = WS_FRAG(sn + b_off[i]);
                     }
@@ -1923,9 +1993,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
 #pragma unroll
                     for (int i = 0; i < NT; ++i) ACC(i, j) = __builtin_amdgcn_mfma_f32_16x16x32_f16(bl[i], ah[(j + P) & 1], ACC(i, j), 0, 0, 0);
                     __builtin_amdgcn_sched_barrier(0);
+#endif
                 }
+                if (!(DML_WS_ABL & 1)) {
 #pragma unroll
-                for (int i = 0; i < NT; ++i) bl[i] = WS_FRAG(sn + b_off[i] + B_PLANE);
+                    for (int i = 0; i < NT; ++i) bl[i] = WS_FRAG(sn + b_off[i] + B_PLANE);
+                }
                 __builtin_amdgcn_sched_barrier(0);
                 ++g;
             };
@@ -2568,6 +2641,7 @@ __global__ __launch_bounds__((4 + WGW_NLD) * 64) void conv_wgrad_ws_kernel(const
         return;
     }
     // ---------------------------------------------------------------------- consumer
+    __builtin_amdgcn_s_setprio(3);
     const int wn = wave >> 1, wk = wave & 1;
     const int lr = lane & 15, lq = lane >> 4;
     const int tiles_total = (a.M + BK - 1) / BK;

@@ -1514,8 +1514,10 @@ class Engine:
                                "in oracle/ and is test infrastructure only" % x.device)
         if x.dim() != 4 or x.shape[1] != 3:
             raise ValueError("expected input [B,3,H,W], got %s" % (tuple(x.shape),))
-        if training and x.shape[0] < 2 and self.bn_modes() != (1 << len(self._bn_list)) - 1:
+        synced = bool(self.sync_bn and dist.is_available() and dist.is_initialized() and dist.get_world_size(self.sync_group) > 1)
+        if training and x.shape[0] < 2 and not synced and self.bn_modes() != (1 << len(self._bn_list)) - 1:
             # same failure as the reference: BatchNorm over B x 256 x 1 x 1 in ASPPPooling (network/utils.py:318-329)
+            # (synchronised statistics span the ranks: one image per rank is a legal batch there)
             raise ValueError("Expected more than 1 value per channel when training, got input size "
                              "torch.Size([%d, 256, 1, 1])" % x.shape[0])
         x = x.contiguous().float()
