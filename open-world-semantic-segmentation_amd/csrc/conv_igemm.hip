@@ -3896,6 +3896,8 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         sk = (tiles + a.slab_tiles - 1) / a.slab_tiles;
         const int nitems = base * sk;
         const uint32_t xpb = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2), ypb = (uint32_t)((((int64_t)a.M - 1) * a.ldy + a.N) * 2);
+        // (one item per workgroup instead of persistent workgroups, with and without a high-priority main stream: no change of the
+        // overlapped step, 83.4-83.9 ms in every combination, serial 86.1 -- profiles/r05_ab_wgrad_nonpersist_priority.txt)
         const dim3 wgrid(nitems < 256 ? nitems : 256), wblock((4 + WGW_NLD) * 64);
         if (a.R == 1 && a.S == 1 && a.stride == 1 && a.pad == 0)
             hipLaunchKernelGGL(conv_wgrad_ws_kernel<true>, wgrid, wblock, 0, st, a, xpb, ypb, nitems);

@@ -836,9 +836,12 @@ class Plan:
         fused = (prod is not None and self.dtype == torch.bfloat16 and (u.mask is not None or not u.relu)
                  and u.drop is None and N % 8 == 0 and N > 32 and G <= 4096 and prod.N == N and prod.ldy == N
                  and dz.ld == N and prod.y == dz.ptr)
-        # fp32 tensors: the two-plane kernel's epilogue does the same (4-channel mask bytes, 48-row groups, max |g| for dy's bound)
+        # fp32 tensors: the two-plane kernel's epilogue does the same (4-channel mask bytes, 48-row groups, max |g| for dy's bound).
+        # Up to 16384 groups since round 5 (the 192 x 192 layers: 12288 groups, folded in two stages by dml_bn_bwd_finalize): with the
+        # row epilogue's vector mask loads the fused sums win there too, 83.90 -> 83.60 ms (profiles/r05_ab_bnr_maxg.txt)
         fused = fused or (prod is not None and self.dtype == torch.float32 and prod.f32_split == 2 and prows == 48
-                          and (u.mask is not None or not u.relu) and u.drop is None and N % 64 == 0 and G <= 4096
+                          and (u.mask is not None or not u.relu) and u.drop is None and N % 64 == 0
+                          and G <= 16384
                           and prod.N == N and prod.ldy == N and dz.ld == N and prod.y == dz.ptr and u.y.ld % 4 == 0)
         a1 = None
         if fused:
