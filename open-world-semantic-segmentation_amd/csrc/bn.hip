@@ -615,6 +615,85 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_cols_kernel(
     if (amax != nullptr) amax_publish(amx, amax);
 }
 
+// The launches of an f16x2 plan whose dy exists as planes only (every unit whose weight and data gradient read planes), ReLU from the
+// bit mask: eight channels per thread -- dz and y as two float4 each, the mask as ONE 2-byte load, the planes as 8 x fp16 (16-byte
+// stores; bn_apply_planes8_kernel is the forward twin).  Optionally the identity branch's masked gradient dres (fp32, set or accumulate).
+template <int U>
+__global__ __launch_bounds__(256) void bn_bwd_apply_planes8_kernel(
+    const float* __restrict__ dz, const float* __restrict__ y, const uint8_t* __restrict__ mask, const float* __restrict__ coef,
+    float* dres, int64_t M, int N, int lddz, int ldy, int lddres, int relu, float gscale, int dres_accum, int CB, int RB,
+    int rows_per_block, _Float16* __restrict__ planes, int64_t plane_stride, int ldp, const float* __restrict__ unscale) {
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    constexpr int V = 8;
+    const float h2s = 1.0f / unscale[0];
+    const int NV = N / V;
+    const int col = threadIdx.x % CB, rl = threadIdx.x / CB;
+    const int vcol = blockIdx.y * CB + col;
+    if (!(rl < RB && vcol < NV)) return;
+    const int c = vcol * V;
+    float cA[V], cB[V], cC[V], cM[V];
+#pragma unroll
+    for (int q = 0; q < V; ++q) {
+        cA[q] = coef[c + q] * gscale;
+        cB[q] = coef[N + c + q];
+        cC[q] = coef[2 * N + c + q];
+        cM[q] = coef[3 * N + c + q];
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    const int64_t r1 = min(M, r0 + rows_per_block);
+    for (int64_t m0 = r0 + rl; m0 < r1; m0 += (int64_t)RB * U) {
+        float4 ga[U], gb[U], ya[U], yb[U], ra[U], rb[U];
+        uint32_t bits[U];
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            bits[u] = 0xffffu;
+            if (m < r1) {
+                ga[u] = *reinterpret_cast<const float4*>(dz + m * lddz + c);
+                gb[u] = *reinterpret_cast<const float4*>(dz + m * lddz + c + 4);
+                ya[u] = *reinterpret_cast<const float4*>(y + m * ldy + c);
+                yb[u] = *reinterpret_cast<const float4*>(y + m * ldy + c + 4);
+                if (relu) bits[u] = *reinterpret_cast<const uint16_t*>(mask + m * (N / 4) + vcol * 2);
+                if (dres != nullptr && dres_accum) {
+                    ra[u] = *reinterpret_cast<const float4*>(dres + m * lddres + c);
+                    rb[u] = *reinterpret_cast<const float4*>(dres + m * lddres + c + 4);
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int64_t m = m0 + (int64_t)u * RB;
+            if (m >= r1) continue;
+            float g[V] = {ga[u].x, ga[u].y, ga[u].z, ga[u].w, gb[u].x, gb[u].y, gb[u].z, gb[u].w};
+            const float yy[V] = {ya[u].x, ya[u].y, ya[u].z, ya[u].w, yb[u].x, yb[u].y, yb[u].z, yb[u].w};
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const bool on = ((bits[u] >> (q + (q >= 4 ? 4 : 0))) & 1u) != 0;      // one mask byte per four channels
+                g[q] = on ? g[q] : 0.f;
+            }
+            h8 hi, lo;
+#pragma unroll
+            for (int q = 0; q < V; ++q) {
+                const float o = cA[q] * g[q] + cB[q] * (yy[q] - cM[q]) + cC[q];
+                const float xs = o * h2s;
+                const _Float16 h = (_Float16)xs;
+                hi[q] = h;
+                lo[q] = (_Float16)(xs - (float)h);
+            }
+            *reinterpret_cast<h8*>(planes + m * ldp + c) = hi;
+            *reinterpret_cast<h8*>(planes + plane_stride + m * ldp + c) = lo;
+            if (dres != nullptr) {
+                float r[V] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+                if (dres_accum) { r[0] = ra[u].x; r[1] = ra[u].y; r[2] = ra[u].z; r[3] = ra[u].w; r[4] = rb[u].x; r[5] = rb[u].y; r[6] = rb[u].z; r[7] = rb[u].w; }
+#pragma unroll
+                for (int q = 0; q < V; ++q) r[q] += g[q] * gscale;
+                *reinterpret_cast<float4*>(dres + m * lddres + c) = make_float4(r[0], r[1], r[2], r[3]);
+                *reinterpret_cast<float4*>(dres + m * lddres + c + 4) = make_float4(r[4], r[5], r[6], r[7]);
+            }
+        }
+    }
+}
+
 // Large feature maps (G >= 2048 row groups): two coalesced stages instead of one strided walk per channel.
 // Stage 1: block (channel tile of 64, chunk of R groups) reads its rows 512 B per wave and folds them to three
 // fp64 sums per channel -- S = sum s_g, Q = sum M2_g, P = sum s_g^2 / n_g -- which it writes IN PLACE over the
@@ -962,6 +1041,18 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     }
     const int V = dtype == DML_BF16 ? 8 : 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if (dtype == DML_F32 && planes && !dy && !amax && (mask || !relu) && (N & 7) == 0 && (lddz & 3) == 0 && (ldy & 3) == 0 &&
+        (ldp & 7) == 0 && (plane_stride & 7) == 0 && (!dres || (lddres & 3) == 0) &&
+        ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y) |
+          reinterpret_cast<uintptr_t>(dres)) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 1) == 0) {
+        // dy as planes only: eight channels per thread, 16-byte accesses throughout
+        const ColGeom g8 = col_geom(M, N / 8, 2, stream_blocks(M, N, dtype));
+        hipLaunchKernelGGL((bn_bwd_apply_planes8_kernel<2>), dim3(g8.row_blocks, g8.col_chunks), dim3(256), 0, st, (const float*)dz,
+                           (const float*)y, mask, coef, (float*)dres, M, N, lddz, ldy, lddres, relu, gscale, dres_accum, g8.CB, g8.RB,
+                           g8.rows_per_block, static_cast<_Float16*>(planes), plane_stride, (int)ldp, unscale);
+        DML_LAUNCH_CHECK();
+        return 0;
+    }
     const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype));
     dim3 grid(g.row_blocks, g.col_chunks);
     if (dtype == DML_BF16)

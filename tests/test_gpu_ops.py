@@ -602,11 +602,16 @@ def test_bn_train_fwd_bwd(lib, dname, relu, res, drop):
         err = (rec - dyd.double().view(-1)).abs().max().item()
         assert err <= 2.0 ** -21 * dmax + 2.0 ** -32 * un * 2.0 ** 15, (err, dmax, un)
         # planes only (dy == NULL) writes the same planes
+        # (with the bit mask: bn_bwd_apply_planes8_kernel, eight channels per thread; the identity branch's gradient rides along)
         pdy2 = torch.zeros_like(pdy)
-        chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zarg, mk, coef.data_ptr(), None, None, M, Cc, Cc, Cc, Cc, Cc, 0,
+        dres2 = torch.full_like(dres, float("nan")) if res else None
+        chk(lib.dml_bn_bwd_apply(gzd.data_ptr(), yd.data_ptr(), zarg, mk, coef.data_ptr(), None, dres2.data_ptr() if res else None,
+                                 M, Cc, Cc, Cc, Cc, Cc, Cc if res else 0,
                                  1 if (relu or drop > 0) else 0, gs, 0, dt, None, pdy2.data_ptr(), M * Cc, Cc, dwork.data_ptr() + 4096, st()))
         torch.cuda.synchronize()
         assert torch.equal(pdy2, pdy)
+        if res:
+            assert torch.equal(dres2, dres)
     assert abs(amax_dy.max().item() - dyd.float().abs().max().item()) <= 2.0 ** -7 * amax_dy.max().item()
     btol = 1e-4 if dname == "f32" else 2e-2
     relclose(dg.cpu(), gamma.grad, btol, "dgamma")
