@@ -38,8 +38,8 @@ ARITHMETIC = {
     "f16x2": "fp32 tensors, fp32 accumulation; convolution products on the fp16 matrix cores through a two-term split of the "
              "power-of-two-scaled operands (22 significand bits per element, three MFMAs per block: NOT the reference's literal fp32 "
              "products).  Gates it passes, same bars as the exact-fp32 mode, no mode-dependent branch in tests/: the reference-minted "
-             "conditioned fixtures g5l / g8l / g12l (2x3x128x128, every ReLU input proved >= 64 eps32 sum|terms| from zero: logits / loss "
-             "1e-3, all gradient checksums 2e-3), 2x768x768 vs the oracle, 1024x2048 eval vs the oracle; 16x768x768 against the "
+             "conditioned fixtures g5l / g8l / g12l (2x3x128x128, every ReLU input proved >= 64 eps32 sum|terms| from zero: logits, loss, "
+             "running statistics and all gradient checksums at 1e-3; the trajectory at 8x the reference's own run-to-run spread), 2x768x768 vs the oracle, 1024x2048 eval vs the oracle; 16x768x768 against the "
              "exact-fp32 step of this library.  The unconditioned 64x64 fixtures g5 / g8 / g12 gate the exact-fp32 mode only",
     "f32x3": "fp32 tensors, fp32 accumulation; convolution products on the bf16 matrix cores through a three-term split (six MFMAs "
              "per block); same gates as f16x2",
