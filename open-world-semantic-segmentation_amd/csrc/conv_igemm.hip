@@ -2700,13 +2700,23 @@ __global__ __launch_bounds__((4 + WGW_NLD) * 64) void conv_wgrad_ws_kernel(const
             const char* sn = has_next ? smem + ((g + 1) % NST) * WGW_SB : sb;
 #pragma unroll
             for (int j = 0; j < MT; ++j) {
+                // (round 5: the transposed fragment reads of the next column group sit BETWEEN this group's three MFMA quads, as in
+                // conv_ws_kernel: a cluster of reads in front of twelve MFMAs outlasts the MFMA before it)
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[j & 1], yh[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+                if (j + 1 < MT) xh[(j + 1) & 1] = frag(sb + x_off[j + 1], WGW_XROW);
+                else xh[0] = frag(sn + x_off[0], WGW_XROW);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[j & 1], yh[i], acc[i][j], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
                 if (j + 1 < MT) {
-                    xh[(j + 1) & 1] = frag(sb + x_off[j + 1], WGW_XROW);
                     xl[(j + 1) & 1] = frag(sb + x_off[j + 1] + WGW_XPL, WGW_XROW);
                 } else {
                     asm volatile("" ::: "memory");
                     ws_st(consumed + wave, g + 1);      // every read of stage g has been issued
-                    xh[0] = frag(sn + x_off[0], WGW_XROW);
                     xl[0] = frag(sn + x_off[0] + WGW_XPL, WGW_XROW);
                 }
                 if (j == 1) {
@@ -2719,15 +2729,8 @@ __global__ __launch_bounds__((4 + WGW_NLD) * 64) void conv_wgrad_ws_kernel(const
                     for (int w = 1; w < NLD; ++w) rflag = min(rflag, pl[w]);
                     if (has_next) wait_ready(g + 2);
                 }
-                if (j == 4) {
-#pragma unroll
-                    for (int i = 0; i < NT; ++i) yhn[i] = frag(sn + y_off[i], WGW_YROW);
-                }
+                if (j >= 4 && j < 4 + NT) yhn[j - 4] = frag(sn + y_off[j - 4], WGW_YROW);
                 __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[j & 1], yh[i], acc[i][j], 0, 0, 0);
-#pragma unroll
-                for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xl[j & 1], yh[i], acc[i][j], 0, 0, 0);
 #pragma unroll
                 for (int i = 0; i < NT; ++i) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(xh[j & 1], yl[i], acc[i][j], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
