@@ -167,7 +167,7 @@ def test_committed_bench_line_carries_the_contract_fields():
     files = [f for f in glob.glob(os.path.join(H.ROOT, "profiles", "r*_bench_v*.json")) if re.search(r"r\d+_bench_v\d+\.json$", f)]
     newest = max(files, key=lambda f: tuple(int(x) for x in re.findall(r"r(\d+)_bench_v(\d+)", f)[0]))
     d = json.load(open(newest))
-    assert os.path.basename(newest).startswith("r04"), newest
+    assert os.path.basename(newest).startswith("r05"), newest
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
               "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline", "bf16_companion", "fp32_exact_companion",
               "hbm_kernel"):
@@ -196,7 +196,7 @@ def test_committed_bench_line_carries_the_contract_fields():
     b = d["bf16_companion"]
     assert b["dtype"] == "bf16" and b["value"] > d["value"] and abs(b["roofline"]["frac"] - b["roofline"]["achieved"] / 2500.0) < 1e-6
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and str(c["cores"]) in c["by_threads"]
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["sample"] and str(c["cores"]) in c["probe_by_threads"] and len(c["timed_steps_s"]) >= 3
     h = d["hbm_kernel"]
     assert h["bound"] == "hbm" and abs(h["frac"] - h["achieved"] / h["peak"]) < 1e-9
     assert h["traffic"] is None or h["traffic"] > 0.99 * 192 * 16 * 768 * 768
