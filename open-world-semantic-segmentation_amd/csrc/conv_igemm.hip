@@ -1320,7 +1320,7 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
 // BatchNorm statistics come from the accumulators as before (conv_epilogue, STATS_ONLY); accumulate and the stores happen on the
 // row side (launches with a bias or the inference epilogue post_* keep conv_epilogue).  `stage`: this wave's own 12 KB.
 constexpr int WS_STAT_ROWS_C = 48;             // (= WS_STAT_ROWS, declared below)
-template <int NT, int MODE>
+template <int NT, int MODE, bool OPS = true>      // OPS = false: launches with epilogue operands go to conv_epilogue_rows_ops
 __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
                                                    const int lane, char* stage, char* mstage) {
     static_assert(NT == 4, "64-channel wave tile");
@@ -1338,11 +1338,11 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
     if (c0 >= a.N) return;                                       // (a last, half-empty 128-wide block)
     // the accumulate operand: the gradient's earlier value (accum), or the identity branch's share of it -- the block output's
     // gradient res_dz under its ReLU mask (DmlConvDesc.res_*, one mask byte per four channels)
-    const bool resm = MODE == 1 && a.res_dz != nullptr;
-    const bool has_old = a.accum != 0 || resm;
-    const bool bnr = MODE == 1 && a.bnr_partials != nullptr;
+    const bool resm = OPS && MODE == 1 && a.res_dz != nullptr;
+    const bool has_old = OPS && (a.accum != 0 || resm);
+    const bool bnr = OPS && MODE == 1 && a.bnr_partials != nullptr;
     float* const yb = static_cast<float*>(a.y);
-    if (!has_old && !bnr) {
+    if (!OPS || (!has_old && !bnr)) {
         // all twelve LDS reads first (into the registers the sub-tile's accumulators just left), then twelve stores back to back.
         // (One path with the accumulate operand selected per element made every store wait vmcnt(0) -- stores count there too on
         // gfx950 -- i.e. for the store before it: 36 serialised round trips per tile, as slow as the scattered stores this function
@@ -1470,11 +1470,190 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
             }
         }
     };
-    if (bnr) {
-        if (has_old) body(std::true_type{}, std::true_type{});
-        else body(std::false_type{}, std::true_type{});
-    } else {
-        body(std::true_type{}, std::false_type{});
+    if constexpr (OPS) {
+        if (bnr) {
+            if (has_old) body(std::true_type{}, std::true_type{});
+            else body(std::false_type{}, std::true_type{});
+        } else {
+            body(std::true_type{}, std::false_type{});
+        }
+    }
+}
+
+// conv_epilogue_rows for a WHOLE wave tile (NS 48-row sub-tiles) of a data gradient WITH epilogue operands (identity-branch gradient /
+// accumulate, fused BatchNorm-backward sums): one software pipeline over all 12 NS row quads instead of one per sub-tile.  The operand
+// loads of a launch like the data gradient of 1x1 1024 -> 256 (dz and y in, dx out: 490 MB) ran at 4 TB/s = the bytes a CU had in
+// flight (two groups of four row quads per wave) over the loaded HBM latency, and every sub-tile began with an exposed round trip
+// (its masks and its first group).  Here every row quad has its own operand registers (a ring of 12, indices compile-time in the
+// unrolled quad loop), the loads run WS_EPI_P quads ahead ACROSS the sub-tile boundaries of the rolled sub-tile loop, and the masks
+// of sub-tile h + 1 are fetched during sub-tile h.
+#ifndef DML_WS_EPI_P
+#define DML_WS_EPI_P 8
+#endif
+#ifndef DML_WS_EPI_OPS
+#define DML_WS_EPI_OPS 1                       // 0: the per-sub-tile pipeline of conv_epilogue_rows for launches with operands too (A/B)
+#endif
+template <int I, int N, class F>
+__device__ __forceinline__ void ws_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        ws_static_for<I + 1, N>(f);
+    }
+}
+template <int NT, int NS, bool HO, bool BNR>
+__device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3], const ConvArgs& a, const int mwt, const int nw0,
+                                                       const int lane_in, char* stage0, char* stage1, char* mstage) {
+    static_assert(NT == 4, "64-channel wave tile");
+    constexpr int P = DML_WS_EPI_P;
+    static_assert(P >= 1 && P <= 11, "ring of 12 row quads");
+    typedef unsigned int u32x4_b __attribute__((ext_vector_type(4)));
+    constexpr uint32_t OOB = 0x80000000u;
+    // (a lane index the optimiser cannot see through: hoisted out of the tile loop, the per-quad addresses below get spilled)
+    int lane = lane_in;
+    asm volatile("" : "+v"(lane));
+    // Every global access of the quad loop is a BUFFER access with the tensor's byte size as range: rows beyond M read zeros and
+    // their stores are dropped by the address unit, an access that must not happen gets an offset 2^31 bytes further (all these
+    // tensors are below 2^31 bytes, conv_ws_planes_eligible).  No branch around any memory instruction, so the loop is straight-line
+    // code whose vmcnt waits the compiler counts exactly; under `if (m < M)` / `if (h + 1 < NS)` branches it must assume the
+    // fewest instructions behind a load and ends up draining the queue.
+    const int c0 = nw0 + (lane & 15) * 4;
+    const uint32_t coff = c0 < a.N ? (uint32_t)c0 * 4u : OOB;
+    const bool resm = a.res_dz != nullptr;
+    const uint32_t y_row = (uint32_t)a.ldy * 4u;
+    const uint32_t o_row = resm ? (uint32_t)a.res_ld * 4u : y_row, b_row = (uint32_t)a.bnr_ldy * 4u, m_row = (uint32_t)(a.N >> 2);
+    const bool use_rm = HO && resm, use_bm = BNR && a.bnr_relu != 0;
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((uint32_t)a.M * y_row), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
+        resm ? const_cast<void*>(a.res_dz) : a.y, 0, HO ? (int)((uint32_t)a.M * o_row) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
+        BNR ? const_cast<void*>(static_cast<const void*>(a.bnr_y)) : a.y, 0, BNR ? (int)((uint32_t)a.M * b_row) : 0, 0x00020000);
+    // (a mask that is not in use: a zero-sized range -- the loads return zeros without touching memory -- and constant bits instead)
+    const __amdgpu_buffer_rsrc_t rs_rm = __builtin_amdgcn_make_buffer_rsrc(
+        use_rm ? const_cast<void*>(static_cast<const void*>(a.res_mask)) : a.y, 0, use_rm ? (int)((uint32_t)a.M * m_row) : 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_bm = __builtin_amdgcn_make_buffer_rsrc(
+        use_bm ? const_cast<void*>(static_cast<const void*>(a.bnr_mask)) : a.y, 0, use_bm ? (int)((uint32_t)a.M * m_row) : 0, 0x00020000);
+    const int ngroups = (a.M + WS_STAT_ROWS_C - 1) / WS_STAT_ROWS_C;
+    const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
+        BNR ? static_cast<void*>(a.bnr_partials) : a.y, 0, BNR ? (int)((uint32_t)ngroups * (uint32_t)a.N * 8u) : 0, 0x00020000);
+    const uint32_t nomask = use_bm ? 0u : 0xfu;
+    u32x4_b old[12], yv[12];
+    float4 mu = make_float4(0.f, 0.f, 0.f, 0.f), is = mu;
+    if (BNR && c0 < a.N) {
+        mu = *reinterpret_cast<const float4*>(a.bnr_mean + c0);
+        is = *reinterpret_cast<const float4*>(a.bnr_invstd + c0);
+    }
+    // ReLU masks of a sub-tile: lane L fetches row L's 16 mask bytes (this wave's 64 channels) of each mask; lanes < 48 park them,
+    // packed (identity-branch mask: low nibble, BatchNorm mask: high nibble), in the wave's mask area (as conv_epilogue_rows);
+    // the masks of sub-tile h + 1 are fetched during sub-tile h
+    u32x4_b rv, bv;
+    auto load_masks = [&](const int h) {
+        const uint32_t mo = (uint32_t)(mwt + h * WS_STAT_ROWS_C + lane) * m_row + (uint32_t)(nw0 >> 2);
+        rv = __builtin_amdgcn_raw_buffer_load_b128(rs_rm, mo, 0, 0);
+        bv = __builtin_amdgcn_raw_buffer_load_b128(rs_bm, mo, 0, 0);
+    };
+    // operands of row quad Q of the wave tile (rows mwt + 4 Q + (lane >> 4)) into its ring slot
+    auto load_quad = [&](auto Qc) {
+        constexpr int Q = decltype(Qc)::value, slot = Q % 12;
+        if constexpr (Q < 12 * NS) {
+            const uint32_t m = (uint32_t)(mwt + Q * 4 + (lane >> 4));
+            if (HO) old[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, m * o_row + coff, 0, 0);
+            if (BNR) yv[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, m * b_row + coff, 0, 0);
+        }
+    };
+    // accumulators -> LDS rows: sub-tiles 0 and 1 at once (two staging areas: the slots of the tile's last TWO K stages), sub-tile 2
+    // into area 0 when sub-tile 0 has been read -- 48 accumulator registers live under the operand ring instead of 96
+    auto stage_acc = [&](f32x4 (&sub)[NT][3], char* st) {
+        const int lr = lane & 15, lq = lane >> 4;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                const int row = j * 16 + lr, chunk = frag_chan<NT>(i, lq) >> 2;
+                *reinterpret_cast<f32x4*>(st + row * 256 + ((chunk ^ (row & 15)) << 4)) = sub[i][j];
+            }
+    };
+    stage_acc(acc3[0], stage0);
+    if constexpr (NS == 3) stage_acc(acc3[1], stage1);
+    __builtin_amdgcn_sched_barrier(0);      // (the ring's first loads after the staging: 96 accumulator registers are free by then)
+    load_masks(0);
+    ws_static_for<0, P>(load_quad);
+    uint32_t gmx = 0;
+    // (the sub-tile loop unrolled: rolled, the ring slots still in flight at its back edge get copied from register to register there,
+    // and every copy waits for its load -- the queue drained once per sub-tile)
+    ws_static_for<0, NS>([&](auto hc) {
+        constexpr int h = decltype(hc)::value;
+        asm volatile("" : "+v"(lane));      // (per-quad LDS offsets recomputed per sub-tile, not kept live across sub-tiles)
+        const int mw0 = mwt + h * WS_STAT_ROWS_C;
+        const char* const stage = (h & 1) ? stage1 : stage0;
+        {
+            u32x4_b pk;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) pk[e] = (rv[e] & 0x0f0f0f0fu) | ((bv[e] & 0x0f0f0f0fu) << 4);
+            if (lane < WS_STAT_ROWS_C) *reinterpret_cast<u32x4_b*>(mstage + lane * 16) = pk;
+            if constexpr (h + 1 < NS) load_masks(h + 1);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // the wave's own writes, read back by other lanes
+        float4 r1 = make_float4(0.f, 0.f, 0.f, 0.f), r2 = r1;
+        auto quad = [&](auto qc) {
+            constexpr int q = decltype(qc)::value;
+            __builtin_amdgcn_sched_barrier(0);      // quads in program order: the ring slots are what bounds the registers
+            // the loads that run P quads ahead (into the slot quad q + P - 12 left P quads ago)
+            load_quad(std::integral_constant<int, h * 12 + q + P>{});
+            const int r = q * 4 + (lane >> 4);
+            const uint32_t m = (uint32_t)(mw0 + r);
+            float4 o = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
+            const uint32_t pkb = *reinterpret_cast<const uint8_t*>(mstage + lane + q * 64);
+            if (HO) {
+                float4 t = make_float4(__uint_as_float(old[q][0]), __uint_as_float(old[q][1]), __uint_as_float(old[q][2]),
+                                       __uint_as_float(old[q][3]));
+                if (resm) {
+                    t.x = (pkb & 1u) ? t.x : 0.f; t.y = (pkb & 2u) ? t.y : 0.f; t.z = (pkb & 4u) ? t.z : 0.f; t.w = (pkb & 8u) ? t.w : 0.f;
+                }
+                o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
+            }
+            const u32x4_b ov = {__float_as_uint(o.x), __float_as_uint(o.y), __float_as_uint(o.z), __float_as_uint(o.w)};
+            // (non-temporal whatever nt_out says: one store instruction on every path -- data gradients with operands write 38-600 MB)
+            __builtin_amdgcn_raw_buffer_store_b128(ov, rs_y, m * y_row + coff, 0, 2);
+            if (BNR) {
+                // (rows beyond M: their accumulators are zero -- the loaders fill such rows with zeros -- and so are the operands)
+                const uint32_t bits = (pkb >> 4) | nomask;
+                const float4 y4 = make_float4(__uint_as_float(yv[q][0]), __uint_as_float(yv[q][1]), __uint_as_float(yv[q][2]),
+                                              __uint_as_float(yv[q][3]));
+                const float g0 = (bits & 1u) ? o.x : 0.f, g1 = (bits & 2u) ? o.y : 0.f, g2 = (bits & 4u) ? o.z : 0.f,
+                            g3 = (bits & 8u) ? o.w : 0.f;
+                r1.x += g0; r1.y += g1; r1.z += g2; r1.w += g3;
+                r2.x += g0 * (y4.x - mu.x) * is.x; r2.y += g1 * (y4.y - mu.y) * is.y;
+                r2.z += g2 * (y4.z - mu.z) * is.z; r2.w += g3 * (y4.w - mu.w) * is.w;
+                gmx = max(max(gmx, __float_as_uint(g0) & 0x7fffffffu), max(__float_as_uint(g1) & 0x7fffffffu,
+                          max(__float_as_uint(g2) & 0x7fffffffu, __float_as_uint(g3) & 0x7fffffffu)));
+                asm volatile("" : "+v"(gmx), "+v"(r1.x), "+v"(r2.x));      // (here, not at the end of the sub-tile with 48 values kept live for it)
+            }
+        };
+        ws_static_for<0, 12>(quad);
+        __builtin_amdgcn_sched_barrier(0);
+        if (BNR) {
+            // the four lane groups (lane >> 4) hold the same four channels: fold, then lanes 0 .. 15 write their channels' pairs
+            float v[8] = {r1.x, r2.x, r1.y, r2.y, r1.z, r2.z, r1.w, r2.w};
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                v[e] += __shfl_xor(v[e], 16, 64);
+                v[e] += __shfl_xor(v[e], 32, 64);
+            }
+            const uint32_t po = (lane < 16 && mw0 < a.M && c0 < a.N) ? ((uint32_t)(mw0 / WS_STAT_ROWS_C) * (uint32_t)a.N + (uint32_t)c0) * 8u : OOB;
+            const u32x4_b p0 = {__float_as_uint(v[0]), __float_as_uint(v[1]), __float_as_uint(v[2]), __float_as_uint(v[3])};
+            const u32x4_b p1 = {__float_as_uint(v[4]), __float_as_uint(v[5]), __float_as_uint(v[6]), __float_as_uint(v[7])};
+            __builtin_amdgcn_raw_buffer_store_b128(p0, rs_p, po, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(p1, rs_p, po + 16u, 0, 0);
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");          // this sub-tile's reads of its staging area and of the masks
+        static_assert(NS == 1 || NS == 3, "one or three sub-tiles per wave tile");
+        if constexpr (NS == 3 && h == 0) stage_acc(acc3[2], stage0);
+    });
+    if (BNR && a.bnr_gmax != nullptr) {      // max |g| of the wave tile, for the plane scale of dy (dml_h2_bound_bn_bwd)
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) gmx = max(gmx, (uint32_t)__shfl_xor((int)gmx, o, 64));
+        if (lane == 0 && gmx != 0)
+            atomicMax(reinterpret_cast<uint32_t*>(a.bnr_gmax) + ((blockIdx.x * 16u + (uint32_t)(mwt / WS_STAT_ROWS_C) + (uint32_t)(nw0 >> 6)) & 1023u), gmx);
     }
 }
 
@@ -1748,7 +1927,10 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
 
 typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
 
-template <int MW, int NW, int MODE, int NLD, int PL = 1, int MT = WS_MT>
+// EPI (two planes, data gradient): 0 no epilogue operand, 1 accumulate / identity-branch gradient, 2 fused BatchNorm-backward sums,
+// 3 both -- ONE epilogue per instantiation (all of them behind run-time branches in one kernel: 144 accumulators live at a four-way
+// fork, 400-700 bytes of scratch per lane)
+template <int MW, int NW, int MODE, int NLD, int PL = 1, int MT = WS_MT, int EPI = 0>
 __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs a, const uint32_t x_bytes, const uint32_t w_bytes) {
     typedef bf16_t T;
     static_assert(MW * NW == 4, "four consumer waves, one per SIMD");
@@ -1811,6 +1993,9 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         asm volatile("" ::: "memory");
     };
     constexpr int A_PLANE = BM * BK * 2, B_PLANE = BN * BK * 2;      // bytes from the hi plane to the lo plane inside a stage
+    constexpr bool EPI_OPS = PL == 2 && MODE == 1 && !PRIV_STAGE && DML_WS_EPI_OPS != 0;
+    static_assert(EPI == 0 || EPI_OPS, "epilogue operands: two-plane data gradients");
+    constexpr bool hold2 = EPI != 0 && !priv;
 
     for (int tile = first_tile; tile < ntiles; tile += (int)gridDim.x) {
         const int blk_m = ws_tile_m<PL>(tile, a), blk_n = ws_tile_n<PL>(tile, a);
@@ -1896,7 +2081,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                 ah[0] = WS_FRAG(sb + a_off[0]);
                 al[0] = WS_FRAG(sb + a_off[0] + A_PLANE);
             }
-            auto step = [&](auto pc, mfma_f16x8 (&bc)[NT], mfma_f16x8 (&bn)[NT], const bool has_next) {
+            auto step = [&](auto pc, mfma_f16x8 (&bc)[NT], mfma_f16x8 (&bn)[NT], const bool has_next, const bool rel) {
                 constexpr int P = decltype(pc)::value;
                 const char* sb = smem + (g % NST) * SB;
                 // (last step of the tile: the "next" reads fall on this stage again and are never used)
@@ -1930,7 +2115,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                         // every read of stage g has been issued (the tile's LAST stage is announced after the epilogue, which
                         // stages the output rows in its slot)
                         asm volatile("" ::: "memory");
-                        if (has_next || priv) ws_st(consumed + wave, g + 1);
+                        if (rel || priv) ws_st(consumed + wave, g + 1);
                         if (!(DML_WS_ABL & 1)) al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
                     }
                     __builtin_amdgcn_sched_barrier(0);
@@ -1965,7 +2150,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                         asm volatile("" ::: "memory");
                         // every read of stage g has been issued (the tile's LAST stage is announced after the epilogue, which
                         // stages the output rows in its slot)
-                        if (has_next || priv) ws_st(consumed + wave, g + 1);
+                        if (rel || priv) ws_st(consumed + wave, g + 1);
                         if (!(DML_WS_ABL & 1)) {
                             ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
                             al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
@@ -2002,12 +2187,13 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                 __builtin_amdgcn_sched_barrier(0);
                 ++g;
             };
+            // (a data gradient with epilogue operands holds back the slots of its last TWO K stages: conv_epilogue_rows_ops)
             int kt = 0;
             for (; kt + 1 < KT; kt += 2) {
-                step(std::integral_constant<int, 0>{}, bhA, bhB, true);
-                step(std::integral_constant<int, 1>{}, bhB, bhA, kt + 2 < KT);
+                step(std::integral_constant<int, 0>{}, bhA, bhB, true, !(hold2 && kt + 2 == KT));
+                step(std::integral_constant<int, 1>{}, bhB, bhA, kt + 2 < KT, kt + 2 < KT && !(hold2 && kt + 3 == KT));
             }
-            if (kt < KT) step(std::integral_constant<int, 0>{}, bhA, bhB, false);
+            if (kt < KT) step(std::integral_constant<int, 0>{}, bhA, bhB, false, false);
         }
         // cut the accumulators' live ranges (see conv_igemm_kernel), then the shared epilogue per 48-row group
 #pragma unroll
@@ -2046,8 +2232,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         // between (2 x 96 register moves): three inlined copies -- what a compile-time sub-tile index costs; a run-time index into
         // acc would send all of it through scratch memory -- made these kernels 10-19 K instructions, more than the instruction
         // cache two CUs share.
+        if constexpr (EPI != 0)
+            conv_epilogue_rows_ops<NT, MT / 3, (EPI & 1) != 0, (EPI & 2) != 0>(
+                acc3, a, blk_m * BM + wm * (16 * MT), blk_n * BN + wn * 64, lane, rows_stage,
+                priv ? rows_stage : smem + ((g - 2) % NST) * SB + wave * (WS_STAT_ROWS * 256), smem + NST * SB + 64 + wave * MASK_STAGE);
 #pragma clang loop unroll(disable)
-        for (int h = 0; h < MT / 3; ++h) {
+        for (int h = 0; h < (EPI != 0 ? 0 : MT / 3); ++h) {
             const int mw0 = blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, nw0 = blk_n * BN + wn * 64;
             if constexpr (PL == 1) conv_epilogue<bf16_t, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);
             else if (MODE == 0 && (a.bias != nullptr || a.post_scale != nullptr)) {
@@ -2055,7 +2245,7 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             } else if (PRIV_STAGE) {
                 if constexpr (PRIV_STAGE) conv_epilogue_rows8<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
             } else {
-                conv_epilogue_rows<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage, smem + NST * SB + 64 + wave * MASK_STAGE);
+                conv_epilogue_rows<NT, MODE, !EPI_OPS>(acc3[0], a, mw0, nw0, lane, rows_stage, smem + NST * SB + 64 + wave * MASK_STAGE);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // its reads of the staging area, before the next group's writes
             }
             if constexpr (MT == 9) {
@@ -2111,6 +2301,7 @@ static bool conv_ws_planes_eligible(const ConvArgs& a, const int mode) {
     // half of every tile empty: zero weight rows through the descriptor's range check, no stores; still ahead of the three-term
     // kernel those layers took before: whole step +0.4 %, two interleaved pairs)
     if ((a.C % BK) != 0 || a.R * a.S > 32 || (a.N % 64) != 0) return false;
+    if (mode == 1 && a.Ktot < 2 * BK) return false;      // (conv_epilogue_rows_ops stages in the slots of a tile's last two K stages)
     // whole 16-byte vectors of the fp32 output and of every epilogue operand (conv_epilogue_rows)
     if ((a.ldy & 3) != 0 || (a.post_res != nullptr && (a.post_ldres & 3) != 0) ||
         ((reinterpret_cast<uintptr_t>(a.y) | reinterpret_cast<uintptr_t>(a.post_res) | reinterpret_cast<uintptr_t>(a.bias) |
@@ -3513,12 +3704,26 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             const int ntiles = a.nblk_m * a.nblk_n;
             const int grid = ntiles < CUS ? ntiles : CUS;
             const uint32_t xpb = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2), wpb = (uint32_t)((int64_t)a.N * a.Ktot * 2);
-            if (n64)
-                hipLaunchKernelGGL((conv_ws_kernel<4, 1, MODE, NLD, 2, 3>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
-            else if (wide)
-                hipLaunchKernelGGL((conv_ws_kernel<1, 4, MODE, NLD, 2>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
-            else
-                hipLaunchKernelGGL((conv_ws_kernel<2, 2, MODE, NLD, 2>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+            auto go = [&](auto epi_c) {
+                constexpr int EPI = decltype(epi_c)::value;
+                if (n64)
+                    hipLaunchKernelGGL((conv_ws_kernel<4, 1, MODE, NLD, 2, 3, EPI>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+                else if (wide)
+                    hipLaunchKernelGGL((conv_ws_kernel<1, 4, MODE, NLD, 2, WS_MT, EPI>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+                else
+                    hipLaunchKernelGGL((conv_ws_kernel<2, 2, MODE, NLD, 2, WS_MT, EPI>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+            };
+            // data gradients: one instantiation per set of epilogue operands (conv_epilogue_rows_ops)
+            const int epi = (MODE == 1 && DML_WS_EPI_OPS != 0)
+                                ? ((a.accum != 0 || a.res_dz != nullptr) ? 1 : 0) | (a.bnr_partials != nullptr ? 2 : 0) : 0;
+            if constexpr (MODE == 1 && DML_WS_EPI_OPS != 0) {
+                if (epi == 3) go(std::integral_constant<int, 3>{});
+                else if (epi == 2) go(std::integral_constant<int, 2>{});
+                else if (epi == 1) go(std::integral_constant<int, 1>{});
+                else go(std::integral_constant<int, 0>{});
+            } else {
+                go(std::integral_constant<int, 0>{});
+            }
             DML_LAUNCH_CHECK();
             return 0;
         }
