@@ -153,7 +153,8 @@ __device__ __forceinline__ void amax_publish(uint32_t amx, uint32_t* __restrict_
     if ((threadIdx.x & 63) == 0) sh_amax[threadIdx.x >> 6] = amx;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const uint32_t m = max(max(sh_amax[0], sh_amax[1]), max(sh_amax[2], sh_amax[3]));
+        uint32_t m = sh_amax[0];
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) m = max(m, sh_amax[w]);      // (blocks of 1 .. 4 waves)
         if (m != 0) atomicMax(words + ((blockIdx.x + blockIdx.y * gridDim.x) & 1023u), m);
     }
 }
@@ -350,10 +351,11 @@ __global__ __launch_bounds__(256) void bn_apply_planes8_kernel(
 
 // geometry shared by the column-stationary kernels: CB vector columns x RB row lanes per 256-thread block
 struct ColGeom { int CB, RB, col_chunks, rows_per_block, row_blocks; };
-static ColGeom col_geom(int64_t M, int NV, int U, int target_blocks) {
+static ColGeom col_geom(int64_t M, int NV, int U, int target_blocks, const int threads = 256) {
     ColGeom g;
-    g.CB = NV < 256 ? NV : 256;
-    g.RB = 256 / g.CB;
+    g.CB = NV < threads ? NV : threads;
+    g.RB = threads / g.CB;
+    target_blocks *= 256 / threads;
     g.col_chunks = (NV + g.CB - 1) / g.CB;
     const int64_t step = (int64_t)g.RB * U;
     int64_t rpb = (M * g.col_chunks + target_blocks - 1) / target_blocks;
@@ -1041,19 +1043,27 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     }
     const int V = dtype == DML_BF16 ? 8 : 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
+    // fp32 tensors: ONE-WAVE workgroups.  In the f16x2 backward this kernel runs on the main stream while a weight-gradient kernel
+    // of the side stream holds every CU with one persistent 7-wave workgroup of 256 registers per lane -- 3 SIMDs full, 256 registers
+    // free on the fourth.  A 4-wave block of ~128 registers per lane does not fit beside it and waited for a weight-gradient
+    // workgroup to retire (in the overlapped trace this kernel lasted 175 us per launch against 66 alone); one-wave blocks start at
+    // once, two per CU: 80.35 -> 79.15 ms per step, alone unchanged (profiles/r05_ab_bn_bwd_one_wave_blocks.txt).
+    // DML_BN_BWD_THREADS=256: the old geometry (A/B)
+    static const int bt_env = getenv("DML_BN_BWD_THREADS") ? atoi(getenv("DML_BN_BWD_THREADS")) : 64;
+    const int bt = (dtype == DML_F32 && (bt_env == 64 || bt_env == 128 || bt_env == 256)) ? bt_env : 256;
     if (dtype == DML_F32 && planes && !dy && !amax && (mask || !relu) && (N & 7) == 0 && (lddz & 3) == 0 && (ldy & 3) == 0 &&
         (ldp & 7) == 0 && (plane_stride & 7) == 0 && (!dres || (lddres & 3) == 0) &&
         ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y) |
           reinterpret_cast<uintptr_t>(dres)) & 15) == 0 && (reinterpret_cast<uintptr_t>(mask) & 1) == 0) {
         // dy as planes only: eight channels per thread, 16-byte accesses throughout
-        const ColGeom g8 = col_geom(M, N / 8, 2, stream_blocks(M, N, dtype));
-        hipLaunchKernelGGL((bn_bwd_apply_planes8_kernel<2>), dim3(g8.row_blocks, g8.col_chunks), dim3(256), 0, st, (const float*)dz,
+        const ColGeom g8 = col_geom(M, N / 8, 2, stream_blocks(M, N, dtype), bt);
+        hipLaunchKernelGGL((bn_bwd_apply_planes8_kernel<2>), dim3(g8.row_blocks, g8.col_chunks), dim3(bt), 0, st, (const float*)dz,
                            (const float*)y, mask, coef, (float*)dres, M, N, lddz, ldy, lddres, relu, gscale, dres_accum, g8.CB, g8.RB,
                            g8.rows_per_block, static_cast<_Float16*>(planes), plane_stride, (int)ldp, unscale);
         DML_LAUNCH_CHECK();
         return 0;
     }
-    const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype));
+    const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype), bt);
     dim3 grid(g.row_blocks, g.col_chunks);
     if (dtype == DML_BF16)
         hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)dz,
@@ -1061,7 +1071,7 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
                            ldz, lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block,
                            reinterpret_cast<uint32_t*>(amax), (_Float16*)nullptr, (int64_t)0, 0, (const float*)nullptr);
     else
-        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 2>), grid, dim3(256), 0, st, (const float*)dz,
+        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<float, 2>), grid, dim3(bt), 0, st, (const float*)dz,
                            (const float*)y, (const float*)z, mask, coef, (float*)dy, (float*)dres, M, N, lddz, ldy, ldz,
                            lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block, reinterpret_cast<uint32_t*>(amax),
                            static_cast<_Float16*>(planes), plane_stride, (int)ldp, unscale);

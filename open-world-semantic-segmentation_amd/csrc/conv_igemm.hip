@@ -4112,7 +4112,10 @@ extern "C" int dml_conv_wgrad(const DmlWgradDesc* d, void* stream) {
         else
             hipLaunchKernelGGL(conv_wgrad_ws_kernel<false>, wgrid, wblock, 0, st, a, xpb, ypb, nitems);
         const int64_t nrs = (int64_t)a.N * a.R * a.S;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, 256), 1), dim3(256), 0, st, d->ws, d->dw, sk, nrs,
+        // (one-wave blocks: they start beside the persistent data-gradient workgroups of the other stream instead of waiting for one
+        // to retire -- 28.6 us per launch in the overlapped trace against 9.8 alone, 122 launches per step; see dml_bn_bwd_apply)
+        static const int rt = getenv("DML_WGRAD_REDUCE_THREADS") ? atoi(getenv("DML_WGRAD_REDUCE_THREADS")) : 64;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(grid_for(nrs * cm, rt, 256 * 8 * (256 / rt)), 1), dim3(rt), 0, st, d->ws, d->dw, sk, nrs,
                            cm, d->C, 1, 0);
         DML_LAUNCH_CHECK();
         return 0;
