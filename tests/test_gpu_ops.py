@@ -1529,12 +1529,17 @@ def test_planes_only_operand_is_refused_where_the_planes_kernels_cannot_take_it(
     torch.cuda.synchronize()
 
 
-@pytest.mark.parametrize("accum,relu", [(0, 1), (1, 1), (1, 0), (2, 1)])
-def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
+@pytest.mark.parametrize("accum,relu,Cin,bnr", [(0, 1, 128, 1), (1, 1, 128, 1), (1, 0, 128, 1), (2, 1, 128, 1),
+                                                 # the other tile configurations of conv_epilogue_rows_ops: 144 x 256 (Cin = 256: three
+                                                 # 48-row sub-tiles per wave tile, the operand ring crosses them), 192 x 64 (Cin = 64: one
+                                                 # sub-tile), a half-empty last 128-wide block (Cin = 320); operands without the BN sums
+                                                 (2, 1, 256, 1), (1, 0, 256, 1), (0, 1, 256, 1), (2, 1, 64, 1), (0, 0, 64, 1), (2, 1, 320, 1),
+                                                 (1, 1, 256, 0), (2, 1, 256, 0), (2, 1, 64, 0), (1, 1, 320, 0)])
+def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu, Cin, bnr):
     """DmlConvDesc.bnr_* on fp32 tensors (the two-plane kernel's row epilogue): the data gradient writes the BN-backward sums of
     the tensor it stores per 48 rows -- what dml_bn_bwd_reduce computes from that tensor -- and raises max |g| in bnr_gmax; a
     ragged last group, the accumulate path, ReLU mask of one byte per four channels.  Other fp32 kernels refuse the request."""
-    B, Hh, Ww, Cin, Cout, k = 2, 13, 11, 128, 64, 3          # dgrad output: M = 286 rows (5.96 groups of 48) x 128 channels
+    B, Hh, Ww, Cout, k = 2, 13, 11, 64, 3          # dgrad output: M = 286 rows (5.96 groups of 48; 1.99 wave tiles of 144) x Cin channels
     M = B * Hh * Ww
     gyd = (torch.randn(B, Hh, Ww, Cout, device="cuda") * 1e-2).contiguous()
     wt = (torch.randn(Cin, k, k, Cout, device="cuda") * 0.05).contiguous()          # wt[Cin][R][S][Cout]
@@ -1556,10 +1561,14 @@ def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
     d.x_planes, d.x_unscale, d.x_plane_stride = ap.data_ptr(), aw.data_ptr() + 4096, ap.shape[1]
     d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
     assert lib.dml_conv_stat_rows(C.byref(d)) == 48
-    d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr()
-    d.bnr_partials, d.bnr_ldy, d.bnr_relu, d.bnr_gmax = part.data_ptr(), Cin, relu, gmax.data_ptr()
+    if bnr:
+        d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), bits.data_ptr(), mean.data_ptr(), invstd.data_ptr()
+        d.bnr_partials, d.bnr_ldy, d.bnr_relu, d.bnr_gmax = part.data_ptr(), Cin, relu, gmax.data_ptr()
+    guard = dx0.clone() if accum == 2 else None
     chk(lib.dml_conv_igemm(C.byref(d), st()))
     torch.cuda.synchronize()
+    if guard is not None:
+        assert torch.equal(guard, dx0)                 # (the identity gradient is an input)
     # the stored tensor itself: conv (+ the earlier value)
     ref = torch.nn.functional.conv_transpose2d(gyd.permute(0, 3, 1, 2).double(), wt.permute(3, 0, 1, 2).double(), padding=1)
     ref = ref.permute(0, 2, 3, 1)
@@ -1569,6 +1578,9 @@ def test_two_plane_dgrad_emits_bn_backward_partials(lib, accum, relu):
         rmk = ((rbits.view(M, Cin // 4, 1) >> torch.arange(4, device="cuda").view(1, 1, 4)) & 1).reshape(B, Hh, Ww, Cin).double()
         ref = ref + dx0.double() * rmk
     assert (dx.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    if not bnr:
+        assert torch.all(part == 7.0) and gmax.max().item() == 0.0
+        return
     g = dx.view(M, Cin).double()
     if relu:
         mk = ((bits.view(M, Cin // 4, 1) >> torch.arange(4, device="cuda").view(1, 1, 4)) & 1).reshape(M, Cin).double()
