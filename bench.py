@@ -157,6 +157,8 @@ def _conv_flops(d, igemm):
         # data gradient: same MACs as the forward conv = dY pixels x Cout x taps x Cin
         cin = 304 if d.N == 320 else d.N
         return 2.0 * d.B * d.Hi * d.Wi * d.C * d.R * d.S * cin
+    if d.C == 12 and d.R == 4:          # the stem in space-to-depth form (4x4 on 12 channels): the MACs of the 7x7 on 3 channels
+        return 2.0 * d.B * d.Ho * d.Wo * d.N * 49 * 3
     cin = 3 if d.C == 8 else (304 if d.C == 320 else d.C)
     return 2.0 * d.B * d.Ho * d.Wo * d.N * d.R * d.S * cin
 
@@ -236,6 +238,8 @@ def _conv_class(d, igemm):
     else:
         kind = "fwd" if igemm else "wgrad"
         cin, cout, hw = (3 if d.C == 8 else (304 if d.C == 320 else d.C)), d.N, (d.Ho, d.Wo)
+        if d.C == 12 and d.R == 4:      # the stem in space-to-depth form: labelled as the convolution it computes
+            return kind, "7x7 3->%d @%dx%d s2" % (cout, hw[0], hw[1])
     lab = "%dx%d %d->%d @%dx%d" % (d.R, d.S, cin, cout, hw[0], hw[1])
     if d.stride != 1:
         lab += " s%d" % d.stride

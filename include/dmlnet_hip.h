@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DML_ABI_VERSION 4
+#define DML_ABI_VERSION 5
 
 enum { DML_F32 = 0, DML_BF16 = 1 };
 enum { DML_EINVAL = -1, DML_EALIGN = -2, DML_EUNSUPPORTED = -3 };
@@ -244,6 +244,15 @@ int dml_bias_grad_ws(const void* dy, float* db, int64_t M, int N, int ldy, int d
 /* x[B,C,H,W] fp32 (the reference's input layout) -> NHWC with C padded to Cp, dtype. */
 int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W, int Cp, int dtype,
                    void* stream);
+/* Space-to-depth form of a k x k stride-2 convolution with padding (k - 1) / 2 (odd) on few channels -- the stem, 7x7 s2 on the 3
+ * image channels (backbone/resnet.py:139): x2[B][H/2][W/2][4 C] fp32 with channel (dy * 2 + dx) * C + c = x[b][c][2 y2 + dy][2 x2 + dx]
+ * (H, W even), w2[N][k2][k2][4 C] with k2 = (k + 1) / 2 holding w[n][2 r2 + dy - 1][2 s2 + dx - 1][c] (zero outside 0 .. k - 1).  The
+ * convolution is then a k2 x k2 STRIDE-1 one with padding ((k - 1) / 2 + 1) / 2 on x2 (DmlConvDesc: Ho = H / 2, Wo = W / 2 given
+ * explicitly): the same products on K = 4 C k2^2 (192) instead of 8 k^2 (392) for the image padded to 8 channels.
+ * dml_s2d_wgrad adds a weight gradient computed in that form (dw2[N][k2][k2][4 C]) to the parameter's dw[N][k][k][C]. */
+int dml_pack_input_s2d(const float* x_nchw, float* x2, int B, int C, int H, int W, void* stream);
+int dml_s2d_weights(const float* w, float* w2, int N, int k, int C, void* stream);
+int dml_s2d_wgrad(const float* dw2, float* dw, int N, int k, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * BatchNorm2d (112 instances; train: batch statistics, eval: running statistics).

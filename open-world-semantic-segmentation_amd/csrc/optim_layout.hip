@@ -431,6 +431,69 @@ extern "C" int dml_h2_split_table(const DmlH2Desc* table_device, int count, void
     return 0;
 }
 
+// ---- space-to-depth form of a k x k stride-2 convolution on few channels (the stem: 7x7 s2 on 3 channels) -----------------
+// out[yo][xo] = sum_{t,u,c} w[t][u][c] x[2 yo - p + t][2 xo - p + u][c], p = (k - 1) / 2 odd.  With x2[y2][x2][(dy 2 + dx) C + c] =
+// x[2 y2 + dy][2 x2 + dx][c] (half the map, 4 C channels) and t = 2 r2 + dy - 1, u = 2 s2 + dx - 1 this is a (k + 1) / 2 square
+// STRIDE-1 convolution with padding (p + 1) / 2 on x2 whose taps outside 0 .. k - 1 carry zero weights: K = 4 C ((k + 1) / 2)^2 --
+// 192 for the stem -- instead of the 8 k^2 = 392 of the image padded to 8 channels (16-byte vectors per tap).  Same products;
+// the exact-fp32 stem forward 1.36 -> 0.66 ms, its weight gradient 2.81 -> 1.42 ms (tools/probe_stem_s2d.py).
+namespace {
+__global__ __launch_bounds__(256) void pack_input_s2d_kernel(const float* __restrict__ x, float* __restrict__ y, int B, int C, int H, int W) {
+    const int H2 = H >> 1, W2 = W >> 1, C4 = 4 * C;
+    const int64_t total = (int64_t)B * H2 * W2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / ((int64_t)H2 * W2);
+        const int64_t rem = i - b * H2 * W2;
+        const int y2 = (int)(rem / W2), x2 = (int)(rem - (int64_t)y2 * W2);
+        float* o = y + i * C4;
+        for (int c = 0; c < C; ++c) {
+            const float* src = x + ((b * C + c) * H + 2 * y2) * W + 2 * x2;
+            o[c] = src[0]; o[C + c] = src[1]; o[2 * C + c] = src[W]; o[3 * C + c] = src[W + 1];      // (any alignment of the image)
+        }
+    }
+}
+// w[N][k][k][C] <-> w2[N][k2][k2][4 C]; TO_S2D: w2 = gather(w) (zero taps outside), else: w += scatter(w2) (the weight gradient)
+template <bool TO_S2D>
+__global__ __launch_bounds__(256) void s2d_weights_kernel(float* __restrict__ w, float* __restrict__ w2, int N, int k, int C) {
+    const int k2 = (k + 1) / 2, C4 = 4 * C, off = 2 * (((k - 1) / 2 + 1) / 2) - (k - 1) / 2;      // t = 2 r2 + dy - off
+    const int total = N * k2 * k2 * C4;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int j = i % C4, s2 = (i / C4) % k2, r2 = (i / (C4 * k2)) % k2, n = i / (C4 * k2 * k2);
+        const int c = j % C, dx = (j / C) & 1, dy = j / (2 * C);
+        const int t = 2 * r2 + dy - off, u = 2 * s2 + dx - off;
+        const bool in = t >= 0 && t < k && u >= 0 && u < k;
+        const int wi = ((n * k + t) * k + u) * C + c;
+        if (TO_S2D) w2[i] = in ? w[wi] : 0.f;
+        else if (in) w[wi] += w2[i];
+    }
+}
+}  // namespace
+
+extern "C" int dml_pack_input_s2d(const float* x_nchw, float* y, int B, int C, int H, int W, void* stream) {
+    if (!x_nchw || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DML_EINVAL;
+    if ((H | W) & 1) return DML_EALIGN;
+    hipLaunchKernelGGL(pack_input_s2d_kernel, dim3(grid_for((int64_t)B * (H / 2) * (W / 2), 256, 256 * 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), x_nchw, y, B, C, H, W);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dml_s2d_weights(const float* w, float* w2, int N, int k, int C, void* stream) {
+    if (!w || !w2 || N <= 0 || C <= 0 || k < 3 || (k & 1) == 0 || (((k - 1) / 2) & 1) == 0) return DML_EINVAL;
+    const int k2 = (k + 1) / 2;
+    hipLaunchKernelGGL(s2d_weights_kernel<true>, dim3(grid_for((int64_t)N * k2 * k2 * 4 * C, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), const_cast<float*>(w), w2, N, k, C);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int dml_s2d_wgrad(const float* dw2, float* dw, int N, int k, int C, void* stream) {
+    if (!dw2 || !dw || N <= 0 || C <= 0 || k < 3 || (k & 1) == 0 || (((k - 1) / 2) & 1) == 0) return DML_EINVAL;
+    const int k2 = (k + 1) / 2;
+    hipLaunchKernelGGL(s2d_weights_kernel<false>, dim3(grid_for((int64_t)N * k2 * k2 * 4 * C, 256)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), dw, const_cast<float*>(dw2), N, k, C);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dml_unpad_wgrad(const float* src, float* dst, int N, int RS, int Cm, int Cp, void* stream) {
     if (!src || !dst || Cp < Cm) return DML_EINVAL;
     hipLaunchKernelGGL(unpad_wgrad_kernel, dim3(grid_for((int64_t)N * RS * Cm, 256)), dim3(256), 0,

@@ -65,6 +65,9 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_bias_grad),
     DML_ENTRY(dml_bias_grad_ws),
     DML_ENTRY(dml_pack_input),
+    DML_ENTRY(dml_pack_input_s2d),
+    DML_ENTRY(dml_s2d_weights),
+    DML_ENTRY(dml_s2d_wgrad),
     DML_ENTRY(dml_bn_finalize),
     DML_ENTRY(dml_bn_moments),
     DML_ENTRY(dml_bn_finalize_moments),

@@ -109,6 +109,9 @@ _PROTOS = {
     "dml_bias_grad": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p]),
     "dml_bias_grad_ws": (c_i, [c_p, c_p, c_i64, c_i, c_i, c_i, c_p, c_i64, c_p]),
     "dml_pack_input": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
+    "dml_pack_input_s2d": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
+    "dml_s2d_weights": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "dml_s2d_wgrad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_moments": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
     "dml_bn_finalize_moments": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
@@ -193,7 +196,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.dml_abi_version() != 4:
+    if lib.dml_abi_version() != 5:
         raise DmlError("libdmlnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -31,6 +31,28 @@ from ._lib import DML_BF16, DML_F32, STAT_ROWS, ConvDesc, WgradDesc
 _PAD_CIN = 8          # stem input channels 3 -> 8 so that a 16-byte vector never straddles a filter tap
 
 
+class _S2DConv:
+    """The stem's k x k stride-2 convolution (resnet.py:139: 7x7, padding 3, on the 3 image channels) in space-to-depth form: a
+    (k + 1) / 2 square stride-1 convolution on [B][H/2][W/2][4 C] (dml_pack_input_s2d) with the weights regrouped per step
+    (dml_s2d_weights) and the weight gradient scattered back into the parameter's layout (dml_s2d_wgrad).  Same products on
+    K = 192 instead of the 392 of the image padded to 8 channels.  Quacks like the nn.Conv2d the plan builder reads."""
+
+    def __init__(self, conv: nn.Conv2d, Ho: int, Wo: int):
+        k, p = conv.kernel_size[0], conv.padding[0]
+        self.real, self.k = conv, k
+        self.kernel_size, self.stride, self.dilation = ((k + 1) // 2,) * 2, (1, 1), (1, 1)
+        self.padding = ((p + 1) // 2,) * 2
+        self.in_channels, self.out_channels = 4 * conv.in_channels, conv.out_channels
+        self.weight, self.bias = conv.weight, conv.bias
+        self.out_hw = (Ho, Wo)
+
+    @staticmethod
+    def fits(conv: nn.Conv2d, H: int, W: int) -> bool:
+        k, p = conv.kernel_size[0], conv.padding[0]
+        return (conv.kernel_size == (k, k) and k % 2 == 1 and conv.stride == (2, 2) and conv.padding == (p, p) and p == (k - 1) // 2
+                and p % 2 == 1 and conv.dilation == (1, 1) and conv.groups == 1 and conv.bias is None and H % 2 == 0 and W % 2 == 0)
+
+
 def _dt(dtype: torch.dtype) -> int:
     if dtype == torch.float32:
         return DML_F32
@@ -535,6 +557,8 @@ class Plan:
         s, d, p = conv.stride[0], conv.dilation[0], conv.padding[0]
         Ho = (x.H + 2 * p - d * (kh - 1) - 1) // s + 1
         Wo = (x.W + 2 * p - d * (kw - 1) - 1) // s + 1
+        if isinstance(conv, _S2DConv):
+            Ho, Wo = conv.out_hw                  # (the zero taps of the regrouped filter reach one row / column further)
         return kh, kw, s, d, p, Ho, Wo
 
     def prep_weight(self, conv: nn.Conv2d, Cp: int, need_wt: bool, src_ptr=None, N=None, x_bytes=0, dy_bytes=0):
@@ -543,6 +567,13 @@ class Plan:
         `x_bytes` / `dy_bytes`: extents of the forward / data-gradient operand tensors of this conv."""
         N, Cm = N or conv.out_channels, conv.in_channels
         kh, kw = conv.kernel_size
+        if isinstance(conv, _S2DConv):
+            assert Cp == Cm and self.dtype == torch.float32 and not need_wt
+            w = torch.empty(N * kh * kw * Cm, dtype=torch.float32, device=self.device)
+            w.tiled = False
+            self.keep.append(w)
+            self.call(self.fwd, self.lib.dml_s2d_weights, conv.weight.data_ptr(), w.data_ptr(), N, conv.k, conv.real.in_channels)
+            return w, None
         w = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device)
         wt = torch.empty(N * kh * kw * Cp, dtype=self.dtype, device=self.device) if need_wt else None
         # tile-major copies for the LDS-DMA kernels (DmlConvDesc.w_tiled): bf16, the GEMM's K a multiple of 32 per filter tap and
@@ -638,6 +669,11 @@ class Plan:
             h2 = self.h2_of(x, self.bwd) + self.h2_of(dy, self.bwd)
         first = len(self.bwd)
         Nw, tmp = conv.out_channels, None
+        s2d = isinstance(conv, _S2DConv)
+        if s2d:
+            assert not pad_rows
+            tmp = self.fbuf(Nw * kh * kw * Cm)
+            self.call(self.bwd, self.lib.dml_fill_f32, tmp.data_ptr(), tmp.numel(), 0.0)
         if pad_rows and pad_rows != conv.out_channels:
             Nw = pad_rows
             tmp = self.fbuf(Nw * kh * kw * Cm)
@@ -661,7 +697,9 @@ class Plan:
                 self.flush_wgrad()
             return
         self.call(self.bwd, self.lib.dml_conv_wgrad, C.byref(dsc))
-        if tmp is not None:
+        if s2d:
+            self.call(self.bwd, self.lib.dml_s2d_wgrad, tmp.data_ptr(), gptr, conv.out_channels, conv.k, conv.real.in_channels)
+        elif tmp is not None:
             self.call(self.bwd, self.lib.dml_unpad_wgrad, tmp.data_ptr(), gptr, conv.out_channels, kh * kw, Cm, Cm)
         # weight gradients only feed the optimizer: they run on a side stream, next to the HBM-bound BN backward
         # and the data gradient of the following layers (Plan.run_backward)
@@ -964,12 +1002,22 @@ class Plan:
             self.h2_bound_args = self.call(self.fwd, lib.dml_h2_bound_bn_table, 0, 0)
         if n_fixed:
             self.bn_eval_args = self.call(self.fwd, lib.dml_bn_eval_coeffs_table, 0, 0)      # filled in below
-        # input packing NCHW fp32 -> NHWC (8 ch)
-        x_in = self.new(B, H, W, _PAD_CIN)
-        self.images_args = self.call(self.fwd, lib.dml_pack_input, 0, x_in.ptr, B, 3, H, W, _PAD_CIN, self.dt)
+        # input packing NCHW fp32 -> NHWC (8 ch); f16x2 plans: space-to-depth, [B][H/2][W/2][12], and the stem conv in that form
+        # (_S2DConv).  The same products in another summation order: the exact-fp32 and three-term modes keep the 7x7 stride-2 form
+        # on 8 channels so that their results stay what they were (DML_STEM_S2D=1: every fp32 plan, =0: none)
+        stem_conv = bb.conv1
+        s2d_env = os.environ.get("DML_STEM_S2D", "")
+        s2d_on = s2d_env == "1" or (s2d_env != "0" and self.f32_split == 2)
+        if self.dtype == torch.float32 and s2d_on and _S2DConv.fits(bb.conv1, H, W):
+            x_in = self.new(B, H // 2, W // 2, 4 * bb.conv1.in_channels)
+            self.images_args = self.call(self.fwd, lib.dml_pack_input_s2d, 0, x_in.ptr, B, bb.conv1.in_channels, H, W)
+            stem_conv = _S2DConv(bb.conv1, H // 2, W // 2)
+        else:
+            x_in = self.new(B, H, W, _PAD_CIN)
+            self.images_args = self.call(self.fwd, lib.dml_pack_input, 0, x_in.ptr, B, 3, H, W, _PAD_CIN, self.dt)
 
         # stem: 7x7 s2 conv + BN + ReLU, 3x3 s2 max pool (resnet.py:139-143,196-199)
-        stem = self.cbr(x_in, bb.conv1, bb.bn1, need_dgrad=False)
+        stem = self.cbr(x_in, stem_conv, bb.bn1, need_dgrad=False)
         z0 = stem.z
         Hp, Wp = (z0.H - 1) // 2 + 1, (z0.W - 1) // 2 + 1
         p0 = self.new(B, Hp, Wp, 64)

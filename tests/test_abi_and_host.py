@@ -32,7 +32,7 @@ def test_library_exports_every_declared_symbol():
     exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("dml_") and " T " in ln})
     assert exported == syms, (sorted(set(exported) - set(syms)), sorted(set(syms) - set(exported)))
     lib2 = _lib.load()
-    assert lib2.dml_abi_version() == 4
+    assert lib2.dml_abi_version() == 5
     assert lib2.dml_target_arch() == b"gfx950"
 
 

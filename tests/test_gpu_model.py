@@ -346,12 +346,20 @@ def test_against_oracle_fresh_input_all_param_grads():
     _check_against_oracles(m, img, lab, strict=False)
 
 
-def test_against_oracle_small_nonsquare_strict():
-    """Same check on a 2x3x64x96 input, where sign flips are rare: absolute bars against the fp64 gradients."""
-    m = build(seed=11)
-    img = H.synth_tensor(11, "fresh2.img", (2, 3, 64, 96))
-    lab = H.synth_labels(11, "fresh2.lab", (2, 64, 96), 16, 255, ignore_frac=0.05)
-    _check_against_oracles(m, img, lab, strict=True, seed=11)
+@pytest.mark.parametrize("products", ["exact", "bf16x3", "f16x2"])
+def test_against_oracle_nonsquare_strict(products):
+    """Same check on a NON-SQUARE 2 x 3 x 128 x 192 input with CONDITIONED weights (tests/tools/mint_golden_nonsquare.py: the betas
+    moved so that no ReLU input of the network lies within 64 * eps32 * sum|terms| -- and 6 x the reference's own fp32-vs-fp64 noise --
+    of zero, proved on the reference in fp64): absolute bars against the fp64 gradients of the oracle run at test time, one set for
+    all three fp32 arithmetic modes.  (Until round 5 this ran 2 x 3 x 64 x 96 with unconditioned weights in the exact mode only, and
+    its bar on the worst gradient, 5e-2, had been set around ONE ReLU sign flip in a 48-sample BatchNorm; which element flips moved
+    with any change of a convolution's summation order.)"""
+    torch.set_num_threads(min(32, torch.get_num_threads() or 8))
+    state = conditioned("g13n_nonsquare", 11)
+    m = build(seed=11, fp32_products=products, state=state)
+    img = H.synth_tensor(11, "g13n.img", (2, 3, 128, 192))
+    lab = H.synth_labels(11, "g13n.lab", (2, 128, 192), 16, 255, ignore_frac=0.05)
+    _check_against_oracles(m, img, lab, strict=True, seed=11, state=state)
 
 
 @pytest.mark.parametrize("num_classes,output_stride", [(16, 8), (8, 16), (24, 16), (32, 8), (21, 16), (13, 16)])
@@ -394,7 +402,7 @@ def test_default_factory_arguments_bf16_features_have_num_classes_channels():
     assert g.shape == (21, 256, 1, 1) and torch.isfinite(g).all() and g.abs().max() > 0
 
 
-def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_stride=16, prep=None):
+def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_stride=16, prep=None, state=None):
     import utils
     from oracle import dmlnet_ref as O
     if prep is not None:
@@ -405,7 +413,7 @@ def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_s
     ref = {}
     for name, dt in (("f32", torch.float32), ("f64", torch.float64)):
         o = O.deeplabv3plus_embedding_resnet101(num_classes=num_classes, output_stride=output_stride)
-        o.load_state_dict(H.synth_state_dict(H.shapes_of(o), seed=seed))
+        o.load_state_dict(state(H.shapes_of(o)) if state is not None else H.synth_state_dict(H.shapes_of(o), seed=seed))
         o = o.to(dt)
         o.train()
         o.classifier.aspp.project[3].eval()
@@ -439,9 +447,9 @@ def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_s
         assert e_hip.max() <= max(5e-2, 3 * e_ref.max()) and np.median(e_hip) <= max(5e-3, 3 * np.median(e_ref))
         return
     if strict:
-        # absolute bars on a well-conditioned case (measured: median 1.9e-4, p95 3.0e-4, one tensor at 2.6e-2 from
-        # a sign flip in a 48-sample BatchNorm; tools/debug_units.py shows every kernel self-consistent to 1e-6)
-        assert np.median(e_hip) <= TOL and np.percentile(e_hip, 95) <= 3 * TOL and e_hip.max() <= 5e-2
+        # absolute bars on the conditioned case -- every parameter gradient, max-norm against fp64 (measured, exact / bf16x3 / f16x2:
+        # median 1.5e-4 / 1.1e-4 / 0.8e-4, worst tensor 2.8e-4 / 1.8e-4 / 1.5e-4; the fp32 oracle itself: 0.6e-4 / 1.0e-4)
+        assert np.median(e_hip) <= 0.5 * TOL and np.percentile(e_hip, 95) <= TOL and e_hip.max() <= 2 * TOL
         return
     # individual tensors hit rare sign flips (either implementation can), the distribution must match
     assert np.median(e_hip) <= 3 * np.median(e_ref) + TOL
@@ -592,10 +600,14 @@ def test_baseline_size_properties(dtype, products):
 
 def test_baseline_size_f16x2_step_against_exact_fp32_step():
     """768x768 bs=16, one train step in the headline arithmetic (f16x2) against the same step with exact fp32 products (the mode
-    the golden fixtures of the small cases pin to the reference).  Logits and loss agree to 1e-4.  Parameter gradients of 9.4 M
-    pixels carry fp32 summation-order noise of a few per cent per entry whatever the products (the fp32 oracle is as far from an fp64
-    evaluation already at 2 x 768 x 768, test_gpu_bf16_parity.py::test_fp32_768_bs2_against_oracle), so the yardstick is the
-    three-term bf16 split, whose products are exact to fp32 level: f16x2 must sit as close to the exact step as that one does."""
+    the golden fixtures of the small cases pin to the reference), the three-term bf16 split beside it as yardstick.  Logits and loss
+    agree to 1e-4; sampled parameter gradients within 1e-2 (median) / 2e-2 (worst tensor) in relative 2-norm, their norms to 2e-3 (95th
+    percentile) / 5e-3 -- measured 3.8e-3 / 5.8e-3 and 4.5e-4 / 1.3e-3 -- and f16x2 as close to the exact step as the three-term split.
+    The BatchNorm of the ASPP image-pooling branch (network/utils.py:318-329: 16 samples per channel at this batch, its output
+    broadcast over the whole map) runs on its running statistics here: with batch statistics ONE of its 4096 ReLU inputs sits within
+    fp32 rounding of zero, and the side an implementation lands on moves EVERY gradient of the network by 2.3 % -- until round 5 the
+    bars of this test (5e-2 / 0.2) were set around that one event, which any change of summation order could move from one mode to
+    another (profiles/r05_stem_s2d_and_knife_edges.txt: the same three plans, 2.29e-2 apart or 3e-3 apart depending on that side)."""
     import utils
     g = torch.Generator(device="cpu").manual_seed(77)
     img = torch.randn(16, 3, 768, 768, generator=g).cuda()
@@ -609,6 +621,7 @@ def test_baseline_size_f16x2_step_against_exact_fp32_step():
         torch.cuda.empty_cache()
         assert torch.cuda.memory_allocated() < 20e9, "plans of earlier tests are still allocated"
         m = build(fp32_products=products)
+        m.classifier.aspp.convs[4][2].eval()               # (the 16-sample BatchNorm: see above)
         crit = utils.DMLLoss(alpha=0.01, ignore_index=255)
         lg, ctr, ft = m(img)
         loss = crit(lg, lab, ft)
@@ -633,7 +646,7 @@ def test_baseline_size_f16x2_step_against_exact_fp32_step():
               "%.2e max %.2e (%s); loss %.9g vs %.9g" % (mode, np.median(errs), np.percentile(errs, 95), errs.max(),
                                                       keys[int(errs.argmax())], np.median(nerr), np.percentile(nerr, 95), nerr.max(),
                                                       keys[int(nerr.argmax())], l1, l0))
-        assert np.median(errs) <= 5e-2 and errs.max() <= 0.2 and np.percentile(nerr, 95) <= 1e-2 and nerr.max() <= 3e-2, mode
+        assert np.median(errs) <= 1e-2 and errs.max() <= 2e-2 and np.percentile(nerr, 95) <= 2e-3 and nerr.max() <= 5e-3, mode
     (e3, n3), (e2, n2) = stats["bf16x3"], stats["f16x2"]
     assert np.median(e2) <= 1.5 * np.median(e3) + 1e-3 and e2.max() <= 2.0 * e3.max() + 1e-3
     assert np.median(n2) <= 1.5 * np.median(n3) + 1e-4 and np.percentile(n2, 95) <= 2.0 * np.percentile(n3, 95) + 1e-4

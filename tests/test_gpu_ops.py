@@ -400,6 +400,59 @@ def test_pack_input(lib):
         assert (y[..., 3:] == 0).all()
 
 
+@pytest.mark.parametrize("B,H,W,N", [(2, 20, 28, 64), (1, 6, 4, 8), (3, 34, 18, 24)])
+def test_space_to_depth_stem_equals_the_7x7_stride2_convolution(lib, B, H, W, N):
+    """dml_pack_input_s2d / dml_s2d_weights / dml_s2d_wgrad: the stem (backbone/resnet.py:139, nn.Conv2d(3, 64, 7, stride=2,
+    padding=3, bias=False)) as a 4x4 stride-1 convolution on the space-to-depth image.  The regrouping itself is exact (pure
+    copies, zero taps); forward and weight gradient through the library's fp32 kernels must match F.conv2d at fp32 level, including
+    the image border (the regrouped filter's zero taps reach one row / column beyond it) and an unaligned image pointer."""
+    from dmlnet._lib import ConvDesc, WgradDesc
+    g = torch.Generator().manual_seed(B * 100 + H)
+    buf = torch.randn(B * 3 * H * W + 1, generator=g).cuda()
+    img = buf[1:].view(B, 3, H, W)                               # 4-byte aligned only
+    wm = (torch.randn(N, 3, 7, 7, generator=g) * 0.1).cuda()
+    wcl = wm.permute(0, 2, 3, 1).contiguous()                     # the parameter store's layout [N][7][7][3]
+    H2, W2 = H // 2, W // 2
+    x2 = torch.empty(B, H2, W2, 12, device="cuda")
+    w2 = torch.full((N, 4, 4, 12), 9.0, device="cuda")
+    chk(lib.dml_pack_input_s2d(img.data_ptr(), x2.data_ptr(), B, 3, H, W, st()))
+    chk(lib.dml_s2d_weights(wcl.data_ptr(), w2.data_ptr(), N, 7, 3, st()))
+    torch.cuda.synchronize()
+    # the regrouping, element by element
+    want = img.view(B, 3, H2, 2, W2, 2).permute(0, 2, 4, 3, 5, 1).reshape(B, H2, W2, 12)      # channel (dy, dx, c)
+    assert torch.equal(x2, want)
+    wz = torch.zeros(N, 8, 8, 3, device="cuda")
+    wz[:, 1:, 1:, :] = wcl                                        # tap t = 2 r2 + dy - 1: one zero row / column in front
+    assert torch.equal(w2, wz.view(N, 4, 2, 4, 2, 3).permute(0, 1, 3, 2, 4, 5).reshape(N, 4, 4, 12))
+    # forward
+    ref = torch.nn.functional.conv2d(img.double(), wm.double(), stride=2, padding=3)
+    y = torch.empty(B, H2, W2, N, device="cuda")
+    d = ConvDesc(x=x2.data_ptr(), w=w2.data_ptr(), y=y.data_ptr(), bias=None, stats=None, B=B, Hi=H2, Wi=W2, C=12, ldx=12, Ho=H2, Wo=W2,
+                 N=N, ldy=N, R=4, S=4, stride=1, dil=1, pad=2, dtype=0, y_f32=0, accum=0, mode=0)
+    chk(lib.dml_conv_igemm(C.byref(d), st()))
+    torch.cuda.synchronize()
+    assert (y.permute(0, 3, 1, 2).double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
+    # weight gradient, added to whatever the parameter's gradient holds
+    gy = torch.randn(ref.shape, generator=g, dtype=torch.float64).cuda()
+    gref = torch.nn.grad.conv2d_weight(img.double(), wm.shape, gy, stride=2, padding=3)
+    dyd = gy.float().permute(0, 2, 3, 1).contiguous()
+    ws = torch.empty(1 << 22, device="cuda")
+    for split in (0, 1):
+        dw2 = torch.zeros(N, 4, 4, 12, device="cuda")
+        wg = WgradDesc(x=x2.data_ptr(), dy=dyd.data_ptr(), dw=dw2.data_ptr(), B=B, Hi=H2, Wi=W2, C=12, ldx=12, Ho=H2, Wo=W2, N=N, ldy=N,
+                       R=4, S=4, stride=1, dil=1, pad=2, dtype=0, splitk=0, Cm=12, ws=ws.data_ptr(), ws_elems=ws.numel(), f32_split=split)
+        chk(lib.dml_conv_wgrad(C.byref(wg), st()))
+        dw = torch.full((N, 7, 7, 3), 1.0, device="cuda")
+        chk(lib.dml_s2d_wgrad(dw2.data_ptr(), dw.data_ptr(), N, 7, 3, st()))
+        torch.cuda.synchronize()
+        err = ((dw - 1.0).permute(0, 3, 1, 2).double() - gref).abs().max().item() / gref.abs().max().item()
+        assert err <= 3e-6, (split, err)
+    # odd image sizes / even kernels are refused
+    assert lib.dml_pack_input_s2d(img.data_ptr(), x2.data_ptr(), B, 3, H - 1, W, st()) == -2
+    assert lib.dml_s2d_weights(wcl.data_ptr(), w2.data_ptr(), N, 6, 3, st()) == -1
+    assert lib.dml_s2d_wgrad(w2.data_ptr(), wcl.data_ptr(), N, 5, 3, st()) == -1       # (padding 2: even, no such regrouping)
+
+
 @pytest.mark.parametrize("Cc", [72, 256])
 def test_bn_finalize_many_groups(lib, Cc):
     """G >= 2048 row groups takes the folded two-stage finalize (the 192x192 / 384x384 layers); compare with fp64
