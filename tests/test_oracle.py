@@ -160,6 +160,22 @@ def test_g5_full_train_and_g8_trajectory():
     close(m.state_dict()["backbone.conv1.weight"], T(t["w_stem"]), 1e-3)
 
 
+def test_nonsquare_conditioning_record_g13n():
+    """tests/golden/g13n_nonsquare.npz (tests/tools/mint_golden_nonsquare.py) carries the moved BatchNorm betas of the non-square
+    2 x 3 x 128 x 192 live-oracle check and the proof numbers the mint script asserted on the reference."""
+    g = H.load_golden("g13n_nonsquare")
+    assert int(g["seed"]) == 11 and tuple(int(v) for v in g["shape"]) == (2, 3, 128, 192)
+    assert float(g["relu_margin"]) >= 64.0 and float(g["relu_margin_over_noise"]) >= 6.0 and int(g["relu_elems"]) > 16_000_000
+    assert (g["relu_margins"] >= np.maximum(64.0, 6.0 * g["relu_fp32_noise"])).all() and int(g["beta_moved"]) == g["beta_idx"].size
+    m = O.deeplabv3plus_embedding_resnet101(num_classes=16, output_stride=16)
+    sd = H.conditioned_state_dict(H.shapes_of(m), 11, g["beta_idx"], g["beta_val"])
+    plain = H.synth_state_dict(H.shapes_of(m), seed=11)
+    moved = [k for k in sd if not torch.equal(sd[k], plain[k])]
+    assert moved and all(k.endswith(".bias") and k[:-4] + "running_mean" in sd for k in moved)       # only BatchNorm betas
+    assert max(float((sd[k] - plain[k]).abs().max()) for k in moved) <= float(g["beta_max_delta"]) + 1e-12
+    m.load_state_dict(sd)
+
+
 def test_large_conditioned_fixtures_g5l_g8l_g12l():
     """The well-conditioned 128 x 128 fixtures (tests/tools/mint_golden_large.py: every ReLU input of the network at least
     64 x eps32 x sum|terms| -- and 6 x the reference's own fp32-vs-fp64 noise -- away from zero): the oracle reproduces them, and the
