@@ -1729,6 +1729,12 @@ typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
 constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
 constexpr int WS_STAT_ROWS = 48;               // rows per statistics group of this kernel
 constexpr int WS_NST = 6, WS_D = 2;            // ring stages; stages in flight per loader behind the published one
+#ifndef DML_WS_AHEAD
+// activation fragments of the two-plane K loop read this many row groups ahead of their use.  2 (three slots, waits at lgkmcnt 3-6
+// instead of 1-2) measured +-0 on the step, 76.64 vs 76.56 ms over five interleaved pairs: the latency of the fragment reads is covered
+// at one group already; what they cost is issue slots (profiles/r05_h2_kloop_ablations.txt)
+#define DML_WS_AHEAD 1
+#endif
 #ifndef DML_WS_TAP_INNER
 #define DML_WS_TAP_INNER 1                     // K order of the two-plane instantiation: channel groups outermost, taps inside
 #endif
@@ -2006,8 +2012,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         int lr_k = lr, lq_k = lq;
         asm volatile("" : "+v"(lr_k), "+v"(lq_k));
         int a_off[MT], b_off[NT];
+        // (the chunk swizzle of a 64-byte bf16 / fp16 row looks at row bits 2-3 only: fragment j sits j KB behind fragment 0 -- written
+        // that way, the nine offsets are ONE register and immediates)
+        static_assert(BK * 2 * 16 == 1024, "16 rows of 64 bytes per fragment");
+        const int a_off0 = (wm * (16 * MT) + lr_k) * (BK * 2) + swz_chunk<T>(lr_k & 15, lq_k) * 16;
 #pragma unroll
-        for (int j = 0; j < MT; ++j) a_off[j] = (wm * (16 * MT) + j * 16 + lr_k) * (BK * 2) + swz_chunk<T>(j * 16 + lr_k, lq_k) * 16;
+        for (int j = 0; j < MT; ++j) a_off[j] = a_off0 + j * 1024;
 #pragma unroll
         for (int i = 0; i < NT; ++i) b_off[i] = PL * BM * BK * 2 + (wn * 64 + b_row<NT>(i, lr_k)) * (BK * 2) + swz_chunk<T>(lr_k, lq_k) * 16;
         // accumulators by 48-row sub-tile: ACC(i, j) = acc3[j / 3][i][j % 3], so that the epilogue takes a sub-tile by reference
@@ -2067,7 +2077,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             // first eight of step k + 1.  __builtin_amdgcn_sched_barrier pins that order: left to itself hipcc sinks each
             // read to just before its use and waits lgkmcnt(0) there, nine exposed LDS latencies per step (measured: 1.45 us per
             // step against 0.72 of MFMA issue).
-            mfma_f16x8 bhA[NT], bhB[NT], bl[NT], ah[2], al[2];
+            // read-ahead distance of the activation fragments in row groups, and their slots.  Two groups (~24 MFMAs) on the 144-row
+            // wave tiles; the 48-row ones (three groups per step) keep one: two ahead would read the NEXT stage from group 1 on, before
+            // the poll of that stage has been answered
+            constexpr int AH = (DML_WS_AHEAD == 2 && MT >= 9) ? 2 : 1, NS_A = AH + 1;
+            static_assert(AH == 1 || MT % NS_A == 0, "slot of group j = j % 3 in every step");
+            mfma_f16x8 bhA[NT], bhB[NT], bl[NT], ah[NS_A], al[NS_A];
             uint32_t pl[NLD];
 #define WS_FRAG(p) (*reinterpret_cast<const mfma_f16x8*>(p))
             wait_ready(g + 1);                                      // first K step of the tile: exposed once per tile
@@ -2080,6 +2095,10 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                 }
                 ah[0] = WS_FRAG(sb + a_off[0]);
                 al[0] = WS_FRAG(sb + a_off[0] + A_PLANE);
+                if constexpr (AH == 2) {
+                    ah[1] = WS_FRAG(sb + a_off[1]);
+                    al[1] = WS_FRAG(sb + a_off[1] + A_PLANE);
+                }
             }
             auto step = [&](auto pc, mfma_f16x8 (&bc)[NT], mfma_f16x8 (&bn)[NT], const bool has_next, const bool rel) {
                 constexpr int P = decltype(pc)::value;
@@ -2095,32 +2114,35 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
                     // them: a wave issues in order, and a cluster of five or six of them (two fragment reads, waits, hazard nops)
                     // outlasts the 16 cycles of the MFMA before it -- the ablations put 25-30 % of the K loop on the fragment reads
                     // although the LDS itself is busy a fifth of the time (profiles/r05_h2_kloop_ablations.txt).
+                    // fragment slots: this group's and the one of the group read ahead (AH = 1: two slots, alternating from step to
+                    // step with P because MT is odd; AH = 2: three slots, slot = j % 3 in every step)
+                    const int CUR = AH == 2 ? j % NS_A : (j + P) & 1, NXT = AH == 2 ? (j + AH) % NS_A : (j + 1 + P) & 1;
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bc[i], ah[(j + P) & 1]);
+                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bc[i], ah[CUR]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (j + 1 < MT) {
-                        if (!(DML_WS_ABL & 1)) ah[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1]);
+                    if (j + AH < MT) {
+                        if (!(DML_WS_ABL & 1)) ah[NXT] = WS_FRAG(sb + a_off[(j + AH) % MT]);
                     } else {
                         asm volatile("" ::: "memory");
-                        if (!(DML_WS_ABL & 1)) ah[(MT + P) & 1] = WS_FRAG(sn + a_off[0]);
+                        if (!(DML_WS_ABL & 1)) ah[NXT] = WS_FRAG(sn + a_off[(j + AH) % MT]);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bc[i], al[(j + P) & 1]);
+                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bc[i], al[CUR]);
                     __builtin_amdgcn_sched_barrier(0);
-                    if (j + 1 < MT) {
-                        if (!(DML_WS_ABL & 1)) al[(j + 1 + P) & 1] = WS_FRAG(sb + a_off[j + 1] + A_PLANE);
+                    if (j + AH < MT) {
+                        if (!(DML_WS_ABL & 1)) al[NXT] = WS_FRAG(sb + a_off[(j + AH) % MT] + A_PLANE);
                     } else {
+                        asm volatile("" ::: "memory");
                         // every read of stage g has been issued (the tile's LAST stage is announced after the epilogue, which
                         // stages the output rows in its slot)
-                        asm volatile("" ::: "memory");
-                        if (rel || priv) ws_st(consumed + wave, g + 1);
-                        if (!(DML_WS_ABL & 1)) al[(MT + P) & 1] = WS_FRAG(sn + a_off[0] + A_PLANE);
+                        if (j + 1 == MT && (rel || priv)) ws_st(consumed + wave, g + 1);
+                        if (!(DML_WS_ABL & 1)) al[NXT] = WS_FRAG(sn + a_off[(j + AH) % MT] + A_PLANE);
                     }
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bl[i], ah[(j + P) & 1]);
+                    for (int i = 0; i < NT; ++i) WS_MFMA_F16(ACC(i, j), bl[i], ah[CUR]);
                     __builtin_amdgcn_sched_barrier(0);
                     if (j == JP && !(DML_WS_ABL & 2)) {     // the next step's poll, answered under the MFMAs
 #pragma unroll
