@@ -366,12 +366,16 @@ def test_against_oracle_nonsquare_strict(products):
 def test_variants_against_oracle(num_classes, output_stride):
     """The factory's other configurations (network/modeling.py:140-148: output_stride 8 = dilations 2/4 in layer3/4
     and ASPP rates 12/24/36; embedding widths other than 16, incl. the factory default 21 and 13 = StreetHazards, which
-    are carried padded to a multiple of 8 internally), train step vs the fp32 / fp64 oracle."""
+    are carried padded to a multiple of 8 internally), train step vs the fp32 / fp64 oracle -- on CONDITIONED weights
+    (tests/tools/mint_golden_variants.py: one record per output stride, proved on the reference in fp64; the embedding width only
+    changes the last 1x1 convolution, which no ReLU follows).  Until round 5 this ran on unconditioned weights and its bars -- 5e-2
+    on the worst gradient, 5e-3 on the median -- were set around ReLU sign flips of 40-sample BatchNorms."""
     torch.set_num_threads(min(32, torch.get_num_threads() or 8))
-    m = build(seed=21, num_classes=num_classes, output_stride=output_stride)
+    state = conditioned("g14v_os%d" % output_stride, 21)
+    m = build(seed=21, num_classes=num_classes, output_stride=output_stride, state=state)
     img = H.synth_tensor(21, "var.img", (2, 3, 64, 80))
     lab = H.synth_labels(21, "var.lab", (2, 64, 80), num_classes, 255, ignore_frac=0.05)
-    _check_against_oracles(m, img, lab, strict=None, seed=21, num_classes=num_classes, output_stride=output_stride)
+    _check_against_oracles(m, img, lab, strict=True, seed=21, num_classes=num_classes, output_stride=output_stride, state=state)
 
 
 def test_unsupported_embedding_width_raises():
@@ -447,8 +451,9 @@ def _check_against_oracles(m, img, lab, strict, seed=9, num_classes=16, output_s
         assert e_hip.max() <= max(5e-2, 3 * e_ref.max()) and np.median(e_hip) <= max(5e-3, 3 * np.median(e_ref))
         return
     if strict:
-        # absolute bars on the conditioned case -- every parameter gradient, max-norm against fp64 (measured, exact / bf16x3 / f16x2:
-        # median 1.5e-4 / 1.1e-4 / 0.8e-4, worst tensor 2.8e-4 / 1.8e-4 / 1.5e-4; the fp32 oracle itself: 0.6e-4 / 1.0e-4)
+        # absolute bars on the conditioned cases -- every parameter gradient, max-norm against fp64 (measured on the non-square input,
+        # exact / bf16x3 / f16x2: median 1.5e-4 / 1.1e-4 / 0.8e-4, worst tensor 2.8e-4 / 1.8e-4 / 1.5e-4; the six factory variants, exact:
+        # median 0.8-1.1e-4, worst tensor 1.6-4.1e-4 -- 4.8e-4 with the stem regrouped; the fp32 oracle itself: 0.5-0.7e-4 / 1.0-1.4e-4)
         assert np.median(e_hip) <= 0.5 * TOL and np.percentile(e_hip, 95) <= TOL and e_hip.max() <= 2 * TOL
         return
     # individual tensors hit rare sign flips (either implementation can), the distribution must match

@@ -176,6 +176,23 @@ def test_nonsquare_conditioning_record_g13n():
     m.load_state_dict(sd)
 
 
+@pytest.mark.parametrize("os_", [8, 16])
+def test_variant_conditioning_records_g14v(os_):
+    """tests/golden/g14v_os<OS>.npz (tests/tools/mint_golden_variants.py): moved BatchNorm betas of the factory-variant checks and the
+    proof numbers asserted on the reference; they load into every embedding width of that output stride."""
+    g = H.load_golden("g14v_os%d" % os_)
+    assert int(g["seed"]) == 21 and tuple(int(v) for v in g["shape"]) == (2, 3, 64, 80)
+    assert float(g["relu_margin"]) >= 64.0 and float(g["relu_margin_over_noise"]) >= 6.0
+    assert (g["relu_margins"] >= np.maximum(64.0, 6.0 * g["relu_fp32_noise"])).all() and int(g["beta_moved"]) == g["beta_idx"].size
+    for K in (13, 32):
+        m = O.deeplabv3plus_embedding_resnet101(num_classes=K, output_stride=os_)
+        sd = H.conditioned_state_dict(H.shapes_of(m), 21, g["beta_idx"], g["beta_val"])
+        plain = H.synth_state_dict(H.shapes_of(m), seed=21)
+        moved = [k for k in sd if not torch.equal(sd[k], plain[k])]
+        assert moved and all(k.endswith(".bias") and k[:-4] + "running_mean" in sd for k in moved)
+        m.load_state_dict(sd)
+
+
 def test_large_conditioned_fixtures_g5l_g8l_g12l():
     """The well-conditioned 128 x 128 fixtures (tests/tools/mint_golden_large.py: every ReLU input of the network at least
     64 x eps32 x sum|terms| -- and 6 x the reference's own fp32-vs-fp64 noise -- away from zero): the oracle reproduces them, and the
