@@ -1043,14 +1043,15 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     }
     const int V = dtype == DML_BF16 ? 8 : 4;
     hipStream_t st = static_cast<hipStream_t>(stream);
-    // fp32 tensors: ONE-WAVE workgroups.  In the f16x2 backward this kernel runs on the main stream while a weight-gradient kernel
+    // ONE-WAVE workgroups.  In the f16x2 backward this kernel runs on the main stream while a weight-gradient kernel
     // of the side stream holds every CU with one persistent 7-wave workgroup of 256 registers per lane -- 3 SIMDs full, 256 registers
     // free on the fourth.  A 4-wave block of ~128 registers per lane does not fit beside it and waited for a weight-gradient
     // workgroup to retire (in the overlapped trace this kernel lasted 175 us per launch against 66 alone); one-wave blocks start at
-    // once, two per CU: 80.35 -> 79.15 ms per step, alone unchanged (profiles/r05_ab_bn_bwd_one_wave_blocks.txt).
+    // once, two per CU: 80.35 -> 79.15 ms per step, alone unchanged (profiles/r05_ab_bn_bwd_one_wave_blocks.txt).  The bf16 step, whose
+    // convolution workgroups are not persistent, gains 0.5 % from the same geometry (40.06 -> 39.87 ms).
     // DML_BN_BWD_THREADS=256: the old geometry (A/B)
     static const int bt_env = getenv("DML_BN_BWD_THREADS") ? atoi(getenv("DML_BN_BWD_THREADS")) : 64;
-    const int bt = (dtype == DML_F32 && (bt_env == 64 || bt_env == 128 || bt_env == 256)) ? bt_env : 256;
+    const int bt = (bt_env == 64 || bt_env == 128 || bt_env == 256) ? bt_env : 256;
     if (dtype == DML_F32 && planes && !dy && !amax && (mask || !relu) && (N & 7) == 0 && (lddz & 3) == 0 && (ldy & 3) == 0 &&
         (ldp & 7) == 0 && (plane_stride & 7) == 0 && (!dres || (lddres & 3) == 0) &&
         ((reinterpret_cast<uintptr_t>(planes) | reinterpret_cast<uintptr_t>(dz) | reinterpret_cast<uintptr_t>(y) |
@@ -1066,7 +1067,7 @@ extern "C" int dml_bn_bwd_apply(const void* dz, const void* y, const void* z, co
     const ColGeom g = col_geom(M, N / V, 2, stream_blocks(M, N, dtype), bt);
     dim3 grid(g.row_blocks, g.col_chunks);
     if (dtype == DML_BF16)
-        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 2>), grid, dim3(256), 0, st, (const bf16_t*)dz,
+        hipLaunchKernelGGL((bn_bwd_apply_cols_kernel<bf16_t, 2>), grid, dim3(bt), 0, st, (const bf16_t*)dz,
                            (const bf16_t*)y, (const bf16_t*)z, mask, coef, (bf16_t*)dy, (bf16_t*)dres, M, N, lddz, ldy,
                            ldz, lddy, lddres, relu, gscale, dres_accum, g.CB, g.RB, g.rows_per_block,
                            reinterpret_cast<uint32_t*>(amax), (_Float16*)nullptr, (int64_t)0, 0, (const float*)nullptr);
