@@ -1473,7 +1473,11 @@ H2_CASES = [("h2_1x1", 2, 24, 20, 64, 128, 1, 1, 1), ("h2_3x3", 2, 19, 23, 64, 2
             # K order of the two-plane kernel (64-channel groups outermost, taps inside): a last group of 32 channels (C = 96), five
             # groups (C = 320); three column blocks, the last one half empty, walked fastest (N = 320: forward of the first case and
             # data gradient of the second, the shape of the decoder's 3x3)
-            ("h2_3x3_c96_n320", 2, 17, 21, 96, 320, 3, 1, 1), ("h2_3x3_c320_n192", 2, 15, 14, 320, 192, 3, 1, 1)]
+            ("h2_3x3_c96_n320", 2, 17, 21, 96, 320, 3, 1, 1), ("h2_3x3_c320_n192", 2, 15, 14, 320, 192, 3, 1, 1),
+            # dilated 3x3 on a 48 x 48 map (the ASPP branches): whole filter rows are padding for the tiles at the top and the bottom of an
+            # image and their K steps are skipped (ws_live_taps) -- 144-row tiles forward and data gradient, 192-row tiles (64 channels)
+            ("h2_3x3_d12_48", 2, 48, 48, 256, 256, 3, 1, 12), ("h2_3x3_d18_48", 1, 48, 48, 64, 256, 3, 1, 18),
+            ("h2_3x3_d6_40x48", 2, 40, 48, 128, 128, 3, 1, 6)]
 
 
 @pytest.mark.parametrize("case", H2_CASES, ids=lambda c: c[0])
