@@ -32,7 +32,7 @@ def get_argparser():
     p.add_argument("--weight_decay", type=float, default=1e-4)
     p.add_argument("--batch_size", type=int, default=16, help="GLOBAL batch size, sharded over the ranks")
     p.add_argument("--crop_size", type=int, default=768)
-    p.add_argument("--loss_type", default="cross_entropy", choices=["cross_entropy", "dml"])
+    p.add_argument("--loss_type", default="cross_entropy", choices=["cross_entropy", "dml", "focal_loss"])
     p.add_argument("--alpha", type=float, default=0.01, help="weight of the variance loss for --loss_type dml")
     p.add_argument("--ckpt", default=None)
     p.add_argument("--continue_training", action="store_true")
@@ -91,6 +91,11 @@ def main():
     else:
         scheduler = torch.optim.lr_scheduler.StepLR(optimizer, step_size=opts.step_size, gamma=0.1)
     sync = True if world > 1 else None
+    if opts.loss_type == "focal_loss":
+        # accepted by the reference's parser (main_embedding.py:72,398-399) but dead there: its train loop calls
+        # criterion(outputs, labels, features) (:467) and utils/loss.py:7-23 FocalLoss.forward takes two arguments -> TypeError
+        raise SystemExit("--loss_type focal_loss: the reference's FocalLoss (utils/loss.py:7-23) cannot run under its own "
+                         "embedding train loop (main_embedding.py:467 passes three arguments); use cross_entropy or dml")
     if opts.loss_type == "dml":
         criterion = utils.DMLLoss(alpha=opts.alpha, ignore_index=255, sync=sync, fused_backward=True)
     else:

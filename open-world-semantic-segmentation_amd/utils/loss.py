@@ -93,7 +93,8 @@ class CrossEntropyLoss(nn.Module):
         self.ignore_index, self.size_average, self.sync = ignore_index, size_average, sync
         self.fused_backward = fused_backward
         if not size_average:
-            raise NotImplementedError("size_average=False is never used by the embedding drivers")
+            raise NotImplementedError("CrossEntropyLoss(size_average=False) (the reference's utils/loss.py:26,35 sum reduction) is "
+                                      "never used by the embedding drivers and has no HIP kernel here")
 
     def forward(self, logit, target, features_in=None):
         return _DMLLossFn.apply(logit, target, 0.0, self.ignore_index, self.sync, self.fused_backward)

@@ -36,21 +36,25 @@ def _calibrated_pair(seed, size):
     return m, o
 
 
-def test_config5_full_size_inference_and_scores_against_oracle():
-    """1 x 3 x 1024 x 2048, fp32 mode, against the fp32 oracle on the same input: logits / features at 1e-3, argmax,
-    max-softmax score, dissum map (both clip rules) and the relabel mask of test_embedding.py:428-445."""
+@pytest.mark.parametrize("products", ["exact", "f16x2"])
+def test_config5_full_size_inference_and_scores_against_oracle(products):
+    """1 x 3 x 1024 x 2048, both fp32 modes (the reference's literal fp32 products, and the bench headline's two-plane fp16
+    products), forked eval plan (the default at this size), against the fp32 oracle on the same input: logits / features at
+    1e-3, argmax, max-softmax score, dissum map (both clip rules) and the relabel mask of test_embedding.py:428-445."""
     import utils
     from oracle import dmlnet_ref as O
     torch.set_num_threads(min(64, torch.get_num_threads() or 8))
     m, o = _calibrated_pair(51, (1024, 2048))
-    m.set_compute_dtype(torch.float32)
+    m.set_compute_dtype(torch.float32, fp32_products=products)
     img = H.synth_tensor(51, "cfg5.img", (1, 3, 1024, 2048))
     with torch.no_grad():
         lg, ctr, ft = m(img.cuda())
         olg, _, oft = o(img)
     assert lg.shape == (1, 16, 1024, 2048) and ft.shape == (1, 1024, 2048, 16)
     e_lg, e_ft = H.rel_err(lg, olg), H.rel_err(ft, oft)
-    print("config5 fp32: logits rel %.2e, features rel %.2e" % (e_lg, e_ft))
+    print("config5 fp32 (%s products): logits rel %.2e, features rel %.2e" % (products, e_lg, e_ft))
+    plan = next(iter(m._engine.plans.values()))
+    assert getattr(plan, "fwd_forks", None), "the 1024x2048 batch-1 eval plan is expected to fork the ASPP branches"
     assert e_lg <= 1e-3 and e_ft <= 1e-3
     preds, msp = utils.argmax_msp(lg)
     opred = olg.argmax(1)
@@ -73,6 +77,8 @@ def test_config5_full_size_inference_and_scores_against_oracle():
     # the distance head's closed form at full size (F5) and bf16 mode tracking it
     closed = (-(ft * ft).sum(-1, keepdim=True) + 6 * ft - 9).permute(0, 3, 1, 2)
     assert (lg - closed).abs().max().item() <= 1e-4 * lg.abs().max().item()
+    if products != "exact":
+        return
     m.set_compute_dtype(torch.bfloat16)
     with torch.no_grad():
         lgb, _, _ = m(img.cuda())
