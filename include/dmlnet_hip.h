@@ -345,6 +345,18 @@ int dml_h2_bound_bn(const float* gamma, const float* beta, int N, int64_t count,
                     float* work, void* stream);
 int dml_h2_bound_bn_bwd(const float* coef, const float* save_invstd, int N, int64_t count, const float* g_amax,
                         float* work, void* stream);
+/* The two pairs above as ONE launch each (round 6: 145 dependent one-block launches per train step removed).  Every block of the
+ * finalize kernel raises state[0] to the largest bound term of its own channels and takes a ticket in state[1]; the block that
+ * arrives last writes work[1024] and leaves both words zero for the next call.  `state`: two zero-initialised 32-bit words owned by
+ * this BatchNorm (not shared between launches that may run concurrently).  Results equal the two-call sequence's.  Replaces
+ * nn.BatchNorm2d's statistics step in backbone/resnet.py:97-108 of the reference like the calls it fuses. */
+int dml_bn_finalize_bound(float* partials, int64_t M, int N, int stat_rows, const float* gamma, const float* beta,
+                          float* running_mean, float* running_var, float momentum, float eps,
+                          float* scale, float* shift, float* save_mean, float* save_invstd,
+                          int64_t count, float mult, const float* res_amax, float* work, uint32_t* state, void* stream);
+int dml_bn_bwd_finalize_bound(float* partials, int nblocks, int64_t M, int N, const float* gamma,
+                              const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                              float* coef, int64_t count, const float* g_amax, float* work, uint32_t* state, void* stream);
 /* dml_h2_bound_bn for `count` residual-free BatchNorms in one launch (`table_device`: DEVICE array; root_count = sqrt(elements per
  * channel) * 1.0001, as the single call computes it). */
 typedef struct DmlH2BoundDesc {

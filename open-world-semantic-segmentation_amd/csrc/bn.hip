@@ -32,11 +32,68 @@ __device__ __forceinline__ double shfl_xor_f64(double v, int mask) {
     const int lo = __shfl_xor((int)(b & 0xffffffffll), mask), hi = __shfl_xor((int)(b >> 32), mask);
     return __longlong_as_double(((long long)hi << 32) | (unsigned int)lo);
 }
+
+// ---- plane-scale bound folded into the finalize launches (round 6) ------------------------------------------------------------
+// dml_h2_bound_bn / dml_h2_bound_bn_bwd were one-block launches right behind every finalize: a dependent hop of ~7 us, 145 times
+// per step.  The finalize blocks now each raise state[0] to the largest bound term of their own channels and take a ticket
+// (state[1]); the block that arrives LAST turns the maximum into the scale word work[1024] and resets both words for the next
+// step.  max() is order-independent, so the result is the same whatever the arrival order (and equal to the stand-alone kernel's).
+__device__ __forceinline__ float h2_words_max(const float* __restrict__ words, float* sh4) {
+    uint32_t wm = 0;
+    if (words != nullptr)
+        for (int i = threadIdx.x; i < 1024; i += 256) wm = max(wm, __float_as_uint(words[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) wm = max(wm, (uint32_t)__shfl_xor((int)wm, o, 64));
+    __syncthreads();                                   // (sh4 may still be read by an earlier use)
+    if ((threadIdx.x & 63) == 0) sh4[threadIdx.x >> 6] = __uint_as_float(wm);
+    __syncthreads();
+    return __uint_as_float(max(max(__float_as_uint(sh4[0]), __float_as_uint(sh4[1])), max(__float_as_uint(sh4[2]), __float_as_uint(sh4[3]))));
+}
+__device__ __forceinline__ float h2_scale_of_bound(float b) {
+    b *= 1.0009765625f;                                        // rounding of the statistics and of this sum
+    const uint32_t m = __float_as_uint(b);
+    float s = 1.0f;
+    if (m != 0) {
+        int se = 14 - ((int)(m >> 23) - 127);                  // scale = 2^(14 - floor(log2 b)): b * scale in [2^14, 2^15), as dml_h2_split
+        se = se > 127 ? 127 : (se < -126 ? -126 : se);
+        s = __uint_as_float((uint32_t)(se + 127) << 23);
+        if (m >= 0x7f800000u) s = 1.0f;                        // the bound overflowed: the tensor is not finite either
+    }
+    return s;
+}
+// v: this thread's bound term (0 where it has none).  Forward: bound = max v * mult + max |res| (res_words, may be null);
+// backward: bound = max v.  Every thread of every block of the (1-D) grid must call it.
+__device__ __forceinline__ void h2_bound_tail(float v, uint32_t* __restrict__ state, float* __restrict__ work,
+                                              const float* __restrict__ res_words, const float mult, const bool bwd) {
+    __shared__ float shb[4];
+    __shared__ int sh_last;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));      // (NaN terms: fmaxf drops them; the tensor carries them anyway)
+    if ((threadIdx.x & 63) == 0) shb[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const float b = fmaxf(fmaxf(shb[0], shb[1]), fmaxf(shb[2], shb[3]));
+        const uint32_t old = __hip_atomic_fetch_max(state, __float_as_uint(b), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("" ::"v"(old));                           // the maximum has been applied before the ticket is taken
+        const uint32_t t = __hip_atomic_fetch_add(state + 1, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        sh_last = (t == gridDim.x - 1) ? 1 : 0;
+    }
+    __syncthreads();
+    if (!sh_last) return;
+    const float wmax = bwd ? 0.f : h2_words_max(res_words, shb);
+    if (threadIdx.x != 0) return;
+    float b = __uint_as_float(__hip_atomic_exchange(state, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+    __hip_atomic_store(state + 1, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);      // both words ready for the next step
+    b = bwd ? b : b * mult + wmax;
+    work[1024] = 1.0f / h2_scale_of_bound(b);
+}
 template <int FIN_CH, int FIN_SL>      // channels x group-slices per 256-thread block
 __global__ __launch_bounds__(256) void bn_finalize_kernel(
     const float* __restrict__ partials, int64_t M, int N, const int SR, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
-    float* scale, float* shift, float* save_mean, float* save_invstd, double* moments_out) {
+    float* scale, float* shift, float* save_mean, float* save_invstd, double* moments_out,
+    uint32_t* bound_state = nullptr, float* bound_work = nullptr, const float* bound_res = nullptr, float bound_root = 0.f,
+    float bound_mult = 1.f) {
     static_assert(FIN_CH == 4 && FIN_SL == 64, "lane = 4 channels x 16 slices per wave");
     __shared__ double sh[3][4][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
@@ -66,31 +123,35 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(
         sh[2][wave][ch] = P;
     }
     __syncthreads();
-    if (threadIdx.x >= FIN_CH || n >= N) return;
-    S = sh[0][0][ch] + sh[0][1][ch] + sh[0][2][ch] + sh[0][3][ch];
-    Q = sh[1][0][ch] + sh[1][1][ch] + sh[1][2][ch] + sh[1][3][ch];
-    P = sh[2][0][ch] + sh[2][1][ch] + sh[2][2][ch] + sh[2][3][ch];
-    const double cnt = (double)M, mean = S / cnt;
-    double m2 = Q + (P - S * mean);
-    if (m2 < 0.0) m2 = 0.0;
-    if (moments_out != nullptr) {       // synchronised BN: this rank's (mean, M2), merged later
-        moments_out[2 * n] = mean;
-        moments_out[2 * n + 1] = m2;
-        return;
+    float bterm = 0.f;                  // this channel's term of the plane-scale bound (h2_bound_tail)
+    if (threadIdx.x < FIN_CH && n < N) {
+        S = sh[0][0][ch] + sh[0][1][ch] + sh[0][2][ch] + sh[0][3][ch];
+        Q = sh[1][0][ch] + sh[1][1][ch] + sh[1][2][ch] + sh[1][3][ch];
+        P = sh[2][0][ch] + sh[2][1][ch] + sh[2][2][ch] + sh[2][3][ch];
+        const double cnt = (double)M, mean = S / cnt;
+        double m2 = Q + (P - S * mean);
+        if (m2 < 0.0) m2 = 0.0;
+        if (moments_out != nullptr) {       // synchronised BN: this rank's (mean, M2), merged later
+            moments_out[2 * n] = mean;
+            moments_out[2 * n + 1] = m2;
+        } else {
+            const double var_b = m2 / cnt;
+            const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+            const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
+            const float sc = g * invstd;
+            scale[n] = sc;
+            shift[n] = b;
+            save_mean[n] = (float)mean;
+            if (save_invstd) save_invstd[n] = invstd;
+            if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+            if (running_var) {
+                const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
+                running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
+            }
+            bterm = fabsf(g) * bound_root + fabsf(b);
+        }
     }
-    const double var_b = m2 / cnt;
-    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
-    const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
-    const float sc = g * invstd;
-    scale[n] = sc;
-    shift[n] = b;
-    save_mean[n] = (float)mean;
-    if (save_invstd) save_invstd[n] = invstd;
-    if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
-    if (running_var) {
-        const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
-        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
-    }
+    if (bound_state != nullptr) h2_bound_tail(bterm, bound_state, bound_work, bound_res, bound_mult, false);
 }
 
 template <typename T>
@@ -495,7 +556,8 @@ __global__ __launch_bounds__(256) void bn_bwd_fold_kernel(float* partials, int G
 __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
     const float* __restrict__ partials, int nblocks, int64_t M, int N, const float* __restrict__ gamma,
     const float* __restrict__ save_mean, const float* __restrict__ save_invstd, float* dgamma, float* dbeta,
-    float* coef, double* sums_out, int row_stride) {
+    float* coef, double* sums_out, int row_stride,
+    uint32_t* bound_state = nullptr, float* bound_work = nullptr, const float* bound_gmax = nullptr, float bound_root = 0.f) {
     __shared__ double sh[2][4][FIN_CH];
     const int ch = threadIdx.x % FIN_CH, sl = threadIdx.x / FIN_CH;
     const int n = blockIdx.x * FIN_CH + ch;
@@ -530,6 +592,12 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
         if (dbeta) dbeta[n] += (float)sh[0][0][ch];
         return;
     }
+    float bterm = 0.f;                  // |A| max|g| + |Bc| sqrt(count) / invstd + |C0|: this channel's bound on |dy| (h2_bound_tail)
+    float gmax = 0.f;
+    if (bound_state != nullptr) {       // (uniform; the sums are in LDS, the float staging below may be reused)
+        __shared__ float shg[4];
+        gmax = h2_words_max(bound_gmax, shg);
+    }
     if (sl == 0 && n < N) {
         const double dbeta_s = sh[0][0][ch], dgamma_s = sh[1][0][ch];
         const double g = gamma ? (double)gamma[n] : 1.0, is = save_invstd[n], mu = save_mean[n];
@@ -541,7 +609,9 @@ __global__ __launch_bounds__(256) void bn_bwd_finalize_kernel(
         coef[n] = (float)A; coef[N + n] = (float)Bc; coef[2 * N + n] = (float)C0; coef[3 * N + n] = (float)mu;
         if (dgamma) dgamma[n] += (float)dgamma_s;
         if (dbeta) dbeta[n] += (float)dbeta_s;
+        bterm = fabsf((float)A) * gmax + fabsf((float)Bc) * bound_root / save_invstd[n] + fabsf((float)C0);
     }
+    if (bound_state != nullptr) h2_bound_tail(bterm, bound_state, bound_work, nullptr, 1.f, true);
 }
 
 // column-stationary backward apply (see bn_apply_cols_kernel): coefficients in registers, U rows in flight
@@ -732,7 +802,9 @@ __global__ __launch_bounds__(256) void bn_fold_partials_kernel(float* partials, 
 __global__ __launch_bounds__(256) void bn_finalize_folded_kernel(
     const float* __restrict__ partials, int64_t M, int N, int R, int NC, const float* __restrict__ gamma,
     const float* __restrict__ beta, float* running_mean, float* running_var, float momentum, float eps,
-    float* scale, float* shift, float* save_mean, float* save_invstd) {
+    float* scale, float* shift, float* save_mean, float* save_invstd,
+    uint32_t* bound_state = nullptr, float* bound_work = nullptr, const float* bound_res = nullptr, float bound_root = 0.f,
+    float bound_mult = 1.f) {
     // 8 channels x 32 chunk lanes per block (it was 32 x 8: two blocks for the 64-channel layers, every thread walking 16
     // chunks one after the other -- 14 us): the NC (<= 128) chunk sums are read 32 at a time, N / 8 blocks
     constexpr int FC = 8, FL = 32;
@@ -753,29 +825,33 @@ __global__ __launch_bounds__(256) void bn_finalize_folded_kernel(
     sh[1][cl][c] = Q;
     sh[2][cl][c] = P;
     __syncthreads();
-    if (cl != 0 || n >= N) return;
-    S = Q = P = 0.0;
+    float bterm = 0.f;
+    if (cl == 0 && n < N) {
+        S = Q = P = 0.0;
 #pragma unroll
-    for (int k = 0; k < FL; ++k) {
-        S += sh[0][k][c];
-        Q += sh[1][k][c];
-        P += sh[2][k][c];
+        for (int k = 0; k < FL; ++k) {
+            S += sh[0][k][c];
+            Q += sh[1][k][c];
+            P += sh[2][k][c];
+        }
+        const double cnt = (double)M, mean = S / cnt;
+        double m2 = Q + (P - S * mean);
+        if (m2 < 0.0) m2 = 0.0;
+        const double var_b = m2 / cnt;
+        const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
+        const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
+        scale[n] = g * invstd;
+        shift[n] = b;
+        save_mean[n] = (float)mean;
+        if (save_invstd) save_invstd[n] = invstd;
+        if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
+        if (running_var) {
+            const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
+            running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
+        }
+        bterm = fabsf(g) * bound_root + fabsf(b);
     }
-    const double cnt = (double)M, mean = S / cnt;
-    double m2 = Q + (P - S * mean);
-    if (m2 < 0.0) m2 = 0.0;
-    const double var_b = m2 / cnt;
-    const float invstd = (float)(1.0 / sqrt(var_b + (double)eps));
-    const float g = gamma ? gamma[n] : 1.f, b = beta ? beta[n] : 0.f;
-    scale[n] = g * invstd;
-    shift[n] = b;
-    save_mean[n] = (float)mean;
-    if (save_invstd) save_invstd[n] = invstd;
-    if (running_mean) running_mean[n] = (1.f - momentum) * running_mean[n] + momentum * (float)mean;
-    if (running_var) {
-        const double var_u = cnt > 1.0 ? m2 / (cnt - 1.0) : var_b;
-        running_var[n] = (1.f - momentum) * running_var[n] + momentum * (float)var_u;
-    }
+    if (bound_state != nullptr) h2_bound_tail(bterm, bound_state, bound_work, bound_res, bound_mult, false);
 }
 
 
@@ -783,9 +859,33 @@ inline bool vec_ok(int dtype, int a) { return a % (dtype == DML_BF16 ? 8 : 4) ==
 
 }  // namespace
 
+static int bn_finalize_impl(float* partials, int64_t M, int N, int stat_rows, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            float* scale, float* shift, float* save_mean, float* save_invstd, void* stream,
+                            uint32_t* bstate, float* bwork, const float* bres, float broot, float bmult);
+
 extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, int stat_rows, const float* gamma, const float* beta,
                                float* running_mean, float* running_var, float momentum, float eps,
                                float* scale, float* shift, float* save_mean, float* save_invstd, void* stream) {
+    return bn_finalize_impl(partials, M, N, stat_rows, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
+                            save_invstd, stream, nullptr, nullptr, nullptr, 0.f, 1.f);
+}
+
+// dml_bn_finalize + dml_h2_bound_bn(gamma, beta, N, count, mult, res_amax, work) in ONE launch: the finalize block that arrives
+// last writes the plane scale (h2_bound_tail).  `state`: two zero-initialised words owned by this BatchNorm, left zero again.
+extern "C" int dml_bn_finalize_bound(float* partials, int64_t M, int N, int stat_rows, const float* gamma, const float* beta,
+                                     float* running_mean, float* running_var, float momentum, float eps,
+                                     float* scale, float* shift, float* save_mean, float* save_invstd,
+                                     int64_t count, float mult, const float* res_amax, float* work, uint32_t* state, void* stream) {
+    if (!work || !state || count <= 0 || !(mult > 0.f)) return DML_EINVAL;
+    return bn_finalize_impl(partials, M, N, stat_rows, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
+                            save_invstd, stream, state, work, res_amax, sqrtf((float)count) * 1.0001f, mult);
+}
+
+static int bn_finalize_impl(float* partials, int64_t M, int N, int stat_rows, const float* gamma, const float* beta,
+                            float* running_mean, float* running_var, float momentum, float eps,
+                            float* scale, float* shift, float* save_mean, float* save_invstd, void* stream,
+                            uint32_t* bstate, float* bwork, const float* bres, float broot, float bmult) {
     if (!partials || !scale || !shift || !save_mean || M <= 0 || N <= 0 || stat_rows <= 0) return DML_EINVAL;
     const int64_t G = (M + stat_rows - 1) / stat_rows;
     hipStream_t st = static_cast<hipStream_t>(stream);
@@ -798,11 +898,12 @@ extern "C" int dml_bn_finalize(float* partials, int64_t M, int N, int stat_rows,
         hipLaunchKernelGGL(bn_fold_partials_kernel, dim3((N + 63) / 64, NC), dim3(256), 0, st, partials, G, N, R, NC,
                            last_rows, stat_rows);
         hipLaunchKernelGGL(bn_finalize_folded_kernel, dim3((N + 7) / 8), dim3(256), 0, st, partials, M, N, R, NC,
-                           gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd);
+                           gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd,
+                           bstate, bwork, bres, broot, bmult);
     } else {
         hipLaunchKernelGGL((bn_finalize_kernel<4, 64>), dim3((N + 3) / 4), dim3(256), 0, st, partials, M, N, stat_rows,
                            gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean, save_invstd,
-                           (double*)nullptr);
+                           (double*)nullptr, bstate, bwork, bres, broot, bmult);
     }
     DML_LAUNCH_CHECK();
     return 0;
@@ -940,6 +1041,22 @@ extern "C" int dml_bn_bwd_finalize(float* partials, int nblocks, int64_t M, int 
     const int stride = fold_bwd_partials(partials, nblocks, N, st);
     hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partials, nblocks, M, N,
                        gamma, save_mean, save_invstd, dgamma, dbeta, coef, (double*)nullptr, stride);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
+// dml_bn_bwd_finalize + dml_h2_bound_bn_bwd(coef, save_invstd, N, count, g_amax, work) in ONE launch (h2_bound_tail)
+extern "C" int dml_bn_bwd_finalize_bound(float* partials, int nblocks, int64_t M, int N, const float* gamma,
+                                         const float* save_mean, const float* save_invstd, float* dgamma, float* dbeta,
+                                         float* coef, int64_t count, const float* g_amax, float* work, uint32_t* state,
+                                         void* stream) {
+    if (!partials || !save_mean || !save_invstd || !coef || nblocks <= 0 || N <= 0 || M < 0) return DML_EINVAL;
+    if (!g_amax || !work || !state || count <= 0) return DML_EINVAL;
+    hipStream_t st = static_cast<hipStream_t>(stream);
+    const int stride = fold_bwd_partials(partials, nblocks, N, st);
+    hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((N + FIN_CH - 1) / FIN_CH), dim3(256), 0, st, partials, nblocks, M, N,
+                       gamma, save_mean, save_invstd, dgamma, dbeta, coef, (double*)nullptr, stride, state, work, g_amax,
+                       sqrtf((float)count) * 1.0001f);
     DML_LAUNCH_CHECK();
     return 0;
 }

@@ -130,6 +130,9 @@ _PROTOS = {
     "dml_h2_bound_bn": (c_i, [c_p, c_p, c_i, c_i64, c_f, c_p, c_p, c_p]),
     "dml_h2_bound_bn_table": (c_i, [c_p, c_i, c_p]),
     "dml_h2_bound_bn_bwd": (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p]),
+    "dml_bn_finalize_bound": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p,
+                                    c_i64, c_f, c_p, c_p, c_p, c_p]),
+    "dml_bn_bwd_finalize_bound": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_p, c_p, c_i64, c_p, c_p, c_p, c_p]),
     "dml_maxpool3x3s2_fwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_maxpool3x3s2_bwd": (c_i, [c_p, c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_global_avgpool_fwd": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_p]),

@@ -369,6 +369,10 @@ class Plan:
         # residual add takes (hi + lo) / s, the value those convolutions see (dml_bn_apply, res_unscale).  DML_RES_PLANES=0: off
         self.res_planes_on = os.environ.get("DML_RES_PLANES", "1") != "0"
         self.fuse_bn_reduce = os.environ.get("DML_FUSE_BN_REDUCE", "1") != "0"
+        # f16x2: the plane-scale bound of a BatchNorm output / of dy computed by the finalize launch's last block instead of a
+        # one-block launch of its own behind it (dml_bn_finalize_bound / dml_bn_bwd_finalize_bound).  DML_FUSE_BOUND=0: off (A/B)
+        self.fuse_bound = os.environ.get("DML_FUSE_BOUND", "1") != "0"
+        self._bound_words, self._bound_used = None, 0
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
         # producer, as autograd does in the reference (resnet.py:112-113, network/utils.py:360).  Off by default: measured
         # over 10 + 4 seeds (tests/tools/bf16_noise_seeds.py, profiles/r03_bf16_noise_seeds.txt) the per-tensor gradient
@@ -487,6 +491,16 @@ class Plan:
         """both fp16 planes of an [M][ld] tensor within the 31-bit byte offsets of the planes kernels (launch_conv / dml_conv_wgrad
         fall back to the fp32 tensors beyond): a tensor may exist as planes ONLY when this holds"""
         return 4 * M * ld < (1 << 31) - 4096
+
+    def bound_state(self):
+        """two zeroed 32-bit words (running maximum, ticket) of one dml_bn_*finalize_bound launch: left zero by every call"""
+        if self._bound_words is None:
+            self._bound_words = torch.zeros(2 * 1024, dtype=torch.int32, device=self.device)
+            self.keep.append(self._bound_words)
+        assert self._bound_used < 1024, "out of bound-state words"
+        p = self._bound_words.data_ptr() + 8 * self._bound_used
+        self._bound_used += 1
+        return p
 
     def h2_work(self):
         assert self.h2_used < 1024, "out of dml_h2_split work buffers"
@@ -772,6 +786,7 @@ class Plan:
         elif self.training:
             u.mean, u.invstd = self.fbuf(N), self.fbuf(N)
             mean_ptr = u.mean.data_ptr()
+            bound_done = False
             dsc = self.conv_fwd(x, conv, u.y, u.w, self.sp)
             # rows per statistics partial of THIS launch (48 on the wave-specialised kernel, STAT_ROWS otherwise)
             rows = lib.dml_conv_stat_rows(C.byref(dsc))
@@ -787,6 +802,16 @@ class Plan:
                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
                                  u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr())
                 self.momentum_slots.append((args, 8, bn))
+            elif direct and self.fuse_bound and not (res is None and self.h2_bound_args is not None):
+                # f16x2: the plane scale of z from its bound (dml_h2_bound_bn) comes out of the SAME launch -- the finalize block
+                # that arrives last writes it (dml_bn_finalize_bound: one dependent one-block launch less per residual unit)
+                args = self.call(self.fwd, lib.dml_bn_finalize_bound, self.sp, M, N, rows, g_ptr, b_ptr,
+                                 bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
+                                 u.scale.data_ptr(), u.shift.data_ptr(), u.mean.data_ptr(), u.invstd.data_ptr(),
+                                 M * self.world, 1.0, res.amax.data_ptr() if res is not None else None,
+                                 u.z.h2[1].data_ptr(), self.bound_state())
+                self.momentum_slots.append((args, 8, bn))
+                bound_done = True
             else:
                 args = self.call(self.fwd, lib.dml_bn_finalize, self.sp, M, N, rows, g_ptr, b_ptr,
                                  bn.running_mean.data_ptr(), bn.running_var.data_ptr(), 0.1, float(bn.eps),
@@ -812,7 +837,9 @@ class Plan:
         pl = (None, 0, 0, None)
         if direct:
             planes, work = u.z.h2
-            if res is None and self.h2_bound_args is not None:
+            if bound_done:
+                pass
+            elif res is None and self.h2_bound_args is not None:
                 self.h2_bound_tab.append(_lib.H2BoundDesc(g_ptr, b_ptr, work.data_ptr(), N,
                                                           float(np.float32(np.sqrt(np.float32(M * self.world))) * np.float32(1.0001)), 1.0, 0))
             else:
@@ -882,6 +909,7 @@ class Plan:
                           and G <= 16384
                           and prod.N == N and prod.ldy == N and dz.ld == N and prod.y == dz.ptr and u.y.ld % 4 == 0)
         a1 = None
+        bound_done = False
         if fused:
             part = self.fbuf(G * N * 2)
             prod.bnr_y, prod.bnr_mask = u.y.ptr, mk
@@ -905,6 +933,13 @@ class Plan:
             self.py_op(self.bwd, lambda t=sums, g=grp: dist.all_reduce(t, group=g))
             self.call(self.bwd, lib.dml_bn_bwd_coef, sums.data_ptr(), M * self.world, N, bn.weight.data_ptr(),
                       u.mean.data_ptr(), u.invstd.data_ptr(), coef.data_ptr())
+        elif dy_direct and self.fuse_bound:
+            # (f16x2: dy's plane scale -- dml_h2_bound_bn_bwd -- from the finalize launch itself, its last block)
+            self.call(self.bwd, lib.dml_bn_bwd_finalize_bound, sp, nblk, 0 if u.frozen else M, N, bn.weight.data_ptr(),
+                      u.mean.data_ptr(), u.invstd.data_ptr(), st.grad_ptr_of(bn.weight),
+                      st.grad_ptr_of(bn.bias), coef.data_ptr(), M * self.world, gwork.data_ptr(), dy.h2[1].data_ptr(),
+                      self.bound_state())
+            bound_done = True
         else:
             self.call(self.bwd, lib.dml_bn_bwd_finalize, sp, nblk, 0 if u.frozen else M, N, bn.weight.data_ptr(),
                       u.mean.data_ptr(), u.invstd.data_ptr(), st.grad_ptr_of(bn.weight),
@@ -914,8 +949,9 @@ class Plan:
         pl = (None, 0, 0, None)
         if dy_direct:
             planes, work = dy.h2
-            self.call(self.bwd, lib.dml_h2_bound_bn_bwd, coef.data_ptr(), u.invstd.data_ptr(), N, M * self.world,
-                      gwork.data_ptr(), work.data_ptr())
+            if not bound_done:
+                self.call(self.bwd, lib.dml_h2_bound_bn_bwd, coef.data_ptr(), u.invstd.data_ptr(), N, M * self.world,
+                          gwork.data_ptr(), work.data_ptr())
             pl = (planes.data_ptr(), M * N, N, work.data_ptr() + 4096)
         a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, mk, coef.data_ptr(),
                        None if only else dy.ptr, dres.ptr if dres is not None else None, M, N, dz.ld, u.y.ld, u.z.ld, dy.ld,
