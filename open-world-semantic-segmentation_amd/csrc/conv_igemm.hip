@@ -1713,7 +1713,8 @@ __device__ __forceinline__ void conv_epilogue_rows8(f32x4 (&acc)[NT][3], const C
 }
 
 // timing ablations of the two-plane K loop (tools/build_ablations.sh; never defined in the product build): 1 = no fragment reads in
-// the loop, 2 = no flag polls / waits, 4 = the loaders issue no DMA.  Results are garbage, durations are what is measured.
+// the loop, 2 = no flag polls / waits, 4 = the loaders issue no DMA, 8 = no epilogue (nothing is stored), 16 = no MFMAs.  Results are
+// garbage, durations are what is measured.
 #ifndef DML_WS_ABL
 #define DML_WS_ABL 0
 #endif
@@ -1723,7 +1724,11 @@ __device__ __forceinline__ void conv_epilogue_rows8(f32x4 (&acc)[NT][3], const C
 // (accumulators in the accumulator register file through inline-asm MFMAs were tried in round 5: hipcc splits the 256 registers of a
 // two-waves-per-SIMD kernel 128 / 128, the 144 accumulators of the 144 x 64 wave tile do not fit, and the K loop did not get faster:
 // 888 -> 944 us on the ASPP 3x3, profiles/r05_h2_kloop_ablations.txt)
+#if DML_WS_ABL & 16
+#define WS_MFMA_F16(ACCV, A_, B_) asm volatile("" ::"v"(A_), "v"(B_))
+#else
 #define WS_MFMA_F16(ACCV, A_, B_) ACCV = __builtin_amdgcn_mfma_f32_16x16x32_f16(A_, B_, ACCV, 0, 0, 0)
+#endif
 
 typedef unsigned int u32x4_ws __attribute__((ext_vector_type(4)));
 constexpr int WS_MT = 9;                       // 16-row fragments per wave tile (144 rows)
@@ -2254,12 +2259,12 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
         // between (2 x 96 register moves): three inlined copies -- what a compile-time sub-tile index costs; a run-time index into
         // acc would send all of it through scratch memory -- made these kernels 10-19 K instructions, more than the instruction
         // cache two CUs share.
-        if constexpr (EPI != 0)
+        if constexpr (EPI != 0 && !(DML_WS_ABL & 8))
             conv_epilogue_rows_ops<NT, MT / 3, (EPI & 1) != 0, (EPI & 2) != 0>(
                 acc3, a, blk_m * BM + wm * (16 * MT), blk_n * BN + wn * 64, lane, rows_stage,
                 priv ? rows_stage : smem + ((g - 2) % NST) * SB + wave * (WS_STAT_ROWS * 256), smem + NST * SB + 64 + wave * MASK_STAGE);
 #pragma clang loop unroll(disable)
-        for (int h = 0; h < (EPI != 0 ? 0 : MT / 3); ++h) {
+        for (int h = 0; h < ((EPI != 0 || (DML_WS_ABL & 8)) ? 0 : MT / 3); ++h) {      // (ablation 8: no epilogue at all)
             const int mw0 = blk_m * BM + wm * (16 * MT) + h * WS_STAT_ROWS, nw0 = blk_n * BN + wn * 64;
             if constexpr (PL == 1) conv_epilogue<bf16_t, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);
             else if (MODE == 0 && (a.bias != nullptr || a.post_scale != nullptr)) {

@@ -70,6 +70,23 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
             if sp == 2:
                 d.x_planes, d.x_unscale, d.x_plane_stride = yp.data_ptr(), yw.data_ptr() + 4096, yp.shape[1]
                 d.w_planes, d.w_unscale, d.w_plane_stride = wtp.data_ptr(), wtw.data_ptr() + 4096, wtp.shape[1]
+            epi = int(os.environ.get("BENCH_EPI", "0"))      # 1: identity-branch gradient, 2: fused BN-backward sums, 3: both (as conv1's data gradient in the plan)
+            if sp == 2 and epi:
+                keep = []
+                if epi & 1:
+                    rdz = torch.randn(M, Cc, device="cuda") * 1e-3
+                    rmask = torch.randint(0, 256, (M * (Cc // 4),), device="cuda", dtype=torch.uint8)
+                    d.res_dz, d.res_mask, d.res_ld = rdz.data_ptr(), rmask.data_ptr(), Cc
+                    keep += [rdz, rmask]
+                if epi & 2:
+                    by = torch.randn(M, Cc, device="cuda")
+                    bmask = torch.randint(0, 256, (M * (Cc // 4),), device="cuda", dtype=torch.uint8)
+                    bmean, binv = torch.zeros(Cc, device="cuda"), torch.ones(Cc, device="cuda")
+                    part = torch.empty((M + 47) // 48 * Cc * 2, device="cuda")
+                    gmx = torch.zeros(1025, device="cuda")
+                    d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = by.data_ptr(), bmask.data_ptr(), bmean.data_ptr(), binv.data_ptr()
+                    d.bnr_partials, d.bnr_ldy, d.bnr_relu, d.bnr_gmax = part.data_ptr(), Cc, 1, gmx.data_ptr()
+                    keep += [by, bmask, bmean, binv, part, gmx]
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
             line += "dgrad %s %.1fus %.0fTF | " % (nm, t * 1e6, fl / t / 1e12)
         if which in ("all", "wgrad"):
