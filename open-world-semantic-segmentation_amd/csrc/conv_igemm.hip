@@ -75,6 +75,7 @@ struct ConvArgs {
     int f32_split;      // fp32 tensors: products through the three-term bf16 split (DmlConvDesc::f32_split)
     // bit 0: the epilogue's bf16 output stores carry the non-temporal hint, bit 1: its partial-statistics stores (launch_conv)
     int nt_out;
+    int half_stagger;      // conv_ws_half_kernel: start delay of a CU's second workgroup, 10 ns ticks (launch_conv)
 };
 
 constexpr int WGRAD_DEPTH = 2;      // K steps per barrier of the 256 x 256 weight-gradient kernel (one: 3-12 % slower)
@@ -1784,6 +1785,10 @@ __device__ __forceinline__ int ws_tile_n(const int tile, const ConvArgs& a) {
     return (PL == 2 && DML_WS_N_FASTEST != 0) ? tile % a.nblk_n : tile / a.nblk_m;
 }
 
+// ring stages: six in one-plane (bf16) launches, three on two planes (51 KB stages), TWO in the half-tile configuration (two consumer
+// waves, 144 x 128, two workgroups per CU: 2 x 34 KB + flags + staging = 74 KB each)
+constexpr int ws_ring_stages(const int PL, const int NCW) { return PL == 1 ? WS_NST : (NCW == 2 ? 2 : 3); }
+
 // loader wave LW of NLD: compile-time piece ownership (no branches in the issue loop)
 // PL = 2: every operand tile is two planes (hi, lo fp16 of the scaled fp32 tensor); a stage = [A hi | A lo | B hi | B lo]
 template <int MW, int NW, int MODE, int NLD, int LW, int PL, int MT = WS_MT>
@@ -1791,12 +1796,12 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
                                                uint32_t* ready, uint32_t* consumed, const int lane, const int ntiles,
                                                const int first_tile) {
     typedef bf16_t T;
-    constexpr int NCW = 4, NT = 4;
+    constexpr int NCW = MW * NW, NT = 4;
     constexpr int BM = 16 * MT * MW, BN = 64 * NW;
     constexpr int PA = BM / 16, PB = BN / 16, NP = PL * (PA + PB);
     constexpr int SB = PL * (BM + BN) * BK * 2;
     constexpr int MYP = (NP - LW + NLD - 1) / NLD;
-    constexpr int NST = PL == 1 ? WS_NST : 3, D = PL == 1 ? WS_D : 1;
+    constexpr int NST = ws_ring_stages(PL, NCW), D = PL == 1 ? WS_D : 1;
     constexpr uint32_t OOB = 0x80000000u;
     static_assert(D * MYP <= 63, "vmcnt is a 6-bit counter");
     // (PL = 2: the descriptors span both planes; the lo plane is reached through the scalar offset)
@@ -1941,12 +1946,13 @@ typedef _Float16 mfma_f16x8 __attribute__((ext_vector_type(8)));
 // EPI (two planes, data gradient): 0 no epilogue operand, 1 accumulate / identity-branch gradient, 2 fused BatchNorm-backward sums,
 // 3 both -- ONE epilogue per instantiation (all of them behind run-time branches in one kernel: 144 accumulators live at a four-way
 // fork, 400-700 bytes of scratch per lane)
-template <int MW, int NW, int MODE, int NLD, int PL = 1, int MT = WS_MT, int EPI = 0>
-__global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs a, const uint32_t x_bytes, const uint32_t w_bytes) {
+template <int MW, int NW, int MODE, int NLD, int PL, int MT, int EPI>
+__device__ __forceinline__ void conv_ws_body(const ConvArgs& a, const uint32_t x_bytes, const uint32_t w_bytes) {
     typedef bf16_t T;
-    static_assert(MW * NW == 4, "four consumer waves, one per SIMD");
+    static_assert(MW * NW == 4 || (PL == 2 && MW == 1 && NW == 2 && NLD == 2),
+                  "four consumer waves, one per SIMD -- or the half-tile configuration: two consumer + two loader waves, two workgroups per CU");
     static_assert(MT % 3 == 0 && MT >= 3, "48-row sub-tiles (statistics groups, row epilogue)");
-    constexpr int NCW = 4, NT = 4, NST = PL == 1 ? WS_NST : 3;
+    constexpr int NCW = MW * NW, NT = 4, NST = ws_ring_stages(PL, NCW);
     constexpr int BM = 16 * MT * MW, BN = 64 * NW;
     constexpr int SB = PL * (BM + BN) * BK * 2;
     // two planes, 144 x 256: 2 KB of private staging per consumer wave behind the flags (conv_epilogue_rows8); the 288 x 128
@@ -1966,8 +1972,30 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
     uint32_t* const consumed = ready + 4;                                          // [4] stages whose reads were issued
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     if (tid < 16) reinterpret_cast<uint32_t*>(smem + NST * SB)[tid] = 0;
+    if constexpr (NCW == 2) {
+        __syncthreads();
+        // Half-tile configuration: workgroups b and b + grid / 2 share a CU, and the four waves of a workgroup sit on the CU's four
+        // SIMDs in an order that rotates from workgroup to workgroup (tools/probe_wg_placement.hip, profiles/r06_wg_placement.txt).
+        // Roles by SIMD, so that the CU's four consumer waves own a SIMD each: the first workgroup's consumers are its waves on SIMDs
+        // 0 / 1, the second's those on SIMDs 2 / 3.  (Were two waves of a workgroup ever on one SIMD, roles by wave index.)
+        uint32_t hw;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_HW_ID)" : "=s"(hw));
+        const int simd = (int)((hw >> 4) & 3u);
+        uint32_t* const sid = reinterpret_cast<uint32_t*>(smem + NST * SB) + 12;      // [4] (words 0 .. 11: ready / consumed / edone)
+        if (lane == 0) sid[wave] = 1u << simd;
+        __syncthreads();
+        const bool perm = (sid[0] | sid[1] | sid[2] | sid[3]) == 0xfu;
+        const int slot = (blockIdx.x >= (gridDim.x + 1) / 2) ? 1 : 0;
+        if (perm) wave = __builtin_amdgcn_readfirstlane(((simd >> 1) == slot ? 0 : NCW) + (simd & 1));
+        // the second workgroup of a CU starts late, so that its epilogues fall under the first one's K loops and vice versa: left to
+        // themselves the two start together and do the same thing at the same time
+        if (slot == 1 && a.half_stagger > 0) {
+            const uint64_t t0 = wall_clock64();
+            while (wall_clock64() - t0 < (uint64_t)a.half_stagger) __builtin_amdgcn_s_sleep(16);
+        }
+    }
     __syncthreads();
 
     const int ntiles = a.nblk_m * a.nblk_n;
@@ -2295,6 +2323,17 @@ __global__ __launch_bounds__((4 + NLD) * 64) void conv_ws_kernel(const ConvArgs 
             ws_st(consumed + wave, g);                  // the tile's last stage: its slot is free again
         }
     }
+}
+
+template <int MW, int NW, int MODE, int NLD, int PL = 1, int MT = WS_MT, int EPI = 0>
+__global__ __launch_bounds__((MW * NW + NLD) * 64) void conv_ws_kernel(const ConvArgs a, const uint32_t x_bytes, const uint32_t w_bytes) {
+    conv_ws_body<MW, NW, MODE, NLD, PL, MT, EPI>(a, x_bytes, w_bytes);
+}
+// the half-tile configuration (144 x 128, two consumer + two loader waves): at most 256 registers, so that two workgroups share a CU
+template <int MODE, int EPI>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void conv_ws_half_kernel(const ConvArgs a, const uint32_t x_bytes,
+                                                                                                const uint32_t w_bytes) {
+    conv_ws_body<1, 2, MODE, 2, 2, WS_MT, EPI>(a, x_bytes, w_bytes);
 }
 
 // may this launch run on conv_ws_kernel?  (shared by launch_conv and dml_conv_stat_rows)
@@ -3731,9 +3770,25 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             const int ntiles = a.nblk_m * a.nblk_n;
             const int grid = ntiles < CUS ? ntiles : CUS;
             const uint32_t xpb = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2), wpb = (uint32_t)((int64_t)a.N * a.Ktot * 2);
+            // Half-tile configuration (round 6): short K loops with several tiles per workgroup -- the layer3 1x1
+            // launches whose K loops (HBM nearly idle) and epilogues (matrix cores idle) alternate.  144 x 128 tiles, two consumer
+            // and two loader waves, 74 KB of LDS: TWO workgroups per CU, one's epilogue under the other's K loop.
+            static const int half_on = getenv("DML_WS_HALF") ? atoi(getenv("DML_WS_HALF")) : 0;
+            static const int half_kt = getenv("DML_WS_HALF_KT") ? atoi(getenv("DML_WS_HALF_KT")) : 32;
+            static const int half_stag = getenv("DML_WS_HALF_STAGGER") ? atoi(getenv("DML_WS_HALF_STAGGER")) : 0;
+            const int half_tiles = ((a.M + 143) / 144) * (a.N / 128);
+            const bool half = half_on != 0 && !n64 && (a.N % 128) == 0 && a.Ktot / BK <= half_kt && a.Ktot / BK >= 2 &&
+                              half_tiles >= (half_on == 2 ? 1 : 4) * CUS;
+            if (half) {
+                a.nblk_m = (a.M + 143) / 144;
+                a.nblk_n = a.N / 128;
+                a.half_stagger = half_stag;
+            }
             auto go = [&](auto epi_c) {
                 constexpr int EPI = decltype(epi_c)::value;
-                if (n64)
+                if (half)
+                    hipLaunchKernelGGL((conv_ws_half_kernel<MODE, EPI>), dim3(half_tiles < 2 * CUS ? half_tiles : 2 * CUS), dim3(256), 0, st, a, xpb, wpb);
+                else if (n64)
                     hipLaunchKernelGGL((conv_ws_kernel<4, 1, MODE, NLD, 2, 3, EPI>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
                 else if (wide)
                     hipLaunchKernelGGL((conv_ws_kernel<1, 4, MODE, NLD, 2, WS_MT, EPI>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
@@ -3841,7 +3896,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
-    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.half_stagger = 0;
     a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = d->dtype == DML_F32 ? d->f32_split : 0;
     if (a.f32_split < 0 || a.f32_split > 2) return DML_EINVAL;
     a.x_planes = nullptr; a.w_planes = nullptr; a.x_unscale = nullptr; a.w_unscale = nullptr; a.x_plane_bytes = a.w_plane_bytes = 0;
@@ -3958,7 +4013,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, float* dbg, 
     a.post_scale = nullptr; a.post_shift = nullptr; a.post_mean = nullptr; a.post_res = nullptr; a.post_ldres = 0;
     a.post_relu = 0;
     a.tail_ws = nullptr; a.tail_cnt = nullptr; a.tail_full = 0; a.tail_q = 1; a.tail_ws_elems_ = 0; a.tail_cnt_len_ = 0;
-    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = 0;
+    a.res_dz = nullptr; a.res_mask = nullptr; a.res_ld = 0; a.nt_out = 0; a.half_stagger = 0; a.acc32 = nullptr; a.acc32_ld = 0; a.f32_split = 0;
     a.w_tiled = 0; a.ws_min_tiles = 0;
     a.x_planes = nullptr; a.w_planes = nullptr; a.x_unscale = nullptr; a.w_unscale = nullptr; a.x_plane_bytes = a.w_plane_bytes = 0;
     a.x_bytes = (uint32_t)((((int64_t)(a.B * a.Hi) * a.Wi - 1) * a.ldx + a.C) * 2);

@@ -9,7 +9,18 @@ import torch
 from dmlnet import _lib
 from dmlnet._lib import ConvDesc, WgradDesc
 lib = _lib.load()
+torch.manual_seed(int(os.environ.get("BENCH_SEED", "0")))      # (same inputs in every process: BENCH_DUMP digests are comparable)
 st = torch.cuda.current_stream().cuda_stream
+import hashlib
+DUMP = os.environ.get("BENCH_DUMP")        # file: one line per launch with sha256 of every output tensor (bit-equality checks between builds / configurations)
+
+
+def digest(tag, *tensors):
+    if not DUMP:
+        return
+    torch.cuda.synchronize()
+    with open(DUMP, "a") as fh:
+        fh.write(tag + " " + " ".join(hashlib.sha256(t.detach().cpu().numpy().tobytes()).hexdigest()[:16] for t in tensors) + "\n")
 
 
 def timeit(fn, n=10):
@@ -62,6 +73,7 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
                 d.x_planes, d.x_unscale, d.x_plane_stride = xp.data_ptr(), xw.data_ptr() + 4096, xp.shape[1]
                 d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
+            digest("fwd %s %s" % (line.strip(), nm), y, stats)
             line += "fwd+st %s %.1fus %.0fTF | " % (nm, t * 1e6, fl / t / 1e12)
         if which in ("all", "dgrad") and Cc % 128 == 0:
             d = ConvDesc(x=dy.data_ptr(), w=wt.data_ptr(), y=gx.data_ptr(), bias=None, stats=None, B=B, Hi=H, Wi=W, C=N, ldx=N,
@@ -88,6 +100,7 @@ for (B, H, W, Cc, N, k, dil) in SHAPES:
                     d.bnr_partials, d.bnr_ldy, d.bnr_relu, d.bnr_gmax = part.data_ptr(), Cc, 1, gmx.data_ptr()
                     keep += [by, bmask, bmean, binv, part, gmx]
             t = timeit(lambda: lib.dml_conv_igemm(C.byref(d), st))
+            digest("dgrad epi%d %s %s" % (int(os.environ.get("BENCH_EPI", "0")), line.split("|")[0].strip(), nm), gx, *([part] if (sp == 2 and epi & 2) else []))
             line += "dgrad %s %.1fus %.0fTF | " % (nm, t * 1e6, fl / t / 1e12)
         if which in ("all", "wgrad"):
             ws = torch.empty(48 << 20, device="cuda")
