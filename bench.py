@@ -547,7 +547,12 @@ def infer_bench(args):
     model.to(device).eval()
     model.set_compute_dtype(torch.bfloat16 if args.dtype == "bf16" else torch.float32,
                             fp32_products=None if args.dtype == "bf16" else FP32_PRODUCTS[args.dtype])
-    batch = args.batch if args.batch != 16 else 1
+    fwd_only = args.mode == "fwd"          # BASELINE config #2: forward-only, 768 x 768, 8 images (eval plan: BatchNorm folded into the conv epilogues)
+    if fwd_only:
+        batch = args.batch if args.batch != 16 else 8
+        args.height = args.width = args.size
+    else:
+        batch = args.batch if args.batch != 16 else 1
     g = torch.Generator().manual_seed(4321 + rank)
     img = torch.randn(batch, 3, args.height, args.width, generator=g).to(device)
     proto = np.full((16,), 0.1)
@@ -555,6 +560,8 @@ def infer_bench(args):
     def step():
         with torch.no_grad():
             logits, centers, feats = model(img)
+            if fwd_only:
+                return logits, feats
             preds, msp = utils.argmax_msp(logits)
             score = utils.dissum_score(logits, clip=1000.0, inclusive=False)
             return utils.novel_relabel(preds, logits, feats, proto, -1.5, 16), score
@@ -577,15 +584,32 @@ def infer_bench(args):
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
+    roof = None
+    if rank == 0 and world == 1 and not args.no_profile:
+        # every conv launch of the (un-forked) forward plan alone on the stream, HIP events around each: algorithmic FLOPs / summed time
+        plan = next(iter(model._engine.plans.values()))
+        flops, _ = conv_flops_of_plan(plan)
+        tsec, counts = profile_convs(model, model._engine, step, 2)
+        peak = PEAK[args.dtype]
+        roof = {"bound": "mfma", "kernel": "all conv launches of the forward plan", "achieved": flops / tsec["igemm"] / 1e12,
+                "peak": peak / 1e12, "unit": "TFLOP/s", "frac": flops / tsec["igemm"] / peak, "traffic": None,
+                "flops_per_step": flops, "launches_per_step": counts["igemm"], "conv_ms_per_step": tsec["igemm"] * 1e3,
+                "whole_step_frac": flops / (elapsed / args.steps) / peak,
+                "note": "profiled pass runs the ASPP branches one after the other (Python replay); the timed region forks them where the plan does"}
     if rank == 0:
-        print(json.dumps({
-            "metric": "images/sec open-world inference (eval forward + argmax/msp + dissum + novel relabel), DeepLabV3+R101",
+        out = {
+            "metric": ("images/sec forward-only (eval), DeepLabV3+R101 OS16" if fwd_only else
+                       "images/sec open-world inference (eval forward + argmax/msp + dissum + novel relabel), DeepLabV3+R101"),
             "value": batch * world * args.steps / elapsed, "unit": "images/sec", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": DTYPE_FIELD[args.dtype], "data": "synthetic",
-            "config": {"workload": "open-world inference %dx%d, %d image(s)/GPU/step, 16 prototypes, random-init weights"
+            "config": {"workload": ("forward-only %dx%d, %d images/GPU/step, random-init weights" if fwd_only else
+                                    "open-world inference %dx%d, %d image(s)/GPU/step, 16 prototypes, random-init weights")
                                    % (args.height, args.width, batch), "parallelism": "dp%d" % world,
-                       "arithmetic": ARITHMETIC[args.dtype]}}))
+                       "arithmetic": ARITHMETIC[args.dtype]}}
+        if roof is not None:
+            out["roofline"] = roof
+        print(json.dumps(out))
     if world > 1:
         dist.destroy_process_group()
 
@@ -657,9 +681,10 @@ def main():
                     help="skip the companion passes (bf16 storage, exact fp32, three-term split) of the default run")
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = every physical core of the host")
     ap.add_argument("--dump-conv", default=None, help="write a per-launch conv table (json) from the profiled pass")
-    ap.add_argument("--mode", default="train", choices=["train", "infer", "ood"],
+    ap.add_argument("--mode", default="train", choices=["train", "infer", "fwd", "ood"],
                     help="train = the headline metric (default); infer = SURVEY 8(d) config #5: open-world inference "
-                         "at --height x --width, --batch images per step (default 1), scores on the device")
+                         "at --height x --width, --batch images per step (default 1), scores on the device; fwd = BASELINE "
+                         "config #2: forward-only (eval) at --size, --batch images per step (default 8)")
     ap.add_argument("--height", type=int, default=1024)
     ap.add_argument("--width", type=int, default=2048)
     ap.add_argument("--print-csrc-sha", action="store_true", help="print the fingerprint of the kernel sources and exit")
@@ -671,7 +696,7 @@ def main():
         launch_ranks(args.gpus)                  # never returns
     if args.mode == "ood":
         return ood_bench(args)
-    if args.mode == "infer":
+    if args.mode in ("infer", "fwd"):
         return infer_bench(args)
 
     from dmlnet import parallel
