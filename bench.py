@@ -246,6 +246,8 @@ def _conv_class(d, igemm):
         if d.C == 12 and d.R == 4:      # the stem in space-to-depth form: labelled as the convolution it computes
             return kind, "7x7 3->%d @%dx%d s2" % (cout, hw[0], hw[1])
     lab = "%dx%d %d->%d @%dx%d" % (d.R, d.S, cin, cout, hw[0], hw[1])
+    if igemm and d.mode == 1 and d.sub_grid:
+        lab += " s2 parity class"          # one of the stride-1 launches a stride-2 data gradient is issued as (DmlConvDesc.sub_grid)
     if d.stride != 1:
         lab += " s%d" % d.stride
     if d.dil != 1:

@@ -30,7 +30,7 @@
 extern "C" {
 #endif
 
-#define DML_ABI_VERSION 5
+#define DML_ABI_VERSION 6
 
 enum { DML_F32 = 0, DML_BF16 = 1 };
 enum { DML_EINVAL = -1, DML_EALIGN = -2, DML_EUNSUPPORTED = -3 };
@@ -147,6 +147,17 @@ typedef struct DmlConvDesc {
     const float* w_unscale;
     int64_t x_plane_stride, w_plane_stride;
     float* bnr_gmax;      /* see bnr_* above                                                             */
+    /* mode 1, two-plane launches (f32_split == 2) only -- one PARITY CLASS of the data gradient of a stride-2 convolution, issued as
+     * a stride-1 launch on the grid of dY (round 6): a pixel of dX only sees the filter taps of its own row / column parity, so the
+     * data gradient of a 3x3 stride-2 convolution is four stride-1 correlations with 1, 2, 2 and 4 taps (nine instead of 36 tap
+     * products per four pixels), that of a 1x1 stride-2 convolution one 1x1 launch on the even pixels.  sub_grid = 1: the rows of this
+     * launch (b, y2, x2 on the Ho x Wo grid of the descriptor) are the pixels (b, 2 y2 + sub_y, 2 x2 + sub_x) of y, res_dz, bnr_y and
+     * the masks, tensors of B x 2 Ho x 2 Wo pixels; bnr_partials receives ceil(B Ho Wo / 48) groups (the caller offsets the pointer
+     * per class).  pad_w_set = 1: `pad_w` replaces `pad` along the width (a class's sub-filter is R x S = 1|2 x 1|2 taps with
+     * padding R - 1 / S - 1).  Any other kernel family returns DML_EUNSUPPORTED for such a descriptor. */
+    int32_t sub_grid, sub_y, sub_x;
+    int32_t pad_w_set, pad_w;
+    int32_t reserved_r6;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */
@@ -252,6 +263,12 @@ int dml_pack_input(const float* x_nchw, void* y_nhwc, int B, int C, int H, int W
  * dml_s2d_wgrad adds a weight gradient computed in that form (dw2[N][k2][k2][4 C]) to the parameter's dw[N][k][k][C]. */
 int dml_pack_input_s2d(const float* x_nchw, float* x2, int B, int C, int H, int W, void* stream);
 int dml_s2d_weights(const float* w, float* w2, int N, int k, int C, void* stream);
+/* Sub-filter of a prepared fp32 weight copy [rows][taps_src][n]: dst[row][j][:] = src[row][t_j][:] for j < ntaps <= 4 (n % 4 == 0,
+ * 16-byte aligned).  The data gradient of a stride-2 convolution (backbone/resnet.py:171-193 of the reference: layer2.0 / layer3.0)
+ * runs as one stride-1 launch per pixel-parity class on the taps that class sees (DmlConvDesc.sub_grid); this builds the class's
+ * operand from the transposed copy wt[C][R S][N] of dml_prep_weights. */
+int dml_gather_taps(const float* src, float* dst, int rows, int taps_src, int n, int ntaps, int t0, int t1, int t2, int t3,
+                    void* stream);
 int dml_s2d_wgrad(const float* dw2, float* dw, int N, int k, int C, void* stream);
 
 /* ------------------------------------------------------------------------------------------------

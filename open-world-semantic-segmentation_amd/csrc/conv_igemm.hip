@@ -76,7 +76,26 @@ struct ConvArgs {
     // bit 0: the epilogue's bf16 output stores carry the non-temporal hint, bit 1: its partial-statistics stores (launch_conv)
     int nt_out;
     int half_stagger;      // conv_ws_half_kernel: start delay of a CU's second workgroup, 10 ns ticks (launch_conv)
+    // one parity class of a stride-2 data gradient as a stride-1 launch on dY's grid (DmlConvDesc::sub_grid): the launch's rows are
+    // the pixels (b, 2 y2 + sub_y, 2 x2 + sub_x) of the B x 2 Ho x 2 Wo tensors y / res_dz / bnr_y / masks (ws_out_row)
+    int pad_x;             // padding along the width (== pad unless DmlConvDesc::pad_w_set)
+    int sub_grid, sub_y, sub_x;
 };
+
+// physical pixel row of row m of the launch in the epilogue's tensors (y, accumulate / identity operand, bnr_y, masks); a row beyond
+// M maps to the first row beyond those tensors (buffer accesses with the tensor's size as range drop it / read zeros, pointer
+// accesses are guarded by their callers)
+__device__ __forceinline__ uint32_t ws_out_row(const ConvArgs& a, const uint32_t m) {
+    if (!a.sub_grid) return m;
+    if (m >= (uint32_t)a.M) return 4u * (uint32_t)a.M;
+    const uint32_t b = fdiv(m, a.div_howo);
+    const uint32_t rem = m - b * (uint32_t)(a.Ho * a.Wo);
+    const uint32_t y2 = fdiv(rem, a.div_wo);
+    const uint32_t x2 = rem - y2 * (uint32_t)a.Wo;
+    return ((b * 2u * (uint32_t)a.Ho + 2u * y2 + (uint32_t)a.sub_y) * 2u * (uint32_t)a.Wo) + 2u * x2 + (uint32_t)a.sub_x;
+}
+// rows of those tensors (range of the epilogue's buffer descriptors)
+__device__ __forceinline__ uint32_t ws_out_rows(const ConvArgs& a) { return a.sub_grid ? 4u * (uint32_t)a.M : (uint32_t)a.M; }
 
 constexpr int WGRAD_DEPTH = 2;      // K steps per barrier of the 256 x 256 weight-gradient kernel (one: 3-12 % slower)
 
@@ -1357,7 +1376,8 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
             const int m = mw0 + k * 4 + (lane >> 4);
-            if (m < a.M) st16f(yb + (int64_t)m * a.ldy + c0, o[k].x, o[k].y, o[k].z, o[k].w, (a.nt_out & 1) != 0);
+            if (m < a.M) st16f(yb + (int64_t)(MODE == 1 ? ws_out_row(a, (uint32_t)m) : (uint32_t)m) * a.ldy + c0, o[k].x, o[k].y, o[k].z, o[k].w,
+                               (a.nt_out & 1) != 0);
         }
         return;
     }
@@ -1391,7 +1411,7 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
                 const int m = mw0 + lane;
                 uint4 rv = make_uint4(0x0f0f0f0fu, 0x0f0f0f0fu, 0x0f0f0f0fu, 0x0f0f0f0fu), bv = rv;
                 if (m < a.M) {
-                    const int64_t mo = (int64_t)m * (a.N >> 2) + (nw0 >> 2);
+                    const int64_t mo = (int64_t)ws_out_row(a, (uint32_t)m) * (a.N >> 2) + (nw0 >> 2);
                     if (use_rm) rv = *reinterpret_cast<const uint4*>(a.res_mask + mo);
                     if (use_bm) bv = *reinterpret_cast<const uint4*>(a.bnr_mask + mo);
                 }
@@ -1410,11 +1430,12 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
                 old[g4 & 1][u] = make_float4(0.f, 0.f, 0.f, 0.f);
                 yv[g4 & 1][u] = old[g4 & 1][u];
                 if (m < a.M) {
+                    const int64_t pm = (int64_t)ws_out_row(a, (uint32_t)m);
                     if (HO) {
-                        if (resm) old[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.res_dz) + (int64_t)m * a.res_ld + c0);
-                        else old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + (int64_t)m * a.ldy + c0);
+                        if (resm) old[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.res_dz) + pm * a.res_ld + c0);
+                        else old[g4 & 1][u] = *reinterpret_cast<const float4*>(yb + pm * a.ldy + c0);
                     }
-                    if (BNR) yv[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + (int64_t)m * a.bnr_ldy + c0);
+                    if (BNR) yv[g4 & 1][u] = *reinterpret_cast<const float4*>(static_cast<const float*>(a.bnr_y) + pm * a.bnr_ldy + c0);
                 }
             }
         };
@@ -1436,7 +1457,7 @@ __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const Co
                     }
                     o.x += t.x; o.y += t.y; o.z += t.z; o.w += t.w;
                 }
-                st16f(yb + (int64_t)m * a.ldy + c0, o.x, o.y, o.z, o.w, (a.nt_out & 1) != 0);
+                st16f(yb + (int64_t)ws_out_row(a, (uint32_t)m) * a.ldy + c0, o.x, o.y, o.z, o.w, (a.nt_out & 1) != 0);
                 if (BNR) {
                     const uint32_t bits = pkb >> 4;
                     const float4 y4 = yv[g4 & 1][u];
@@ -1523,16 +1544,19 @@ __device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3],
     const uint32_t y_row = (uint32_t)a.ldy * 4u;
     const uint32_t o_row = resm ? (uint32_t)a.res_ld * 4u : y_row, b_row = (uint32_t)a.bnr_ldy * 4u, m_row = (uint32_t)(a.N >> 2);
     const bool use_rm = HO && resm, use_bm = BNR && a.bnr_relu != 0;
-    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)((uint32_t)a.M * y_row), 0x00020000);
+    // (sub_grid: the launch's rows are a parity class of tensors with four times as many pixels, ws_out_row; a row beyond M maps
+    // beyond every range)
+    const uint32_t prow_n = ws_out_rows(a);
+    const __amdgpu_buffer_rsrc_t rs_y = __builtin_amdgcn_make_buffer_rsrc(a.y, 0, (int)(prow_n * y_row), 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_o = __builtin_amdgcn_make_buffer_rsrc(
-        resm ? const_cast<void*>(a.res_dz) : a.y, 0, HO ? (int)((uint32_t)a.M * o_row) : 0, 0x00020000);
+        resm ? const_cast<void*>(a.res_dz) : a.y, 0, HO ? (int)(prow_n * o_row) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_b = __builtin_amdgcn_make_buffer_rsrc(
-        BNR ? const_cast<void*>(static_cast<const void*>(a.bnr_y)) : a.y, 0, BNR ? (int)((uint32_t)a.M * b_row) : 0, 0x00020000);
+        BNR ? const_cast<void*>(static_cast<const void*>(a.bnr_y)) : a.y, 0, BNR ? (int)(prow_n * b_row) : 0, 0x00020000);
     // (a mask that is not in use: a zero-sized range -- the loads return zeros without touching memory -- and constant bits instead)
     const __amdgpu_buffer_rsrc_t rs_rm = __builtin_amdgcn_make_buffer_rsrc(
-        use_rm ? const_cast<void*>(static_cast<const void*>(a.res_mask)) : a.y, 0, use_rm ? (int)((uint32_t)a.M * m_row) : 0, 0x00020000);
+        use_rm ? const_cast<void*>(static_cast<const void*>(a.res_mask)) : a.y, 0, use_rm ? (int)(prow_n * m_row) : 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_bm = __builtin_amdgcn_make_buffer_rsrc(
-        use_bm ? const_cast<void*>(static_cast<const void*>(a.bnr_mask)) : a.y, 0, use_bm ? (int)((uint32_t)a.M * m_row) : 0, 0x00020000);
+        use_bm ? const_cast<void*>(static_cast<const void*>(a.bnr_mask)) : a.y, 0, use_bm ? (int)(prow_n * m_row) : 0, 0x00020000);
     const int ngroups = (a.M + WS_STAT_ROWS_C - 1) / WS_STAT_ROWS_C;
     const __amdgpu_buffer_rsrc_t rs_p = __builtin_amdgcn_make_buffer_rsrc(
         BNR ? static_cast<void*>(a.bnr_partials) : a.y, 0, BNR ? (int)((uint32_t)ngroups * (uint32_t)a.N * 8u) : 0, 0x00020000);
@@ -1548,7 +1572,7 @@ __device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3],
     // the masks of sub-tile h + 1 are fetched during sub-tile h
     u32x4_b rv, bv;
     auto load_masks = [&](const int h) {
-        const uint32_t mo = (uint32_t)(mwt + h * WS_STAT_ROWS_C + lane) * m_row + (uint32_t)(nw0 >> 2);
+        const uint32_t mo = ws_out_row(a, (uint32_t)(mwt + h * WS_STAT_ROWS_C + lane)) * m_row + (uint32_t)(nw0 >> 2);
         rv = __builtin_amdgcn_raw_buffer_load_b128(rs_rm, mo, 0, 0);
         bv = __builtin_amdgcn_raw_buffer_load_b128(rs_bm, mo, 0, 0);
     };
@@ -1556,7 +1580,7 @@ __device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3],
     auto load_quad = [&](auto Qc) {
         constexpr int Q = decltype(Qc)::value, slot = Q % 12;
         if constexpr (Q < 12 * NS) {
-            const uint32_t m = (uint32_t)(mwt + Q * 4 + (lane >> 4));
+            const uint32_t m = ws_out_row(a, (uint32_t)(mwt + Q * 4 + (lane >> 4)));
             if (HO) old[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_o, m * o_row + coff, 0, 0);
             if (BNR) yv[slot] = __builtin_amdgcn_raw_buffer_load_b128(rs_b, m * b_row + coff, 0, 0);
         }
@@ -1601,7 +1625,7 @@ __device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3],
             // the loads that run P quads ahead (into the slot quad q + P - 12 left P quads ago)
             load_quad(std::integral_constant<int, h * 12 + q + P>{});
             const int r = q * 4 + (lane >> 4);
-            const uint32_t m = (uint32_t)(mw0 + r);
+            const uint32_t m = ws_out_row(a, (uint32_t)(mw0 + r));
             float4 o = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
             const uint32_t pkb = *reinterpret_cast<const uint8_t*>(mstage + lane + q * 64);
             if (HO) {
@@ -1838,7 +1862,7 @@ __device__ __forceinline__ void conv_ws_loader(const ConvArgs& a, const uint32_t
                     const uint32_t yo = fdiv(rem, a.div_wo);
                     const uint32_t xo = rem - yo * (uint32_t)a.Wo;
                     const int iy = MODE == 0 ? (int)yo * a.stride - a.pad : (int)yo + a.pad;
-                    const int ix = MODE == 0 ? (int)xo * a.stride - a.pad : (int)xo + a.pad;
+                    const int ix = MODE == 0 ? (int)xo * a.stride - a.pad_x : (int)xo + a.pad_x;
                     const int by = MODE == 0 ? iy : (iy >> sh2), bx = MODE == 0 ? ix : (ix >> sh2);
                     base[q] = ((((int)b * a.Hi + by) * a.Wi + bx) * a.ldx + lchunk * 8) * 2;
                     uint32_t mk = 0;
@@ -3973,20 +3997,30 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
     }
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
-    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_x = d->pad; a.sub_grid = 0; a.sub_y = a.sub_x = 0;
     a.M = d->B * d->Ho * d->Wo;
     a.Ktot = d->R * d->S * d->C;
     a.y_f32 = d->y_f32; a.accum = d->accum;
+    if (d->pad_w_set) a.pad_x = d->pad_w;
+    if (d->sub_grid) {
+        // a parity class of a stride-2 data gradient: stride-1 geometry on dY's grid, the two-plane kernel's row epilogues only
+        if (d->mode != 1 || d->stride != 1 || d->dil != 1 || d->Hi != d->Ho || d->Wi != d->Wo || (unsigned)d->sub_y > 1u ||
+            (unsigned)d->sub_x > 1u || d->dtype != DML_F32)
+            return DML_EINVAL;
+        if ((int64_t)4 * d->B * d->Ho * d->Wo * (int64_t)d->ldy * 4 >= (1ll << 31)) return DML_EUNSUPPORTED;
+        a.sub_grid = 1; a.sub_y = d->sub_y; a.sub_x = d->sub_x;
+    }
     a.nblk_n = a.nblk_m = 0;
     a.div_wo = make_fastdiv((uint32_t)d->Wo);
     a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));
     a.div_c = make_fastdiv((uint32_t)d->C);
     hipStream_t st = static_cast<hipStream_t>(stream);
+    if ((a.sub_grid || a.pad_x != a.pad) && (d->dtype == DML_BF16 || a.acc32)) return DML_EUNSUPPORTED;
     if (a.acc32) return launch_conv<bf16_t, 2>(a, st);
     if (d->dtype == DML_BF16)
         return d->mode == 0 ? launch_conv<bf16_t, 0>(a, st) : launch_conv<bf16_t, 1>(a, st);
-    // fp32: only the two-plane kernel writes the BN-backward sums / adds the masked identity-branch gradient
-    if ((a.bnr_partials || a.res_dz) && !conv_ws_planes_eligible(a, d->mode)) return DML_EUNSUPPORTED;
+    // fp32: only the two-plane kernel writes the BN-backward sums / adds the masked identity-branch gradient / maps a sub-grid
+    if ((a.bnr_partials || a.res_dz || a.sub_grid || a.pad_x != a.pad) && !conv_ws_planes_eligible(a, d->mode)) return DML_EUNSUPPORTED;
     // x == x_planes: the caller keeps this operand as fp16 planes ONLY (no fp32 tensor behind `x`).  Every other fp32 kernel would
     // read the planes as floats: refuse instead of falling back
     if (d->f32_split == 2 && d->x_planes && d->x == d->x_planes && !conv_ws_planes_eligible(a, d->mode)) return DML_EUNSUPPORTED;
@@ -4001,7 +4035,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, float* dbg, 
     a.x = d->x; a.w = d->w; a.y = d->y; a.bias = nullptr; a.stats = d->stats;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
-    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_x = d->pad; a.sub_grid = 0; a.sub_y = a.sub_x = 0;
     a.M = d->B * d->Ho * d->Wo; a.Ktot = d->R * d->S * d->C; a.y_f32 = 0; a.accum = 0;
     a.nblk_m = (a.M + 127) / 128; a.nblk_n = (a.N + 127) / 128;
     a.div_wo = make_fastdiv((uint32_t)d->Wo); a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));

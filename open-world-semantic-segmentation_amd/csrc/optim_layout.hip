@@ -469,6 +469,34 @@ __global__ __launch_bounds__(256) void s2d_weights_kernel(float* __restrict__ w,
 }
 }  // namespace
 
+// sub-filter of a weight copy: dst[row][j][0 .. n) = src[row][taps[j]][0 .. n), j < ntaps <= 4 (dml_gather_taps)
+namespace {
+__global__ __launch_bounds__(256) void gather_taps_kernel(const float* __restrict__ src, float* __restrict__ dst, int rows, int taps_src,
+                                                          int n, int ntaps, int t0, int t1, int t2, int t3) {
+    const int n4 = n >> 2;
+    const int64_t total = (int64_t)rows * ntaps * n4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int v = (int)(i % n4), j = (int)((i / n4) % ntaps);
+        const int64_t row = i / ((int64_t)n4 * ntaps);
+        const int t = j == 0 ? t0 : (j == 1 ? t1 : (j == 2 ? t2 : t3));
+        reinterpret_cast<float4*>(dst)[i] = reinterpret_cast<const float4*>(src)[(row * taps_src + t) * n4 + v];
+    }
+}
+}  // namespace
+
+extern "C" int dml_gather_taps(const float* src, float* dst, int rows, int taps_src, int n, int ntaps, int t0, int t1, int t2, int t3,
+                               void* stream) {
+    if (!src || !dst || rows <= 0 || taps_src <= 0 || n <= 0 || ntaps <= 0 || ntaps > 4) return DML_EINVAL;
+    const int t[4] = {t0, t1, t2, t3};
+    for (int j = 0; j < ntaps; ++j)
+        if (t[j] < 0 || t[j] >= taps_src) return DML_EINVAL;
+    if ((n & 3) || ((reinterpret_cast<uintptr_t>(src) | reinterpret_cast<uintptr_t>(dst)) & 15)) return DML_EALIGN;
+    hipLaunchKernelGGL(gather_taps_kernel, dim3(grid_for((int64_t)rows * ntaps * (n >> 2), 256, 256 * 16)), dim3(256), 0,
+                       static_cast<hipStream_t>(stream), src, dst, rows, taps_src, n, ntaps, t0, t1, t2, t3);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dml_pack_input_s2d(const float* x_nchw, float* y, int B, int C, int H, int W, void* stream) {
     if (!x_nchw || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0) return DML_EINVAL;
     if ((H | W) & 1) return DML_EALIGN;

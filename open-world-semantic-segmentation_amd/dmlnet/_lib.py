@@ -45,7 +45,10 @@ class ConvDesc(C.Structure):
                 ("w_tiled", C.c_int32), ("ws_min_tiles", C.c_int32),
                 # f32_split == 2: fp16 hi / lo planes of the scaled operands (dml_h2_split; see the header)
                 ("x_planes", c_p), ("w_planes", c_p), ("x_unscale", c_p), ("w_unscale", c_p),
-                ("x_plane_stride", C.c_int64), ("w_plane_stride", C.c_int64), ("bnr_gmax", c_p)]
+                ("x_plane_stride", C.c_int64), ("w_plane_stride", C.c_int64), ("bnr_gmax", c_p),
+                # mode 1, f32_split == 2: one parity class of a stride-2 data gradient as a stride-1 launch (see the header)
+                ("sub_grid", C.c_int32), ("sub_y", C.c_int32), ("sub_x", C.c_int32),
+                ("pad_w_set", C.c_int32), ("pad_w", C.c_int32), ("reserved_r6", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 24
@@ -112,6 +115,7 @@ _PROTOS = {
     "dml_pack_input_s2d": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_p]),
     "dml_s2d_weights": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
     "dml_s2d_wgrad": (c_i, [c_p, c_p, c_i, c_i, c_i, c_p]),
+    "dml_gather_taps": (c_i, [c_p, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_bn_finalize": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
     "dml_bn_moments": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p]),
     "dml_bn_finalize_moments": (c_i, [c_p, c_i, c_i64, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p, c_p]),
@@ -199,7 +203,7 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the header and the library disagree
         fn.restype = res
         fn.argtypes = args
-    if lib.dml_abi_version() != 5:
+    if lib.dml_abi_version() != 6:
         raise DmlError("libdmlnet_hip.so ABI version mismatch")
     _lib = lib
     return lib

@@ -372,6 +372,10 @@ class Plan:
         # f16x2: the plane-scale bound of a BatchNorm output / of dy computed by the finalize launch's last block instead of a
         # one-block launch of its own behind it (dml_bn_finalize_bound / dml_bn_bwd_finalize_bound).  DML_FUSE_BOUND=0: off (A/B)
         self.fuse_bound = os.environ.get("DML_FUSE_BOUND", "1") != "0"
+        # f16x2: data gradients of the stride-2 convolutions as stride-1 launches per pixel-parity class (conv_dgrad_s2_classes).
+        # DML_S2_CLASSES=0: off (A/B, tests)
+        self.s2_classes_on = os.environ.get("DML_S2_CLASSES", "1") != "0"
+        self.prep_gather = []          # dml_gather_taps argument lists: sub-filters of the transposed weight copies, refreshed with them
         self._bound_words, self._bound_used = None, 0
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
         # producer, as autograd does in the reference (resnet.py:112-113, network/utils.py:360).  Off by default: measured
@@ -630,6 +634,8 @@ class Plan:
         this one (only looked at for staged gradients, stage_grad32)."""
         gx = self.grad_of(x)
         kh, kw, s, d, p, _, _ = self.conv_geom(conv, x)
+        if self.s2_classes_ok(dy, conv, x, kh, kw, s, d, p):
+            return self.conv_dgrad_s2_classes(dy, conv, wt, x, gx, kh, kw, p)
         dsc = ConvDesc(x=dy.ptr, w=wt.data_ptr(), y=gx.ptr, bias=None, stats=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld, Ho=x.H, Wo=x.W, N=x.C,
                        ldy=gx.ld, R=kh, S=kw, stride=s, dil=d, pad=p, dtype=self.dt, y_f32=0,
                        accum=1 if x.root.grad_init else 0, mode=1)
@@ -663,6 +669,56 @@ class Plan:
         self.last_dgrad.pop(self.grad_of(x.root).ptr, None)
         if x is x.root and g32 is None:
             self.last_dgrad[gx.ptr] = dsc         # whole-tensor gradient: candidate for the fused BN-backward reduce
+
+    # ---- data gradient of a stride-2 convolution as one stride-1 launch per pixel-parity class (DmlConvDesc.sub_grid)
+    def s2_classes_ok(self, dy, conv, x, kh, kw, s, d, p):
+        """f16x2 plans, 3x3 / pad 1 and 1x1 / pad 0 at stride 2 on even maps, shapes the two-plane kernel takes.  A pixel of dX only sees
+        the taps of its own row / column parity: the 3x3 becomes four launches of 1, 2, 2 and 4 taps (nine tap products per four pixels
+        instead of 36, most of them on zeros), the 1x1 one launch on the even pixels -- which requires that the gradient already holds
+        its other producers' sum (it only ADDS there)."""
+        if not (self.s2_classes_on and s == 2 and d == 1 and kh == kw and (kh, p) in ((3, 1), (1, 0))
+                and self.f32_split == 2 and self.dtype == torch.float32 and not isinstance(conv, _S2DConv)):
+            return False
+        if x is not x.root or x.g32 is not None or x.H != 2 * dy.H or x.W != 2 * dy.W or dy.C % 32 or x.C % 64:
+            return False
+        if kh == 1 and not x.root.grad_init:
+            return False
+        return self.planes_fit(dy.M, dy.ld) and 16 * dy.M * x.C < (1 << 31) - 4096
+
+    def conv_dgrad_s2_classes(self, dy, conv, wt, x, gx, kh, kw, p):
+        lib = self.lib
+        accum = 1 if x.root.grad_init else 0
+        xpl = self.h2_of(dy, self.bwd)
+        descs = []
+        for cy in (0, 1):
+            for cx in (0, 1):
+                rs = [r for r in range(kh) if (r - cy - p) % 2 == 0]
+                ss = [t for t in range(kw) if (t - cx - p) % 2 == 0]
+                if not rs or not ss:
+                    continue                         # (1x1: only the even pixels receive anything; the gradient is accumulated into)
+                taps = [r * kw + t for r in rs for t in ss]
+                # the class's operand: rows = dX channels, K = its taps x dY channels, from the transposed copy wt[C][R S][N]
+                sub = self.fbuf(x.C * len(taps) * dy.C)
+                self.prep_gather.append((wt.data_ptr(), sub.data_ptr(), x.C, kh * kw, dy.C, len(taps), *(taps + [0] * (4 - len(taps)))))
+                self.prepped_version = None
+                dsc = ConvDesc(x=dy.ptr, w=sub.data_ptr(), y=gx.ptr, bias=None, stats=None, B=dy.B, Hi=dy.H, Wi=dy.W, C=dy.C, ldx=dy.ld,
+                               Ho=dy.H, Wo=dy.W, N=x.C, ldy=gx.ld, R=len(rs), S=len(ss), stride=1, dil=1, pad=(cy + p - rs[0]) // 2,
+                               dtype=self.dt, y_f32=0, accum=accum, mode=1)
+                dsc.pad_w_set, dsc.pad_w = 1, (cx + p - ss[0]) // 2
+                dsc.sub_grid, dsc.sub_y, dsc.sub_x = 1, cy, cx
+                dsc.f32_split = 2
+                dsc.x_planes, dsc.x_plane_stride, dsc.x_unscale = xpl
+                dsc.w_planes, dsc.w_plane_stride, dsc.w_unscale = self.h2_weight(sub, x.C, len(taps) * dy.C)
+                dsc.ws_min_tiles = self.ws_min_tiles
+                dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
+                dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
+                self.keep.append(dsc)
+                self.call(self.bwd, lib.dml_conv_igemm, C.byref(dsc))
+                descs.append(dsc)
+        x.root.grad_init = True
+        self.last_dgrad.pop(gx.ptr, None)
+        if len(descs) == 4:
+            self.last_dgrad[gx.ptr] = descs           # the four classes cover the tensor: candidates for the fused BN-backward sums
 
     def round_staged(self, x: Act):
         """fp32 staging tensor -> the bf16 gradient (a staged gradient whose last producer cannot do it itself)"""
@@ -896,9 +952,13 @@ class Plan:
         # stages, which works, but the fused sums then cost the data gradients more than the stand-alone reduce:
         # 363.5 vs 364.5 images/s).
         prod = self.last_dgrad.get(dz.ptr) if (self.fuse_bn_reduce and u.z is u.z.root) else None
+        # (a stride-2 data gradient issued as four parity-class launches: each writes the sums of its own rows, conv_dgrad_s2_classes)
+        prods = prod if isinstance(prod, list) else ([prod] if prod is not None else [])
+        prod = prods[0] if prods else None
         prows = lib.dml_conv_stat_rows(C.byref(prod)) if prod is not None else STAT_ROWS      # rows per partial of that launch
-        G = (M + prows - 1) // prows
-        fused = (prod is not None and self.dtype == torch.bfloat16 and (u.mask is not None or not u.relu)
+        Gs = [(pd.B * pd.Ho * pd.Wo + prows - 1) // prows for pd in prods] if len(prods) > 1 else [(M + prows - 1) // prows]
+        G = sum(Gs)
+        fused = (prod is not None and len(prods) == 1 and self.dtype == torch.bfloat16 and (u.mask is not None or not u.relu)
                  and u.drop is None and N % 8 == 0 and N > 32 and G <= 4096 and prod.N == N and prod.ldy == N
                  and dz.ld == N and prod.y == dz.ptr)
         # fp32 tensors: the two-plane kernel's epilogue does the same (4-channel mask bytes, 48-row groups, max |g| for dy's bound).
@@ -912,11 +972,14 @@ class Plan:
         bound_done = False
         if fused:
             part = self.fbuf(G * N * 2)
-            prod.bnr_y, prod.bnr_mask = u.y.ptr, mk
-            prod.bnr_mean, prod.bnr_invstd = u.mean.data_ptr(), u.invstd.data_ptr()
-            prod.bnr_partials, prod.bnr_ldy, prod.bnr_relu = part.data_ptr(), u.y.ld, 1 if u.relu else 0
-            if gwork is not None:
-                prod.bnr_gmax = gwork.data_ptr()
+            g0 = 0
+            for pd, gc in zip(prods, Gs):
+                pd.bnr_y, pd.bnr_mask = u.y.ptr, mk
+                pd.bnr_mean, pd.bnr_invstd = u.mean.data_ptr(), u.invstd.data_ptr()
+                pd.bnr_partials, pd.bnr_ldy, pd.bnr_relu = part.data_ptr() + g0 * N * 8, u.y.ld, 1 if u.relu else 0
+                if gwork is not None:
+                    pd.bnr_gmax = gwork.data_ptr()
+                g0 += gc
             nblk = C.c_int(G)
             self.keep.append(nblk)
             sp = part.data_ptr()
@@ -1340,6 +1403,8 @@ class Plan:
                 self.prep_table.append((raw.to(self.device), len(ent), dt))
         for tab, n, dt in self.prep_table:
             _lib.check(self.lib.dml_prep_weights(tab.data_ptr(), n, dt, stream), "dml_prep_weights")
+        for g in self.prep_gather:
+            _lib.check(self.lib.dml_gather_taps(*g, stream), "dml_gather_taps")
         if self.prep_h2:
             # fp16 planes of every weight copy (f16x2): one table, two launches
             if self.prep_h2_table is None or self.prep_h2_table[1] != len(self.prep_h2):

@@ -32,15 +32,17 @@ def test_library_exports_every_declared_symbol():
     exported = sorted({ln.split()[-1] for ln in nm.splitlines() if ln.split()[-1].startswith("dml_") and " T " in ln})
     assert exported == syms, (sorted(set(exported) - set(syms)), sorted(set(syms) - set(exported)))
     lib2 = _lib.load()
-    assert lib2.dml_abi_version() == 5
+    assert lib2.dml_abi_version() == 6
     assert lib2.dml_target_arch() == b"gfx950"
 
 
 def test_struct_layout_matches_header():
     from dmlnet._lib import ConvDesc, WgradDesc
     # 5 ptr + 18 int32 | bnr: 5 ptr + 2 int32 | post: 4 ptr + 2 int32 | tail: ptr, int64, ptr, 2 int32 | res: 2 ptr + 2 int32 |
-    # acc32: ptr + int32, f32_split, w_tiled, ws_min_tiles | planes: 4 ptr + 2 int64 | bnr_gmax
-    assert ctypes.sizeof(ConvDesc) == 336 and ConvDesc.bnr_gmax.offset == 328
+    # acc32: ptr + int32, f32_split, w_tiled, ws_min_tiles | planes: 4 ptr + 2 int64 | bnr_gmax | ABI 6: sub_grid, sub_y, sub_x, pad_w_set,
+    # pad_w, reserved
+    assert ctypes.sizeof(ConvDesc) == 360 and ConvDesc.bnr_gmax.offset == 328
+    assert ConvDesc.sub_grid.offset == 336 and ConvDesc.pad_w_set.offset == 348 and ConvDesc.pad_w.offset == 352
     assert ConvDesc.B.offset == 40 and ConvDesc.mode.offset == 40 + 17 * 4
     assert ConvDesc.bnr_y.offset == 112 and ConvDesc.bnr_ldy.offset == 152 and ConvDesc.post_scale.offset == 160
     assert ConvDesc.tail_ws.offset == 200 and ConvDesc.tail_counters_len.offset == 224

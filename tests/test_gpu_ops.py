@@ -1553,6 +1553,94 @@ def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
         assert a_ <= max(4.0 * b_, 2e-6), errs
 
 
+@pytest.mark.parametrize("case", [("s2cls_3x3", 2, 24, 20, 128, 128, 3, 1), ("s2cls_3x3_ragged", 3, 14, 10, 64, 192, 3, 1),
+                                  ("s2cls_1x1", 2, 24, 20, 128, 256, 1, 0)], ids=lambda c: c[0])
+def test_stride2_data_gradient_by_parity_class_equals_the_direct_launch(lib, case):
+    """DmlConvDesc.sub_grid (round 6): the data gradient of a stride-2 convolution as one stride-1 launch per pixel-parity class on the
+    taps that class sees (3x3: 1 / 2 / 2 / 4 taps; 1x1: the even pixels only, accumulating).  Every dX element is the same sum over
+    the same K steps in the same order as in the direct stride-2 launch (whose other taps contribute exact zeros): BIT-EQUAL, with
+    the identity / accumulate operand and with the fused BatchNorm-backward sums (their totals over all partial groups agree to
+    fp32 summation noise: the grouping of the rows differs)."""
+    from dmlnet._lib import ConvDesc
+    name, B, Hh, Ww, Cin, Cout, k, pad = case             # forward conv: x [B, Hh, Ww, Cin] -> y [B, Hh / 2, Ww / 2, Cout]
+    Ho, Wo = Hh // 2, Ww // 2
+    gy = nhwc(rnd(name + ".gy", (B, Cout, Ho, Wo)) * 1e-3, torch.float32)
+    w = rnd(name + ".w", (Cout, Cin, k, k), scale=(2.0 / (Cin * k * k)) ** 0.5)
+    wt = w.permute(1, 2, 3, 0).contiguous().cuda()           # C R S N: the data gradient's operand
+    old = nhwc(rnd(name + ".old", (B, Cin, Hh, Ww)) * 1e-3, torch.float32)       # earlier producers' sum (accumulate)
+    ybn = nhwc(rnd(name + ".ybn", (B, Cin, Hh, Ww)), torch.float32)
+    mask = torch.randint(0, 16, (B * Hh * Ww * (Cin // 4),), device="cuda", dtype=torch.uint8)
+    mean, inv = rnd(name + ".mu", (Cin,)).cuda(), (rnd(name + ".is", (Cin,)).abs() + 0.5).cuda()
+    M = B * Hh * Ww
+    yp, yw = h2_planes(lib, gy.view(-1, Cout), 0)
+    keep = []
+
+    def run(classes, accum, bnr):
+        dx = old.clone() if accum else torch.full_like(old, float("nan"))
+        G = (M + 47) // 48 + 8
+        part = torch.zeros(G * Cin * 2, device="cuda")
+        gmx = torch.zeros(1025, device="cuda")
+        descs = []
+        if not classes:
+            wp, ww = h2_planes(lib, wt.view(Cin, -1), 1)
+            d = make_desc(lib, gy, wt, dx, B, Ho, Wo, Cout, Hh, Ww, Cin, k, 2, 1, pad, 0, mode=1, accum=accum)
+            d.f32_split = 2
+            d.x_planes, d.x_unscale, d.x_plane_stride = yp.data_ptr(), yw.data_ptr() + 4096, yp.shape[1]
+            d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
+            keep.extend([wp, ww])
+            descs.append((d, (M + 47) // 48))
+        else:
+            for cy in (0, 1):
+                for cx in (0, 1):
+                    rs = [r for r in range(k) if (r - cy - pad) % 2 == 0]
+                    ss = [t for t in range(k) if (t - cx - pad) % 2 == 0]
+                    if not rs or not ss:
+                        continue
+                    taps = [r * k + t for r in rs for t in ss]
+                    sub = torch.empty(Cin * len(taps) * Cout, device="cuda")
+                    chk(lib.dml_gather_taps(wt.data_ptr(), sub.data_ptr(), Cin, k * k, Cout, len(taps), *(taps + [0] * (4 - len(taps))), st()))
+                    wp, ww = h2_planes(lib, sub.view(Cin, -1), 1)
+                    d = ConvDesc(x=gy.data_ptr(), w=sub.data_ptr(), y=dx.data_ptr(), bias=None, stats=None, B=B, Hi=Ho, Wi=Wo, C=Cout,
+                                 ldx=Cout, Ho=Ho, Wo=Wo, N=Cin, ldy=Cin, R=len(rs), S=len(ss), stride=1, dil=1,
+                                 pad=(cy + pad - rs[0]) // 2, dtype=0, y_f32=0, accum=accum, mode=1)
+                    d.pad_w_set, d.pad_w = 1, (cx + pad - ss[0]) // 2
+                    d.sub_grid, d.sub_y, d.sub_x = 1, cy, cx
+                    d.f32_split = 2
+                    d.x_planes, d.x_unscale, d.x_plane_stride = yp.data_ptr(), yw.data_ptr() + 4096, yp.shape[1]
+                    d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
+                    keep.extend([sub, wp, ww])
+                    descs.append((d, (B * Ho * Wo + 47) // 48))
+        g0 = 0
+        for d, gc in descs:
+            d.ws_min_tiles = 1
+            if bnr:
+                d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), mask.data_ptr(), mean.data_ptr(), inv.data_ptr()
+                d.bnr_partials, d.bnr_ldy, d.bnr_relu, d.bnr_gmax = part.data_ptr() + g0 * Cin * 8, Cin, 1, gmx.data_ptr()
+            g0 += gc
+            assert lib.dml_conv_stat_rows(C.byref(d)) == 48
+            chk(lib.dml_conv_igemm(C.byref(d), st()))
+        torch.cuda.synchronize()
+        return dx, part.view(-1, Cin, 2)[:g0].double().sum(0), float(gmx[:1024].max()), len(descs)
+
+    for accum, bnr in ((1, False), (1, True)) + (((0, False), (0, True)) if k == 3 else ()):
+        a, pa, ga, na = run(False, accum, bnr)
+        b, pb, gb, nb = run(True, accum, bnr)
+        assert na == 1 and nb == (4 if k == 3 else 1)
+        assert torch.equal(a, b), "%s accum=%d bnr=%d: %d of %d elements differ (max %.3e)" % (
+            name, accum, bnr, int((a != b).sum()), a.numel(), (a - b).abs().max().item())
+        if bnr and k == 3:                 # (1x1: the class launch visits a quarter of the rows -- the plan does not fuse the sums there)
+            assert ga == gb
+            assert (pa - pb).abs().max().item() <= 1e-5 * pa.abs().max().item()
+    # shapes / modes the mapping does not exist for are refused, never mis-executed
+    sub = torch.empty(Cin * Cout, device="cuda")
+    d = ConvDesc(x=gy.data_ptr(), w=sub.data_ptr(), y=old.data_ptr(), bias=None, stats=None, B=B, Hi=Ho, Wi=Wo, C=Cout, ldx=Cout, Ho=Ho,
+                 Wo=Wo, N=Cin, ldy=Cin, R=1, S=1, stride=1, dil=1, pad=0, dtype=0, y_f32=0, accum=1, mode=1)
+    d.sub_grid = 1
+    assert lib.dml_conv_igemm(C.byref(d), st()) == -3                # no planes: DML_EUNSUPPORTED
+    d.mode = 0
+    assert lib.dml_conv_igemm(C.byref(d), st()) == -1                # forward launches have no sub-grid: DML_EINVAL
+
+
 def test_planes_only_operand_is_refused_where_the_planes_kernels_cannot_take_it(lib):
     """x == x_planes (dy == dy_planes) declares an operand that exists as fp16 planes ONLY (the plan drops the fp32 copy of tensors only
     convolutions read).  A launch the planes kernels cannot take must then fail with DML_EUNSUPPORTED -- the fallback kernels would read
