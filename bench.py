@@ -161,8 +161,6 @@ def _conv_flops(d, igemm):
     if igemm and d.mode == 1:
         # data gradient: same MACs as the forward conv = dY pixels x Cout x taps x Cin
         cin = 304 if d.N == 320 else d.N
-        if d.ldy == 320 and d.N != 320 and d.R == 3:      # the decoder's data gradient issued as two column slices (256 + 64 of 320 = 304 real + 16 pad)
-            cin = 256 if d.N == 256 else 48
         return 2.0 * d.B * d.Hi * d.Wi * d.C * d.R * d.S * cin
     if d.C == 12 and d.R == 4:          # the stem in space-to-depth form (4x4 on 12 channels): the MACs of the 7x7 on 3 channels
         return 2.0 * d.B * d.Ho * d.Wo * d.N * 49 * 3
@@ -241,7 +239,7 @@ def dump_conv_table(plan, path):
 def _conv_class(d, igemm):
     """(kind, label) of one conv launch; the label is the FORWARD convolution's signature for all three kinds"""
     if igemm and d.mode == 1:          # data gradient: x = dY [Ho_fwd x Wo_fwd x Cout], result = dX
-        kind, cin, cout, hw = "dgrad", (304 if (d.N == 320 or (d.ldy == 320 and d.R == 3)) else d.N), d.C, (d.Hi, d.Wi)
+        kind, cin, cout, hw = "dgrad", (304 if d.N == 320 else d.N), d.C, (d.Hi, d.Wi)
     else:
         kind = "fwd" if igemm else "wgrad"
         cin, cout, hw = (3 if d.C == 8 else (304 if d.C == 320 else d.C)), d.N, (d.Ho, d.Wo)

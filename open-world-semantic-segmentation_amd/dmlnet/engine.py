@@ -375,7 +375,6 @@ class Plan:
         # f16x2: data gradients of the stride-2 convolutions as stride-1 launches per pixel-parity class (conv_dgrad_s2_classes).
         # DML_S2_CLASSES=0: off (A/B, tests)
         self.s2_classes_on = os.environ.get("DML_S2_CLASSES", "1") != "0"
-        self.split_n_tail = os.environ.get("DML_SPLIT_N_TAIL", "1") != "0"      # conv_dgrad: 256 k + 64 columns as two launches (A/B)
         self.prep_gather = []          # dml_gather_taps argument lists: sub-filters of the transposed weight copies, refreshed with them
         self._bound_words, self._bound_used = None, 0
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
@@ -664,26 +663,11 @@ class Plan:
         dsc.tail_ws, dsc.tail_ws_elems = self.tail_ws.data_ptr(), self.tail_ws.numel()
         dsc.tail_counters, dsc.tail_counters_len = self.tail_cnt.data_ptr(), self.tail_cnt.numel()
         self.keep.append(dsc)
-        # f16x2, 256 k + 64 output columns (the decoder's 3x3: 320): the two-plane kernel would run them as 128-wide column blocks with
-        # the last one half empty (384 columns of MFMA work for 320).  Two launches instead: 256 k columns on 144 x 256 tiles and the
-        # last 64 on the 192 x 64 configuration -- column slices of the same output, row blocks of the same tile-major weight planes.
-        tail = None
-        if (self.split_n_tail and dsc.f32_split == 2 and x.C > 256 and x.C % 256 == 64 and g32 is None and res is None
-                and gx.ld % 4 == 0):
-            K, n0 = kh * kw * dy.C, x.C - 64
-            tail = ConvDesc.from_buffer_copy(dsc)
-            tail.y, tail.N = gx.ptr + n0 * 4, 64
-            tail.w = wt.data_ptr() + n0 * K * 4
-            tail.w_planes = dsc.w_planes + (n0 // 64) * (K // 32) * 2048 * 2
-            dsc.N = n0
-            self.keep.append(tail)
         self.call(self.bwd, self.lib.dml_conv_igemm, C.byref(dsc))
-        if tail is not None:
-            self.call(self.bwd, self.lib.dml_conv_igemm, C.byref(tail))
         if convert:
             self.round_staged(x)
         self.last_dgrad.pop(self.grad_of(x.root).ptr, None)
-        if x is x.root and g32 is None and tail is None:
+        if x is x.root and g32 is None:
             self.last_dgrad[gx.ptr] = dsc         # whole-tensor gradient: candidate for the fused BN-backward reduce
 
     # ---- data gradient of a stride-2 convolution as one stride-1 launch per pixel-parity class (DmlConvDesc.sub_grid)
