@@ -601,6 +601,12 @@ int dml_plan_fn_id(const char* name);
 int dml_plan_fn_nargs(int fn);
 int dml_plan_run(const DmlPlanOp* ops, int first, int last, void* stream, void* side_stream, void* const* events,
                  int n_events, int* failed_op);
+/* dml_plan_run with MARKS: after op marks[k] (ascending op indices; those outside [first, last) are ignored) mark_events[2 k] is
+ * recorded on `stream` and, with a side stream, mark_events[2 k + 1] on `side_stream` (hipEvent_t handles).  Replaces the reference's
+ * per-step nn.DataParallel reduce (main_embedding.py:425,438-439) together with dmlnet/parallel.py: the reducer's communication stream
+ * waits on these events, so the host enqueues the whole backward in one call. */
+int dml_plan_run_marks(const DmlPlanOp* ops, int first, int last, void* stream, void* side_stream, void* const* events,
+                       int n_events, const int32_t* marks, int n_marks, void* const* mark_events, int* failed_op);
 
 #ifdef __cplusplus
 }

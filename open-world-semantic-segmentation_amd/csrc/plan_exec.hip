@@ -129,12 +129,37 @@ extern "C" int dml_plan_fn_id(const char* name) {
 
 extern "C" int dml_plan_fn_nargs(int fn) { return (fn >= 0 && fn < kNumEntries) ? kEntries[fn].nargs : DML_EINVAL; }
 
+namespace {
+int plan_run(const DmlPlanOp* ops, int first, int last, void* stream, void* side_stream, void* const* events, int n_events,
+             const int32_t* marks, int n_marks, void* const* mark_events, int* failed_op);
+}
+
 extern "C" int dml_plan_run(const DmlPlanOp* ops, int first, int last, void* stream, void* side_stream,
                             void* const* events, int n_events, int* failed_op) {
+    return plan_run(ops, first, last, stream, side_stream, events, n_events, nullptr, 0, nullptr, failed_op);
+}
+
+// dml_plan_run + MARKS: after op marks[k] (ascending op indices; those outside [first, last) are ignored) has been issued,
+// mark_events[2 k] is recorded on `stream` and -- with a side stream -- mark_events[2 k + 1] on `side_stream`.  The data-parallel
+// reducer (dmlnet/parallel.py) lets its communication stream wait on them: the gradient buckets' all-reduces start at the same
+// points of the backward as before, but the host walks the whole launch list in ONE call instead of returning to Python per bucket.
+extern "C" int dml_plan_run_marks(const DmlPlanOp* ops, int first, int last, void* stream, void* side_stream,
+                                  void* const* events, int n_events, const int32_t* marks, int n_marks,
+                                  void* const* mark_events, int* failed_op) {
+    if (n_marks < 0 || (n_marks > 0 && (!marks || !mark_events))) return DML_EINVAL;
+    for (int k = 1; k < n_marks; ++k)
+        if (marks[k] <= marks[k - 1]) return DML_EINVAL;
+    return plan_run(ops, first, last, stream, side_stream, events, n_events, marks, n_marks, mark_events, failed_op);
+}
+
+namespace {
+int plan_run(const DmlPlanOp* ops, int first, int last, void* stream, void* side_stream, void* const* events, int n_events,
+             const int32_t* marks, int n_marks, void* const* mark_events, int* failed_op) {
     if (!ops || first < 0 || last < first) return DML_EINVAL;
     hipStream_t main_st = static_cast<hipStream_t>(stream);
     hipStream_t side_st = static_cast<hipStream_t>(side_stream);
-    int ev = 0;
+    int ev = 0, mk = 0;
+    while (mk < n_marks && marks[mk] < first) ++mk;
     for (int i = first; i < last; ++i) {
         const DmlPlanOp& op = ops[i];
         if (op.fn < 0 || op.fn >= kNumEntries || op.nargs != kEntries[op.fn].nargs || op.nargs > DML_PLAN_MAX_ARGS) {
@@ -175,6 +200,16 @@ extern "C" int dml_plan_run(const DmlPlanOp* ops, int first, int last, void* str
             if (failed_op) *failed_op = i;
             return rc;
         }
+        if (mk < n_marks && marks[mk] == i) {
+            hipError_t e = hipEventRecord(static_cast<hipEvent_t>(mark_events[2 * mk]), main_st);
+            if (e == hipSuccess && side_st != nullptr) e = hipEventRecord(static_cast<hipEvent_t>(mark_events[2 * mk + 1]), side_st);
+            if (e != hipSuccess) {
+                if (failed_op) *failed_op = i;
+                return (int)e;
+            }
+            ++mk;
+        }
     }
     return 0;
 }
+}  // namespace

@@ -178,6 +178,7 @@ _PROTOS = {
     "dml_plan_fn_id": (c_i, [C.c_char_p]),
     "dml_plan_fn_nargs": (c_i, [c_i]),
     "dml_plan_run": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, C.POINTER(c_i)]),
+    "dml_plan_run_marks": (c_i, [c_p, c_i, c_i, c_p, c_p, c_p, c_i, c_p, c_i, c_p, C.POINTER(c_i)]),
 }
 
 EXPORTS = tuple(_PROTOS.keys())

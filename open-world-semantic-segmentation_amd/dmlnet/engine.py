@@ -145,8 +145,12 @@ class NativeList:
         self.failed = C.c_int(-1)
         self.on_error = None
 
-    def run(self, first, last, stream, side_stream=None, events=None, n_events=0):
-        rc = self.lib.dml_plan_run(self.arr, first, last, stream, side_stream, events, n_events, C.byref(self.failed))
+    def run(self, first, last, stream, side_stream=None, events=None, n_events=0, marks=None):
+        if marks is not None:      # (marks, count, event handles): dml_plan_run_marks records an event pair after each marked op
+            rc = self.lib.dml_plan_run_marks(self.arr, first, last, stream, side_stream, events, n_events, marks[0], marks[1], marks[2],
+                                             C.byref(self.failed))
+        else:
+            rc = self.lib.dml_plan_run(self.arr, first, last, stream, side_stream, events, n_events, C.byref(self.failed))
         if rc:
             if self.on_error is not None:
                 self.on_error()
@@ -1438,6 +1442,18 @@ class Plan:
             self._ev_handles = (C.c_void_p * len(self._ev_objs))(*[e.cuda_event for e in self._ev_objs])
         return self._ev_handles
 
+    def _mark_events(self, n):
+        """n (main, side) event pairs for the deferred hooks of _exec, instantiated once"""
+        evs = getattr(self, "_mark_ev", [])
+        cur = torch.cuda.current_stream(self.device)
+        while len(evs) < n:
+            pair = (torch.cuda.Event(), torch.cuda.Event())
+            for e in pair:
+                e.record(cur)                       # instantiates the hipEvent_t
+            evs.append(pair)
+        self._mark_ev = evs
+        return evs[:n]
+
     def _exec(self, ops, stream, start=0, stop=None, hook=None, skip_ranges=(), side_stream=None):
         """Issue ops[start:stop] in order.  Native segments run through dml_plan_run; Python steps (collectives), skipped
         ranges and the hook points (hook.points: op indices after which hook(i) must run -- the gradient buckets of the
@@ -1454,6 +1470,21 @@ class Plan:
         points = getattr(hook, "points", None) if hook is not None else ()
         if hook is not None and points is None:
             points = range(start, stop)              # a hook without declared points wants every op
+        # A DEFERRED hook (hook.deferred: the data-parallel reducer) only enqueues work on another stream that has to wait for this
+        # point of the list: the native replay records an event pair (main / side stream) after each of its ops (dml_plan_run_marks)
+        # and the hook runs once the whole list has been enqueued, hook(op, main event, side event) -- one return to Python per
+        # backward instead of one per gradient bucket.
+        deferred = hook is not None and getattr(hook, "deferred", False) and points is not None
+        marks, mark_ops, mark_evs = None, [], []
+        if deferred:
+            mark_ops = sorted(k for k in points if start <= k < stop)
+            mark_evs = self._mark_events(len(mark_ops))
+            if mark_ops:
+                arr = (C.c_int32 * len(mark_ops))(*mark_ops)
+                hnd = (C.c_void_p * (2 * len(mark_ops)))(*[e.cuda_event for pair in mark_evs for e in pair])
+                marks = (arr, len(mark_ops), hnd)
+                self.keep_marks = (arr, hnd)
+            points = ()
         cuts = set(nat.python_ops)
         cuts.update(points)
         skips = sorted((max(lo, start), min(hi, stop)) for (lo, hi) in skip_ranges if lo < stop and hi > start)
@@ -1467,6 +1498,11 @@ class Plan:
                 si += 1
             if si < len(skips) and skips[si][0] <= i:      # inside a skipped range: only the hook points fire
                 hi = skips[si][1]
+                for k, (em, es) in zip(mark_ops, mark_evs):      # (deferred hooks: their events, recorded here)
+                    if i <= k < hi:
+                        em.record(torch.cuda.current_stream(self.device))
+                        if side_stream is not None:
+                            es.record(self.e.side_stream(self.device))
                 if hook is not None:
                     for k in order:
                         if i <= k < hi and k in points:
@@ -1480,17 +1516,24 @@ class Plan:
                 k = order[ci]
                 if k in nat.python_ops:
                     if k > i:
-                        nat.run(i, k, stream, side_stream, events, n_ev)
+                        nat.run(i, k, stream, side_stream, events, n_ev, marks)
                     fn, args = ops[k]
                     fn(*args, stream)
+                    if k in mark_ops:                # (a Python step that is a mark itself)
+                        em, es = mark_evs[mark_ops.index(k)]
+                        em.record(torch.cuda.current_stream(self.device))
+                        if side_stream is not None:
+                            es.record(self.e.side_stream(self.device))
                 else:
-                    nat.run(i, k + 1, stream, side_stream, events, n_ev)
+                    nat.run(i, k + 1, stream, side_stream, events, n_ev, marks)
                 if hook is not None and k in points:
                     hook(k)
                 i = k + 1
             else:
-                nat.run(i, end, stream, side_stream, events, n_ev)
+                nat.run(i, end, stream, side_stream, events, n_ev, marks)
                 i = end
+        for k, (em, es) in zip(mark_ops, mark_evs):
+            hook(k, em, es if side_stream is not None else None)
 
     def run_backward(self, hook=None):
         """Replay the backward plan: weight gradients on the engine's side stream, everything else on the

@@ -80,19 +80,29 @@ class GradReducer:
         cur = torch.cuda.current_stream(dev)
         flat_g = self.store.flat_g
 
-        def hook(i):
-            for b in sched.get(i, ()):
-                lo, hi, _ = self.buckets[b]
+        def hook(i, ev_main=None, ev_side=None):
+            # the communication stream picks up the backward at bucket point i: through the event pair the native replay recorded
+            # there (deferred: the whole backward has been enqueued by now), else through the streams' present tails
+            if ev_main is not None:
+                self.comm_stream.wait_event(ev_main)
+                if ev_side is not None:
+                    self.comm_stream.wait_event(ev_side)                       # weight gradients run on the side stream
+            else:
                 self.comm_stream.wait_stream(cur)
                 if plan.e.overlap_wgrad:
-                    self.comm_stream.wait_stream(plan.e.side_stream(dev))      # weight gradients run there
-                with torch.cuda.stream(self.comm_stream):
+                    self.comm_stream.wait_stream(plan.e.side_stream(dev))
+            with torch.cuda.stream(self.comm_stream):
+                for b in sched.get(i, ()):
+                    lo, hi, _ = self.buckets[b]
                     seg = flat_g[lo:hi]
                     dist.all_reduce(seg, group=self.group)
                     if self.average:
                         seg.div_(self.world)
 
-        hook.points = set(sched.keys())      # the native replay returns to Python only after these ops
+        hook.points = set(sched.keys())      # the bucket points: op indices after which a bucket's gradients are complete
+        # one return to Python per backward instead of one per bucket (dml_plan_run_marks).  DML_REDUCER_DEFERRED=0: the hook runs
+        # at each point, between two native segments (A/B; the Python replay always does)
+        hook.deferred = os.environ.get("DML_REDUCER_DEFERRED", "1") != "0"
         plan.run_backward(hook=hook)
         cur.wait_stream(self.comm_stream)
 
