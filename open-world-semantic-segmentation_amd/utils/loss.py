@@ -18,6 +18,19 @@ def _stream(t):
     return torch.cuda.current_stream(t.device).cuda_stream
 
 
+_COUNTS = {}
+
+
+def _image_count(device, n):
+    """a cached one-element fp64 device tensor holding `n` (device-to-device copies never wait for the stream)"""
+    key = (str(device), int(n))
+    t = _COUNTS.get(key)
+    if t is None:
+        t = torch.full((1,), float(n), dtype=torch.float64, device=device)
+        _COUNTS[key] = t
+    return t
+
+
 class _DMLLossFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logit, target, alpha, ignore_index, group, fused=False):
@@ -40,7 +53,9 @@ class _DMLLossFn(torch.autograd.Function):
             # the reference normalises by the size of the gathered batch (utils/loss.py:38-41 on DataParallel's
             # gather); shards may be uneven (parallel.shard_range spreads a remainder), so the image count travels
             # with the sums (sums[4], read by the kernels on the device: no host sync) instead of assuming B * world
-            sums[4] = float(B)
+            # (not `sums[4] = float(B)`: assigning a Python scalar to a CUDA element copies from pageable host memory and BLOCKS the
+            # host until the stream has drained -- the whole forward, 26 ms per step at 16 x 768 x 768 -- tools/probe_allreduce_host_block.py)
+            sums[4:5].copy_(_image_count(logit.device, B), non_blocking=True)
             dist.all_reduce(sums, group=group if group is not True else None)
             n_images = 0.0
         loss = torch.empty((), dtype=torch.float32, device=logit.device)
