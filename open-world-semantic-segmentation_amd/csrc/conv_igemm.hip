@@ -3788,7 +3788,12 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // (r04: 0.16-0.17 of the class's own bound).  Same box, old -> new: 3x3 64 -> 64 at 192 x 192 forward 347 -> 286 us, 1x1
             // 256 -> 64 244 -> 185, 1x1 128 -> 64 190 -> 132; whole step +0.8 % (profiles/r05_ab_n64.txt)
             const bool n64 = a.N == 64;
-            const int bm = wide ? 144 : (n64 ? 192 : 288);
+            // Forward launches that leave most of the chip empty on 144-row tiles (batch-1 inference at 1024 x 2048: 57 row blocks on
+            // layer3 / layer4 / ASPP; the small maps of the tests): 48 x 256 tiles -- three times the workgroups, each with a third
+            // of the MFMAs per K step behind the same weight pieces.  (Round 6; 1024 x 2048 batch 1: see profiles/r06_infer_short_tiles.txt)
+            static const int short_on = getenv("DML_WS_SHORT") ? atoi(getenv("DML_WS_SHORT")) : 1;
+            const bool shortm = MODE == 0 && short_on != 0 && wide && ((a.M + 143) / 144) * (a.N / 256) * 2 <= CUS;
+            const int bm = wide ? (shortm ? 48 : 144) : (n64 ? 192 : 288);
             a.nblk_m = (a.M + bm - 1) / bm;
             a.nblk_n = wide ? a.N / 256 : (n64 ? 1 : (a.N + 127) / 128);      // (a last 128-wide block may be half empty: zero rows, no stores)
             const int ntiles = a.nblk_m * a.nblk_n;
@@ -3812,7 +3817,10 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
                 constexpr int EPI = decltype(epi_c)::value;
                 if (half)
                     hipLaunchKernelGGL((conv_ws_half_kernel<MODE, EPI>), dim3(half_tiles < 2 * CUS ? half_tiles : 2 * CUS), dim3(256), 0, st, a, xpb, wpb);
-                else if (n64)
+                else if (shortm) {
+                    if constexpr (MODE == 0 && EPI == 0)
+                        hipLaunchKernelGGL((conv_ws_kernel<1, 4, 0, NLD, 2, 3, 0>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
+                } else if (n64)
                     hipLaunchKernelGGL((conv_ws_kernel<4, 1, MODE, NLD, 2, 3, EPI>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
                 else if (wide)
                     hipLaunchKernelGGL((conv_ws_kernel<1, 4, MODE, NLD, 2, WS_MT, EPI>), dim3(grid), dim3((4 + NLD) * 64), 0, st, a, xpb, wpb);
