@@ -204,13 +204,21 @@ def test_bench_script_default_path_small():
     assert d["roofline"]["bound"] == "mfma" and d["roofline"]["achieved"] > 0 and d["value"] > 0
     # the headline is the fp32-accurate mode (fp32 tensors, two-term fp16 split of the conv products); bf16 storage, the exact
     # fp32 MFMA and the three-term split ride along as companions
-    assert d["dtype"] == "f32" and "two-term" in d["config"]["arithmetic"]
+    # (the line says so: dtype "f16x2", never "f32", and the exact-fp32 mode's rate is a first-class field next to `value`)
+    assert d["dtype"] == "f16x2" and "two-term" in d["config"]["arithmetic"]
+    assert d["value_fp32_exact"] == d["fp32_exact_companion"]["value"] and d["fp32_exact_companion"]["dtype"] == "f32"
     assert d["bf16_companion"]["value"] > 0 and d["bf16_companion"]["roofline"]["achieved"] > 0
     assert d["fp32_exact_companion"]["value"] > 0 and d["fp32_exact_companion"]["three_term_split"]["value"] > 0
     r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--mode", "infer", "--height", "128", "--width",
                         "256", "--steps", "2", "--warmup", "1"], capture_output=True, text=True, cwd=H.ROOT, timeout=900)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
-    assert json.loads(r.stdout.strip().splitlines()[-1])["value"] > 0
+    di = json.loads(r.stdout.strip().splitlines()[-1])
+    assert di["value"] > 0 and di["dtype"] == "f16x2" and di["roofline"]["achieved"] > 0
+    r = subprocess.run([sys.executable, os.path.join(H.ROOT, "bench.py"), "--mode", "fwd", "--size", "128", "--batch", "2", "--dtype", "bf16",
+                        "--steps", "2", "--warmup", "1"], capture_output=True, text=True, cwd=H.ROOT, timeout=900)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-3000:]
+    df = json.loads(r.stdout.strip().splitlines()[-1])
+    assert df["value"] > 0 and df["dtype"] == "bf16" and "forward-only" in df["metric"]
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "f16x2"])
