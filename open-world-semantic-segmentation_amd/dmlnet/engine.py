@@ -379,6 +379,7 @@ class Plan:
         # f16x2: data gradients of the stride-2 convolutions as stride-1 launches per pixel-parity class (conv_dgrad_s2_classes).
         # DML_S2_CLASSES=0: off (A/B, tests)
         self.s2_classes_on = os.environ.get("DML_S2_CLASSES", "1") != "0"
+        self.ds_grad_from_dz = os.environ.get("DML_DS_GRAD_FROM_DZ", "1") != "0"      # block_bwd (A/B)
         self.prep_gather = []          # dml_gather_taps argument lists: sub-filters of the transposed weight copies, refreshed with them
         self._bound_words, self._bound_used = None, 0
         # bf16 plans, DML_GRAD_STAGE32=1: a gradient with several producers is summed in fp32 and rounded ONCE by its last
@@ -924,11 +925,14 @@ class Plan:
         self.units.append(u)
         return u
 
-    def unit_bwd(self, u: ConvUnit, dz: Act, dres: Optional[Act] = None, dres_accum=False, need_dgrad=True, final=True):
-        """Backward of `cbr`: BN (two passes) -> weight gradient -> data gradient into u.x.grad (`final`: conv_dgrad)."""
+    def unit_bwd(self, u: ConvUnit, dz: Act, dres: Optional[Act] = None, dres_accum=False, need_dgrad=True, final=True,
+                 up_mask=None):
+        """Backward of `cbr`: BN (two passes) -> weight gradient -> data gradient into u.x.grad (`final`: conv_dgrad).
+        up_mask: `dz` is the gradient of a LATER ReLU's output and `up_mask` that ReLU's 1-bit mask -- this unit's own output gradient
+        is dz (.) mask, formed on the fly by the two BN passes (block_bwd: the downsample branch reads the block output's gradient)."""
         if u.dtype != self.dtype:
             with self.precision(u.dtype):
-                return self.unit_bwd(u, dz, dres, dres_accum, need_dgrad, final)
+                return self.unit_bwd(u, dz, dres, dres_accum, need_dgrad, final, up_mask)
         lib, st = self.lib, self.e.store
         N, M = u.conv.out_channels, u.y.M
         bn = u.bn
@@ -950,12 +954,16 @@ class Plan:
         nblk = C.c_int(0)
         self.keep.append(nblk)
         mk = u.mask.data_ptr() if u.mask is not None else None
+        relu_eff = u.relu
+        if up_mask is not None:
+            assert not u.relu and u.drop is None and dres is None
+            mk, relu_eff = up_mask.data_ptr(), True
         # The data gradient that wrote dz last can emit this BN's backward sums from its epilogue (DmlConvDesc.bnr_*):
         # one pass over dz / y / mask less.  Conditions: it wrote the whole tensor, bf16 with the 1-bit ReLU mask,
         # no dropout scale, at most 4096 row groups (on the 192 x 192 layers the finalize would fold 9216 groups in two
         # stages, which works, but the fused sums then cost the data gradients more than the stand-alone reduce:
         # 363.5 vs 364.5 images/s).
-        prod = self.last_dgrad.get(dz.ptr) if (self.fuse_bn_reduce and u.z is u.z.root) else None
+        prod = self.last_dgrad.get(dz.ptr) if (self.fuse_bn_reduce and u.z is u.z.root and up_mask is None) else None
         # (a stride-2 data gradient issued as four parity-class launches: each writes the sums of its own rows, conv_dgrad_s2_classes)
         prods = prod if isinstance(prod, list) else ([prod] if prod is not None else [])
         prod = prods[0] if prods else None
@@ -990,7 +998,7 @@ class Plan:
         else:
             sp = self.sp
             a1 = self.call(self.bwd, lib.dml_bn_bwd_reduce, dz.ptr, u.y.ptr, u.z.ptr, mk, u.mean.data_ptr(),
-                           u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if u.relu else 0, 1.0,
+                           u.invstd.data_ptr(), self.sp, M, N, dz.ld, u.y.ld, u.z.ld, 1 if relu_eff else 0, 1.0,
                            self.dt, C.byref(nblk), gwork.data_ptr() if gwork is not None else None)
         if self.sync and not u.frozen:
             sums = self.dbuf(N * 2)
@@ -1022,7 +1030,7 @@ class Plan:
             pl = (planes.data_ptr(), M * N, N, work.data_ptr() + 4096)
         a3 = self.call(self.bwd, lib.dml_bn_bwd_apply, dz.ptr, u.y.ptr, u.z.ptr, mk, coef.data_ptr(),
                        None if only else dy.ptr, dres.ptr if dres is not None else None, M, N, dz.ld, u.y.ld, u.z.ld, dy.ld,
-                       dres.ld if dres is not None else 0, 1 if u.relu else 0, 1.0,
+                       dres.ld if dres is not None else 0, 1 if relu_eff else 0, 1.0,
                        1 if dres_accum else 0, self.dt, None if dy_direct else self.amax_of(dy), *pl)
         u.gscale_slots += ([(a1, 13)] if a1 is not None else []) + [(a3, 15)]
         if dres is not None:
@@ -1052,10 +1060,19 @@ class Plan:
         """backward of block_fwd: consumes d(block output), produces d(block input)"""
         xb, u1, u2, u3, ud = rec
         dz = self.grad_of(u3.z)
+        ud_from_dz = False
         if ud is not None:
-            dres = self.grad_of(ud.z)
-            self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
-            ud.z.grad_init = True
+            # The downsample branch's output gradient is the block output's gradient under the block's ReLU mask.  Instead of having
+            # bn3's backward apply write that copy (4 bytes per element of the block output: 1.4 GB per step over the four blocks) the
+            # branch's BN backward reads dz and the mask itself (unit_bwd, up_mask)
+            ud_from_dz = (self.ds_grad_from_dz and u3.relu and u3.mask is not None and u3.drop is None and not ud.relu
+                          and ud.drop is None and ud.z is ud.z.root and ud.conv.out_channels == u3.conv.out_channels)
+            if ud_from_dz:
+                self.unit_bwd(u3, dz, dres=None)
+            else:
+                dres = self.grad_of(ud.z)
+                self.unit_bwd(u3, dz, dres=dres, dres_accum=False)
+                ud.z.grad_init = True
         elif (self.fuse_res_grad and not xb.root.grad_init and xb is xb.root
               and u3.relu and u3.mask is not None and u3.drop is None and xb.C % 8 == 0 and xb.C > 32
               and dz.ld == xb.C and self.conv_geom(u1.conv, xb)[:3] == (1, 1, 1)
@@ -1080,7 +1097,10 @@ class Plan:
         self.unit_bwd(u1, self.grad_of(u1.z), final=ud is None)
         assert not self.res_src, "conv1's data gradient did not take the identity-branch gradient"
         if ud is not None:
-            self.unit_bwd(ud, self.grad_of(ud.z))
+            if ud_from_dz:
+                self.unit_bwd(ud, dz, up_mask=u3.mask)
+            else:
+                self.unit_bwd(ud, self.grad_of(ud.z))
 
     # ---- the network -------------------------------------------------------------------------
     def build(self):
