@@ -385,6 +385,11 @@ typedef struct DmlH2BoundDesc {
     int32_t reserved;
 } DmlH2BoundDesc;
 int dml_h2_bound_bn_table(const DmlH2BoundDesc* table_device, int count, void* stream);
+/* ONE scale for a tensor that several batch-statistics BatchNorms write channel slices of (directly, or through a bilinear resize,
+ * which keeps the bound): work[1024] = 1 / s from the LARGEST of the `count` entries' bounds (their own `work` fields are ignored).
+ * The decoder's concat buffer of network/utils.py:28-32 (low-level projection + upsampled ASPP projection) then exists as fp16 planes
+ * only: no dml_h2_split pass (an amax pass + a split pass over 755 MB at 16 x 768 x 768). */
+int dml_h2_bound_bn_multi(const DmlH2BoundDesc* table_device, int count, float* work, void* stream);
 
 /* ------------------------------------------------------------------------------------------------
  * Pooling (network/backbone/resnet.py:143; network/utils.py:320,326-329).
@@ -417,6 +422,10 @@ int dml_avgpool_bwd_set(const void* dv, void* dx, int B, int HW, int C, int lddx
  * ---------------------------------------------------------------------------------------------- */
 int dml_bilinear_fwd(const void* x, void* y, int B, int h, int w, int H, int W, int C, int ldx, int ldy,
                      int dtype, int in_f32, int out_f32, void* stream);
+/* dml_bilinear_fwd of an fp32 tensor with the result as the two fp16 planes of the scaled value (hi at `planes`, lo `plane_stride`
+ * elements further, pitch ldp, scale = 1 / unscale[0]: dml_h2_split's arithmetic on the value dml_bilinear_fwd would store). */
+int dml_bilinear_fwd_planes(const float* x, void* planes, int64_t plane_stride, int ldp, const float* unscale, int B, int h, int w, int H,
+                            int W, int C, int ldx, void* stream);
 int dml_bilinear_bwd(const void* dy, void* dx, int B, int h, int w, int H, int W, int C, int lddy,
                      int lddx, int dtype, int in_f32, int out_f32, void* stream);
 

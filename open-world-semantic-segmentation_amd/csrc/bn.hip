@@ -1273,6 +1273,37 @@ __global__ __launch_bounds__(256) void h2_bound_table_kernel(const DmlH2BoundDes
 }
 }  // namespace
 
+// ONE scale for a tensor several BatchNorms write channel slices of (the decoder's concat buffer: low-level projection + upsampled
+// ASPP projection): the largest of their bounds.  (A bilinear resize of a bounded tensor is bounded by the same value: its weights are
+// non-negative and sum to one.)
+namespace {
+__global__ __launch_bounds__(256) void h2_bound_multi_kernel(const DmlH2BoundDesc* __restrict__ table, int count, float* __restrict__ work) {
+    __shared__ float sh[4];
+    float b = 0.f;
+    for (int e = 0; e < count; ++e) {
+        const DmlH2BoundDesc d = table[e];
+        float be = 0.f;
+        for (int n = threadIdx.x; n < d.N; n += 256)
+            be = fmaxf(be, fabsf(d.gamma ? d.gamma[n] : 1.f) * d.root_count + fabsf(d.beta ? d.beta[n] : 0.f));
+        b = fmaxf(b, be * d.mult);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) b = fmaxf(b, __shfl_xor(b, o, 64));
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = b;
+    __syncthreads();
+    if (threadIdx.x != 0) return;
+    b = fmaxf(fmaxf(sh[0], sh[1]), fmaxf(sh[2], sh[3]));
+    work[1024] = 1.0f / h2_scale_of_bound(b);
+}
+}  // namespace
+
+extern "C" int dml_h2_bound_bn_multi(const DmlH2BoundDesc* table_device, int count, float* work, void* stream) {
+    if (!table_device || count <= 0 || !work) return DML_EINVAL;
+    hipLaunchKernelGGL(h2_bound_multi_kernel, dim3(1), dim3(256), 0, static_cast<hipStream_t>(stream), table_device, count, work);
+    DML_LAUNCH_CHECK();
+    return 0;
+}
+
 extern "C" int dml_h2_bound_bn_table(const DmlH2BoundDesc* table_device, int count, void* stream) {
     if (count == 0) return 0;
     if (!table_device || count < 0) return DML_EINVAL;

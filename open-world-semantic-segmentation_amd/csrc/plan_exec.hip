@@ -113,6 +113,8 @@ const Entry kEntries[] = {
     DML_ENTRY(dml_h2_bound_bn),
     DML_ENTRY(dml_h2_bound_bn_bwd),
     DML_ENTRY(dml_h2_bound_bn_table),
+    DML_ENTRY(dml_h2_bound_bn_multi),
+    DML_ENTRY(dml_bilinear_fwd_planes),
     DML_ENTRY(dml_bn_finalize_bound),
     DML_ENTRY(dml_bn_bwd_finalize_bound),
 };

@@ -228,6 +228,45 @@ __global__ __launch_bounds__(256) void bilinear_fwd_kernel(const TI* __restrict_
     }
 }
 
+// The same resize with the result written as the two fp16 planes of the power-of-two-scaled value (dml_h2_split's arithmetic, as the
+// BatchNorm apply kernels write them): the decoder's concat buffer exists as planes only in an f16x2 training plan
+__global__ __launch_bounds__(256) void bilinear_fwd_planes_kernel(const float* __restrict__ x, _Float16* __restrict__ planes,
+                                                                  int64_t plane_stride, int ldp, const float* __restrict__ unscale, int B,
+                                                                  int h, int w, int H, int W, int C, int ldx, float sy, float sx) {
+    typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+    const int CV = C / 4;
+    const float s = 1.0f / unscale[0];                 // exact: a power of two
+    const int64_t total = (int64_t)B * H * W * CV;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % CV);
+        int64_t p = i / CV;
+        const int X = (int)(p % W); p /= W;
+        const int Y = (int)(p % H);
+        const int b = (int)(p / H);
+        const Lerp ly = src_index(Y, sy, h), lx = src_index(X, sx, w);
+        const float* base = x + (int64_t)b * h * w * ldx + cv * 4;
+        const float4 v00 = *reinterpret_cast<const float4*>(base + ((int64_t)ly.i0 * w + lx.i0) * ldx);
+        const float4 v01 = *reinterpret_cast<const float4*>(base + ((int64_t)ly.i0 * w + lx.i1) * ldx);
+        const float4 v10 = *reinterpret_cast<const float4*>(base + ((int64_t)ly.i1 * w + lx.i0) * ldx);
+        const float4 v11 = *reinterpret_cast<const float4*>(base + ((int64_t)ly.i1 * w + lx.i1) * ldx);
+        const float a00[4] = {v00.x, v00.y, v00.z, v00.w}, a01[4] = {v01.x, v01.y, v01.z, v01.w};
+        const float a10[4] = {v10.x, v10.y, v10.z, v10.w}, a11[4] = {v11.x, v11.y, v11.z, v11.w};
+        h4 hi, lo;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            // (the expression of bilinear_fwd_kernel: the same value bit for bit)
+            const float o = ly.l0 * (lx.l0 * a00[q] + lx.l1 * a01[q]) + ly.l1 * (lx.l0 * a10[q] + lx.l1 * a11[q]);
+            const float xs = o * s;
+            const _Float16 hh = (_Float16)xs;
+            hi[q] = hh;
+            lo[q] = (_Float16)(xs - (float)hh);
+        }
+        _Float16* yp = planes + (((int64_t)b * H + Y) * W + X) * ldp + cv * 4;
+        *reinterpret_cast<h4*>(yp) = hi;
+        *reinterpret_cast<h4*>(yp + plane_stride) = lo;
+    }
+}
+
 // gather form of the transpose: every source pixel sums the destination pixels that read it
 template <typename TI, typename TO>
 __global__ __launch_bounds__(256) void bilinear_bwd_kernel(const TI* __restrict__ dy, TO* __restrict__ dx, int B,
@@ -548,6 +587,19 @@ static int launch_bilinear(const void* src, void* dst, int B, int h, int w, int 
 extern "C" int dml_bilinear_fwd(const void* x, void* y, int B, int h, int w, int H, int W, int C, int ldx, int ldy,
                                 int dtype, int in_f32, int out_f32, void* stream) {
     return launch_bilinear<false>(x, y, B, h, w, H, W, C, ldx, ldy, dtype, in_f32, out_f32, stream);
+}
+extern "C" int dml_bilinear_fwd_planes(const float* x, void* planes, int64_t plane_stride, int ldp, const float* unscale, int B, int h,
+                                       int w, int H, int W, int C, int ldx, void* stream) {
+    if (!x || !planes || !unscale || B <= 0 || h <= 0 || w <= 0 || H <= 0 || W <= 0 || C <= 0 || plane_stride <= 0) return DML_EINVAL;
+    if ((C & 3) || (ldx & 3) || (ldp & 3) || (plane_stride & 3) || ldp < C || ldx < C || (reinterpret_cast<uintptr_t>(x) & 15) ||
+        (reinterpret_cast<uintptr_t>(planes) & 7))
+        return DML_EALIGN;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(bilinear_fwd_planes_kernel, dim3(grid_for(total, 256, 256 * 32)), dim3(256), 0, static_cast<hipStream_t>(stream), x,
+                       static_cast<_Float16*>(planes), plane_stride, ldp, unscale, B, h, w, H, W, C, ldx, sy, sx);
+    DML_LAUNCH_CHECK();
+    return 0;
 }
 extern "C" int dml_bilinear_bwd(const void* dy, void* dx, int B, int h, int w, int H, int W, int C, int lddy,
                                 int lddx, int dtype, int in_f32, int out_f32, void* stream) {

@@ -133,6 +133,8 @@ _PROTOS = {
                                c_i, c_i, c_p, c_p, c_i64, c_i, c_p, c_p]),
     "dml_h2_bound_bn": (c_i, [c_p, c_p, c_i, c_i64, c_f, c_p, c_p, c_p]),
     "dml_h2_bound_bn_table": (c_i, [c_p, c_i, c_p]),
+    "dml_h2_bound_bn_multi": (c_i, [c_p, c_i, c_p, c_p]),
+    "dml_bilinear_fwd_planes": (c_i, [c_p, c_p, c_i64, c_i, c_p, c_i, c_i, c_i, c_i, c_i, c_i, c_i, c_p]),
     "dml_h2_bound_bn_bwd": (c_i, [c_p, c_p, c_i, c_i64, c_p, c_p, c_p]),
     "dml_bn_finalize_bound": (c_i, [c_p, c_i64, c_i, c_i, c_p, c_p, c_p, c_p, c_f, c_f, c_p, c_p, c_p, c_p,
                                     c_i64, c_f, c_p, c_p, c_p, c_p]),

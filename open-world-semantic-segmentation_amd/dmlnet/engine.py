@@ -908,6 +908,13 @@ class Plan:
                           res.amax.data_ptr() if res is not None else None, work.data_ptr())
             pl = (planes.data_ptr(), M * N, N, work.data_ptr() + 4096)
         only = direct and planes_only
+        if out is not None and out.root.t.dtype == torch.float16:
+            # `out` is a channel slice of a tensor that exists as fp16 planes ONLY (the decoder's concat buffer of an f16x2 training
+            # plan, _head_fwd): this BatchNorm writes its slice of the planes, scaled by the tensor's one scale (dml_h2_bound_bn_multi)
+            assert self.training and bn.training and drop is None and self.dtype == torch.float32 and N % 8 == 0
+            pp, pstride, punscale = self.h2_of(out, self.fwd)
+            pl = (pp, pstride, out.ld, punscale)
+            only = True
         # a residual operand that exists as planes only (the previous block's output, block_fwd): hi + lo, unscaled
         res_pl = (0, None)
         if res is not None and res.t.dtype == torch.float16:
@@ -1231,7 +1238,27 @@ class Plan:
             raise NotImplementedError("num_classes=%d: the distance-head kernels hold at most 32 embedding channels and 33 "
                                       "prototypes; the reference's drivers use 16 (main_embedding.py:336)" % K)
         cat2_c = _round_up(48 + 256, 32)                   # 304 -> 320: K tiles of 32 stay inside one tap
-        cat2 = self.new(B, low.H, low.W, cat2_c, zero=True)
+        # f16x2 training: the concat buffer exists as fp16 planes only.  Its two producers -- the low-level projection's BatchNorm and
+        # the bilinear resize of the ASPP projection -- write their channel slices of the planes themselves, with ONE scale from the
+        # larger of the two BatchNorms' bounds (known from gamma / beta / count alone: dml_h2_bound_bn_multi at the head of the
+        # forward); the amax + split passes of dml_h2_split over this 755 MB tensor (16 x 768 x 768) are gone.  DML_CAT_PLANES=0: off
+        cat_planes = (self.training and self.f32_split == 2 and self.dtype == torch.float32 and self.h2_direct_on
+                      and os.environ.get("DML_CAT_PLANES", "1") != "0" and head.project[1].training and head.aspp.project[1].training
+                      and not self.sync and self.planes_fit(B * low.H * low.W, cat2_c))
+        if cat_planes:
+            cat2 = self.h2_direct(B, low.H, low.W, cat2_c, fp32_too=False)
+            cat2.h2[0].zero_()                              # (the 16 pad channels stay zero: nobody writes them)
+            pdrop = float(head.aspp.project[3].p) if isinstance(head.aspp.project[3], nn.Dropout) else 0.0
+            rc = lambda n: float(np.float32(np.sqrt(np.float32(n * self.world))) * np.float32(1.0001))
+            tab = (_lib.H2BoundDesc * 2)(
+                _lib.H2BoundDesc(head.project[1].weight.data_ptr(), head.project[1].bias.data_ptr(), None, 48, rc(B * low.H * low.W), 1.0, 0),
+                _lib.H2BoundDesc(head.aspp.project[1].weight.data_ptr(), head.aspp.project[1].bias.data_ptr(), None, 256,
+                                 rc(B * out.H * out.W), 1.0 / (1.0 - pdrop) if pdrop < 1.0 else 1.0, 0))
+            self.cat_bound_table = torch.frombuffer(bytearray(bytes(tab)), dtype=torch.uint8).to(self.device)
+            self.keep.append(self.cat_bound_table)
+            self.call(self.fwd, lib.dml_h2_bound_bn_multi, self.cat_bound_table.data_ptr(), 2, cat2.h2[1].data_ptr())
+        else:
+            cat2 = self.new(B, low.H, low.W, cat2_c, zero=True)
         up_low = self.cbr(low, head.project[0], head.project[1], out=cat2.slice(0, 48))
         aspp = head.aspp
         cat1 = self.new(B, out.H, out.W, 5 * 256)
@@ -1284,8 +1311,13 @@ class Plan:
             self.fwd_forks.append([(marks[k], marks[k + 1]) for k in range(5)])
         uproj = self.cbr(cat1, aspp.project[0], aspp.project[1], drop=aspp.project[3])
         up_slice = cat2.slice(48, 256)
-        self.call(self.fwd, lib.dml_bilinear_fwd, uproj.z.ptr, up_slice.ptr, B, out.H, out.W, low.H, low.W, 256,
-                  uproj.z.ld, cat2.ld, self.dt, 0, 0)
+        if cat_planes:
+            pp, pstride, punscale = self.h2_of(up_slice, self.fwd)
+            self.call(self.fwd, lib.dml_bilinear_fwd_planes, uproj.z.ptr, pp, pstride, cat2.ld, punscale, B, out.H, out.W, low.H, low.W,
+                      256, uproj.z.ld)
+        else:
+            self.call(self.fwd, lib.dml_bilinear_fwd, uproj.z.ptr, up_slice.ptr, B, out.H, out.W, low.H, low.W, 256,
+                      uproj.z.ld, cat2.ld, self.dt, 0, 0)
         ucls = self.cbr(cat2, head.classifier[0], head.classifier[1])
         fin = head.classifier[3]
         fin_bias_ptr = fin.bias.data_ptr() if fin.bias is not None else None
