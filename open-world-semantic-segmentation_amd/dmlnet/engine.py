@@ -379,6 +379,7 @@ class Plan:
         # f16x2: data gradients of the stride-2 convolutions as stride-1 launches per pixel-parity class (conv_dgrad_s2_classes).
         # DML_S2_CLASSES=0: off (A/B, tests)
         self.s2_classes_on = os.environ.get("DML_S2_CLASSES", "1") != "0"
+        self.prep_overlap_on = os.environ.get("DML_PREP_OVERLAP", "1") != "0"      # refresh_weights (A/B)
         self.ds_grad_from_dz = os.environ.get("DML_DS_GRAD_FROM_DZ", "1") != "0"      # block_bwd (A/B)
         self.prep_gather = []          # dml_gather_taps argument lists: sub-filters of the transposed weight copies, refreshed with them
         self._bound_words, self._bound_used = None, 0
@@ -1160,7 +1161,12 @@ class Plan:
         blocks = []
         x = p0
         seq = [(li, blk) for li, layer in enumerate((bb.layer1, bb.layer2, bb.layer3, bb.layer4)) for blk in layer]
+        self.prep_cut = None
         for i, (li, blk) in enumerate(seq):
+            if li == 1 and self.prep_cut is None:
+                # everything from layer2 on reads weight copies that refresh_weights prepares on the side stream, under the stem and
+                # layer1 (Plan.refresh_weights, overlap): ops before this index only need the copies made so far
+                self.prep_cut = (len(self.fwd), len(self.prep), len(self.prep_h2))
             # the output as planes only: another block follows whose conv1 / downsample conv take planes, and it is neither `low`
             # (the decoder's 48-channel projection reads the fp32 tensor) nor `out` (global average pooling does)
             nxt = seq[i + 1] if i + 1 < len(seq) else None
@@ -1441,13 +1447,18 @@ class Plan:
         feeders.append(len(self.bwd) - 1)
 
     # ---- execution ---------------------------------------------------------------------------
-    def refresh_weights(self, stream):
+    def refresh_weights(self, stream, overlap=False):
+        """compute copies / fp16 planes of the weights after the masters changed.  overlap (training forward): the copies of layer2 and
+        everything behind it are made on the engine's side stream while the stem and layer1 run (their own few copies first, on the
+        caller's stream); run_forward waits for the side stream's event at Plan.prep_cut.  0.5 ms of launches that only depend on the
+        optimizer step leave the forward's critical path."""
         st = self.e.store
         key = (st.version, sum(p._version for p in st.params))
         if key == self.prepped_version:
             return
         for fn in self.pre_prep:
             fn()
+        self.prep_event = None
         if self.prep_table is None:
             self.prep_table = []
             for dt in sorted({e[7] for e in self.prep}):          # one table launch per storage type present in the plan
@@ -1457,20 +1468,40 @@ class Plan:
                     arr[i] = _lib.PrepDesc(src, w, wt or None, N, RS, Cm, Cp, w_tiled, wt_tiled)
                 raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
                 self.prep_table.append((raw.to(self.device), len(ent), dt))
-        for tab, n, dt in self.prep_table:
-            _lib.check(self.lib.dml_prep_weights(tab.data_ptr(), n, dt, stream), "dml_prep_weights")
-        for g in self.prep_gather:
-            _lib.check(self.lib.dml_gather_taps(*g, stream), "dml_gather_taps")
-        if self.prep_h2:
+        if self.prep_h2 and (self.prep_h2_table is None or self.prep_h2_table[1] != len(self.prep_h2)):
             # fp16 planes of every weight copy (f16x2): one table, two launches
-            if self.prep_h2_table is None or self.prep_h2_table[1] != len(self.prep_h2):
-                arr = (_lib.H2Desc * len(self.prep_h2))()
-                for i, (x, rows, Cc, ld, planes, pstride, ldp, layout, work, _) in enumerate(self.prep_h2):
-                    arr[i] = _lib.H2Desc(x, planes, work, rows, pstride, Cc, ld, ldp, layout)
-                raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
-                self.prep_h2_table = (raw.to(self.device), len(self.prep_h2))
-            _lib.check(self.lib.dml_h2_split_table(self.prep_h2_table[0].data_ptr(), self.prep_h2_table[1], stream),
-                       "dml_h2_split_table")
+            arr = (_lib.H2Desc * len(self.prep_h2))()
+            for i, (x, rows, Cc, ld, planes, pstride, ldp, layout, work, _) in enumerate(self.prep_h2):
+                arr[i] = _lib.H2Desc(x, planes, work, rows, pstride, Cc, ld, ldp, layout)
+            raw = torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8)
+            self.prep_h2_table = (raw.to(self.device), len(self.prep_h2))
+        cut = self.prep_cut if (overlap and self.training and self.prep_overlap_on and len(self.prep_table) == 1) else None
+        if cut is not None and 0 < cut[1] < self.prep_table[0][1] and self.prep_h2 and 0 < cut[2] < len(self.prep_h2):
+            # early part on the caller's stream, the rest on the side stream (which first picks up the caller's stream: the masters)
+            tab, n, dt = self.prep_table[0]
+            nA, hA = cut[1], cut[2]
+            main, side = torch.cuda.current_stream(self.device), self.e.side_stream(self.device)
+            side.wait_stream(main)
+            ss = side.cuda_stream
+            _lib.check(self.lib.dml_prep_weights(tab.data_ptr(), nA, dt, stream), "dml_prep_weights")
+            _lib.check(self.lib.dml_h2_split_table(self.prep_h2_table[0].data_ptr(), hA, stream), "dml_h2_split_table")
+            _lib.check(self.lib.dml_prep_weights(tab.data_ptr() + nA * C.sizeof(_lib.PrepDesc), n - nA, dt, ss), "dml_prep_weights")
+            for g in self.prep_gather:
+                _lib.check(self.lib.dml_gather_taps(*g, ss), "dml_gather_taps")
+            _lib.check(self.lib.dml_h2_split_table(self.prep_h2_table[0].data_ptr() + hA * C.sizeof(_lib.H2Desc),
+                                                   len(self.prep_h2) - hA, ss), "dml_h2_split_table")
+            if getattr(self, "_prep_ev", None) is None:
+                self._prep_ev = torch.cuda.Event()
+            self._prep_ev.record(side)
+            self.prep_event = self._prep_ev
+        else:
+            for tab, n, dt in self.prep_table:
+                _lib.check(self.lib.dml_prep_weights(tab.data_ptr(), n, dt, stream), "dml_prep_weights")
+            for g in self.prep_gather:
+                _lib.check(self.lib.dml_gather_taps(*g, stream), "dml_gather_taps")
+            if self.prep_h2:
+                _lib.check(self.lib.dml_h2_split_table(self.prep_h2_table[0].data_ptr(), self.prep_h2_table[1], stream),
+                           "dml_h2_split_table")
         self.prepped_version = key
 
     # ---- replay: one C call per contiguous run of ops (dml_plan_run) unless the engine is told to stay in Python
@@ -1632,6 +1663,14 @@ class Plan:
         branch is a grid of 128-256 workgroups, too small to fill the chip alone."""
         forks = getattr(self, "fwd_forks", None)
         if not forks:
+            ev = getattr(self, "prep_event", None)
+            if ev is not None and self.prep_cut is not None:
+                # (refresh_weights, overlap: the weight copies of layer2.. are being made on the side stream)
+                self._exec(self.fwd, stream, 0, self.prep_cut[0])
+                torch.cuda.current_stream(self.device).wait_event(ev)
+                self.prep_event = None
+                self._exec(self.fwd, stream, self.prep_cut[0], len(self.fwd))
+                return
             self._exec(self.fwd, stream)
             return
         main = torch.cuda.current_stream(self.device)
@@ -1770,7 +1809,7 @@ class Engine:
         x = x.contiguous().float()
         plan = self.plan_for(x, dtype, training)
         stream = torch.cuda.current_stream(x.device).cuda_stream
-        plan.refresh_weights(stream)
+        plan.refresh_weights(stream, overlap=training)
         B, _, H, W = x.shape
         logits, feats = [], []
         for rec in plan.heads:
