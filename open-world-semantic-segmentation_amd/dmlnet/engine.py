@@ -320,7 +320,7 @@ class HeadRec:
 
 class ConvUnit:
     __slots__ = ("conv", "bn", "x", "y", "z", "relu", "res", "w", "wt", "scale", "shift", "mean", "invstd",
-                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy", "mask", "frozen", "dtype")
+                 "Cp", "drop", "apply_args", "gscale_slots", "dz", "dy", "mask", "frozen", "dtype", "up")
 
 
 class Plan:
@@ -958,6 +958,7 @@ class Plan:
             only = False
             dy = self.new(u.y.B, u.y.H, u.y.W, N)
         u.dz, u.dy = dz, dy
+        u.up = None                    # (block_bwd sets it: the unit whose ReLU mask gates `dz` for this unit, unit_bwd's up_mask)
         coef = self.fbuf(4 * N)
         nblk = C.c_int(0)
         self.keep.append(nblk)
@@ -1107,6 +1108,7 @@ class Plan:
         if ud is not None:
             if ud_from_dz:
                 self.unit_bwd(ud, dz, up_mask=u3.mask)
+                ud.up = u3
             else:
                 self.unit_bwd(ud, self.grad_of(ud.z))
 

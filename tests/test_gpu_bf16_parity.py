@@ -267,6 +267,9 @@ def test_bf16_plan_every_unit_is_locally_exact(shape, seed, stage32, monkeypatch
         # ---- backward, from the stored dz / y / z
         dz = _nchw(_act(u.dz), u.z.B, u.z.H, u.z.W).double()
         g = dz * (z > 0) if u.relu else dz
+        if getattr(u, "up", None) is not None:
+            # the downsample branch reads the BLOCK output's gradient and applies that output's ReLU mask itself (Plan.block_bwd)
+            g = dz * (_nchw(_act(u.up.z), u.up.z.B, u.up.z.H, u.up.z.W) > 0)
         xhat = (y.double() - mu.double().view(sh)) * inv.double().view(sh)
         M = y.numel() // y.shape[1]
         dbeta, dgamma = g.sum((0, 2, 3)), (g * xhat).sum((0, 2, 3))
