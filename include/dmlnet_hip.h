@@ -157,7 +157,12 @@ typedef struct DmlConvDesc {
      * padding R - 1 / S - 1).  Any other kernel family returns DML_EUNSUPPORTED for such a descriptor. */
     int32_t sub_grid, sub_y, sub_x;
     int32_t pad_w_set, pad_w;
-    int32_t reserved_r6;
+    /* with bnr_* and an accumulating launch (accum = 1): the sums are taken over THIS launch's increment (the convolution result under
+     * the mask, before the old value is added) instead of over the stored total -- the BatchNorm-backward sums are linear in the
+     * gradient, so the producers of a gradient with several producers can each emit the sums of their own share into their own partial
+     * groups (the 1x1 stride-2 data gradient as a parity-class launch only visits a quarter of the pixels: the first producer writes
+     * the sums of its share over all pixels).  bnr_gmax still receives the maximum of the stored total. */
+    int32_t bnr_inc;
 } DmlConvDesc;
 
 #define DML_STAT_ROWS 64   /* rows of the GEMM covered by one statistics partial */

@@ -80,6 +80,7 @@ struct ConvArgs {
     // the pixels (b, 2 y2 + sub_y, 2 x2 + sub_x) of the B x 2 Ho x 2 Wo tensors y / res_dz / bnr_y / masks (ws_out_row)
     int pad_x;             // padding along the width (== pad unless DmlConvDesc::pad_w_set)
     int sub_grid, sub_y, sub_x;
+    int bnr_inc;           // fused BN-backward sums over the launch's increment, not the stored total (DmlConvDesc::bnr_inc)
 };
 
 // physical pixel row of row m of the launch in the epilogue's tensors (y, accumulate / identity operand, bnr_y, masks); a row beyond
@@ -1628,6 +1629,7 @@ __device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3],
             const uint32_t m = ws_out_row(a, (uint32_t)(mw0 + r));
             float4 o = *reinterpret_cast<const float4*>(stage + r * 256 + (((lane & 15) ^ (r & 15)) << 4));
             const uint32_t pkb = *reinterpret_cast<const uint8_t*>(mstage + lane + q * 64);
+            const float4 inc = o;          // (the convolution's own share of the gradient: DmlConvDesc.bnr_inc)
             if (HO) {
                 float4 t = make_float4(__uint_as_float(old[q][0]), __uint_as_float(old[q][1]), __uint_as_float(old[q][2]),
                                        __uint_as_float(old[q][3]));
@@ -1646,9 +1648,13 @@ __device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3],
                                               __uint_as_float(yv[q][3]));
                 const float g0 = (bits & 1u) ? o.x : 0.f, g1 = (bits & 2u) ? o.y : 0.f, g2 = (bits & 4u) ? o.z : 0.f,
                             g3 = (bits & 8u) ? o.w : 0.f;
-                r1.x += g0; r1.y += g1; r1.z += g2; r1.w += g3;
-                r2.x += g0 * (y4.x - mu.x) * is.x; r2.y += g1 * (y4.y - mu.y) * is.y;
-                r2.z += g2 * (y4.z - mu.z) * is.z; r2.w += g3 * (y4.w - mu.w) * is.w;
+                // (the sums over this launch's own share where the caller says so -- only an accumulating launch has another share)
+                const bool use_inc = HO && a.bnr_inc != 0;
+                const float s0 = use_inc ? ((bits & 1u) ? inc.x : 0.f) : g0, s1 = use_inc ? ((bits & 2u) ? inc.y : 0.f) : g1,
+                            s2 = use_inc ? ((bits & 4u) ? inc.z : 0.f) : g2, s3 = use_inc ? ((bits & 8u) ? inc.w : 0.f) : g3;
+                r1.x += s0; r1.y += s1; r1.z += s2; r1.w += s3;
+                r2.x += s0 * (y4.x - mu.x) * is.x; r2.y += s1 * (y4.y - mu.y) * is.y;
+                r2.z += s2 * (y4.z - mu.z) * is.z; r2.w += s3 * (y4.w - mu.w) * is.w;
                 gmx = max(max(gmx, __float_as_uint(g0) & 0x7fffffffu), max(__float_as_uint(g1) & 0x7fffffffu,
                           max(__float_as_uint(g2) & 0x7fffffffu, __float_as_uint(g3) & 0x7fffffffu)));
                 asm volatile("" : "+v"(gmx), "+v"(r1.x), "+v"(r2.x));      // (here, not at the end of the sub-tile with 48 values kept live for it)
@@ -3982,6 +3988,7 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
         a.post_ldres = d->post_ldres; a.post_relu = d->post_relu;
     }
     a.bnr_gmax = nullptr;
+    bool bnr_inc_req = false;
     if (d->bnr_partials) {
         // fused BN-backward reduce: data-gradient mode; bf16 result stored as 16-byte vectors, 8-channel mask bytes -- or fp32 on the
         // two-plane kernel (checked below, once the launch is described), 4-channel mask bytes
@@ -4002,13 +4009,20 @@ extern "C" int dml_conv_igemm(const DmlConvDesc* d, void* stream) {
         }
         a.bnr_y = d->bnr_y; a.bnr_mask = d->bnr_mask; a.bnr_mean = d->bnr_mean; a.bnr_invstd = d->bnr_invstd;
         a.bnr_partials = d->bnr_partials; a.bnr_ldy = d->bnr_ldy; a.bnr_relu = d->bnr_relu;
+        bnr_inc_req = d->bnr_inc != 0;
     }
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
-    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_x = d->pad; a.sub_grid = 0; a.sub_y = a.sub_x = 0;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_x = d->pad; a.sub_grid = 0; a.sub_y = a.sub_x = 0; a.bnr_inc = 0;
     a.M = d->B * d->Ho * d->Wo;
     a.Ktot = d->R * d->S * d->C;
     a.y_f32 = d->y_f32; a.accum = d->accum;
+    a.bnr_inc = 0;
+    if (bnr_inc_req) {
+        // (only the two-plane row epilogue with both operand sets knows the increment: an accumulating fp32 launch)
+        if (!d->accum || d->dtype != DML_F32 || d->res_dz) return DML_EUNSUPPORTED;
+        a.bnr_inc = 1;
+    }
     if (d->pad_w_set) a.pad_x = d->pad_w;
     if (d->sub_grid) {
         // a parity class of a stride-2 data gradient: stride-1 geometry on dY's grid, the two-plane kernel's row epilogues only
@@ -4043,7 +4057,7 @@ extern "C" int dml_debug_conv_ablate(const DmlConvDesc* d, int abl, float* dbg, 
     a.x = d->x; a.w = d->w; a.y = d->y; a.bias = nullptr; a.stats = d->stats;
     a.B = d->B; a.Hi = d->Hi; a.Wi = d->Wi; a.C = d->C; a.ldx = d->ldx;
     a.Ho = d->Ho; a.Wo = d->Wo; a.N = d->N; a.ldy = d->ldy;
-    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_x = d->pad; a.sub_grid = 0; a.sub_y = a.sub_x = 0;
+    a.R = d->R; a.S = d->S; a.stride = d->stride; a.dil = d->dil; a.pad = d->pad; a.pad_x = d->pad; a.sub_grid = 0; a.sub_y = a.sub_x = 0; a.bnr_inc = 0;
     a.M = d->B * d->Ho * d->Wo; a.Ktot = d->R * d->S * d->C; a.y_f32 = 0; a.accum = 0;
     a.nblk_m = (a.M + 127) / 128; a.nblk_n = (a.N + 127) / 128;
     a.div_wo = make_fastdiv((uint32_t)d->Wo); a.div_howo = make_fastdiv((uint32_t)(d->Ho * d->Wo));

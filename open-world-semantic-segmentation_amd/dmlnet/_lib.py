@@ -48,7 +48,7 @@ class ConvDesc(C.Structure):
                 ("x_plane_stride", C.c_int64), ("w_plane_stride", C.c_int64), ("bnr_gmax", c_p),
                 # mode 1, f32_split == 2: one parity class of a stride-2 data gradient as a stride-1 launch (see the header)
                 ("sub_grid", C.c_int32), ("sub_y", C.c_int32), ("sub_x", C.c_int32),
-                ("pad_w_set", C.c_int32), ("pad_w", C.c_int32), ("reserved_r6", C.c_int32)]
+                ("pad_w_set", C.c_int32), ("pad_w", C.c_int32), ("bnr_inc", C.c_int32)]
 
 
 PLAN_MAX_ARGS = 24

@@ -1631,6 +1631,39 @@ def test_stride2_data_gradient_by_parity_class_equals_the_direct_launch(lib, cas
         if bnr and k == 3:                 # (1x1: the class launch visits a quarter of the rows -- the plan does not fuse the sums there)
             assert ga == gb
             assert (pa - pb).abs().max().item() <= 1e-5 * pa.abs().max().item()
+    if k == 1:
+        # DmlConvDesc.bnr_inc: the class launch's sums over its INCREMENT + the sums of the earlier producers' share (here: `old`, in
+        # fp64 on the host) = the sums of the stored total, which the direct launch (all pixels, accumulate + fused sums) computes
+        a, pa, ga, _ = run(False, 1, True)
+        rs = [0]
+        sub = torch.empty(Cin * Cout, device="cuda")
+        chk(lib.dml_gather_taps(wt.data_ptr(), sub.data_ptr(), Cin, 1, Cout, 1, 0, 0, 0, 0, st()))
+        wp, ww = h2_planes(lib, sub.view(Cin, -1), 1)
+        dx = old.clone()
+        part = torch.zeros(((B * Ho * Wo + 47) // 48) * Cin * 2, device="cuda")
+        gmx = torch.zeros(1025, device="cuda")
+        d = ConvDesc(x=gy.data_ptr(), w=sub.data_ptr(), y=dx.data_ptr(), bias=None, stats=None, B=B, Hi=Ho, Wi=Wo, C=Cout, ldx=Cout,
+                     Ho=Ho, Wo=Wo, N=Cin, ldy=Cin, R=1, S=1, stride=1, dil=1, pad=0, dtype=0, y_f32=0, accum=1, mode=1)
+        d.pad_w_set, d.pad_w, d.sub_grid, d.sub_y, d.sub_x, d.f32_split, d.ws_min_tiles, d.bnr_inc = 1, 0, 1, 0, 0, 2, 1, 1
+        d.x_planes, d.x_unscale, d.x_plane_stride = yp.data_ptr(), yw.data_ptr() + 4096, yp.shape[1]
+        d.w_planes, d.w_unscale, d.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
+        d.bnr_y, d.bnr_mask, d.bnr_mean, d.bnr_invstd = ybn.data_ptr(), mask.data_ptr(), mean.data_ptr(), inv.data_ptr()
+        d.bnr_partials, d.bnr_ldy, d.bnr_relu, d.bnr_gmax = part.data_ptr(), Cin, 1, gmx.data_ptr()
+        chk(lib.dml_conv_igemm(C.byref(d), st()))
+        torch.cuda.synchronize()
+        assert torch.equal(dx, a)
+        bits = (mask.view(M, Cin // 4, 1) >> torch.arange(4, device="cuda", dtype=torch.uint8).view(1, 1, 4)) & 1
+        g_old = old.view(M, Cin).double() * bits.reshape(M, Cin).double()
+        xhat = (ybn.view(M, Cin).double() - mean.double()) * inv.double()
+        p_old = torch.stack([g_old.sum(0), (g_old * xhat).sum(0)], 1)
+        p_inc = part.view(-1, Cin, 2).double().sum(0)
+        err = ((p_old + p_inc) - pa).abs().max().item() / pa.abs().max().item()
+        print("%s: sums of the increment + sums of the old share vs sums of the total: rel %.2e" % (name, err))
+        assert err <= 1e-5
+        # max |g| is still taken from the stored total of the rows the launch visits
+        tot_even = (a.view(B, Hh, Ww, Cin)[:, ::2, ::2].reshape(-1, Cin) *
+                    bits.reshape(B, Hh, Ww, Cin)[:, ::2, ::2].reshape(-1, Cin).float()).abs().max().item()
+        assert abs(float(gmx[:1024].max()) - tot_even) <= 1e-6 * tot_even
     # shapes / modes the mapping does not exist for are refused, never mis-executed
     sub = torch.empty(Cin * Cout, device="cuda")
     d = ConvDesc(x=gy.data_ptr(), w=sub.data_ptr(), y=old.data_ptr(), bias=None, stats=None, B=B, Hi=Ho, Wi=Wo, C=Cout, ldx=Cout, Ho=Ho,
