@@ -726,10 +726,11 @@ class Plan:
         if len(descs) == 4:
             self.last_dgrad[gx.ptr] = descs           # the four classes cover the tensor: candidates for the fused BN-backward sums
         elif (len(descs) == 1 and accum and prev is not None and not isinstance(prev, list) and not prev.sub_grid
-              and prev.y == gx.ptr and prev.N == x.C and prev.ldy == gx.ld and prev.f32_split == 2 and not prev.accum and not prev.res_dz):
+              and os.environ.get("DML_BNR_INC", "1") != "0"
+              and prev.y == gx.ptr and prev.N == x.C and prev.ldy == gx.ld and prev.f32_split == 2 and not prev.res_dz):
             # 1x1: the class launch only visits the even pixels, but the BatchNorm-backward sums are linear in the gradient -- the
-            # first producer (a whole-tensor data gradient) emits the sums of ITS share over all pixels, this launch those of its
-            # increment over its own (DmlConvDesc.bnr_inc); unit_bwd hands both their partial groups
+            # producer before it (a whole-tensor data gradient) emits the sums of the total stored SO FAR over all pixels, this launch those
+            # of its increment over its own (DmlConvDesc.bnr_inc); unit_bwd hands both their partial groups
             descs[0].bnr_inc = 1
             self.last_dgrad[gx.ptr] = [prev, descs[0]]
 
