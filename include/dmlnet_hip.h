@@ -170,7 +170,8 @@ typedef struct DmlConvDesc {
 int dml_conv_igemm(const DmlConvDesc* d, void* stream);
 /* Rows of the GEMM covered by one partial of `stats` / `bnr_partials` for THIS launch: 48 where the wave-specialised kernel
  * (one persistent workgroup per CU on 144-row tiles: bf16, tile-major weights, N % 128 == 0, enough tiles to fill the chip)
- * takes it, DML_STAT_ROWS otherwise.  Size the partial buffers as ceil(M / rows) * N * 2 floats, pass `rows` to
+ * takes it -- 144 for a two-plane (f32_split == 2) FORWARD launch on 144-row wave tiles, whose statistics are taken per wave tile
+ * (round 6) -- DML_STAT_ROWS otherwise.  Size the partial buffers as ceil(M / rows) * N * 2 floats, pass `rows` to
  * dml_bn_finalize / dml_bn_moments and ceil(M / rows) as `nblocks` to dml_bn_bwd_finalize / dml_bn_bwd_sums. */
 int dml_conv_stat_rows(const DmlConvDesc* desc);
 

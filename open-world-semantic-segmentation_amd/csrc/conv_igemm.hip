@@ -1340,13 +1340,73 @@ __global__ __launch_bounds__(BM / TMW * 128) __attribute__((amdgpu_waves_per_eu(
 // of the accumulate / residual operands -- covers four pixel rows x 256 contiguous bytes: 5-6 us (profiles/r04_h2_epilogue.txt).
 // BatchNorm statistics come from the accumulators as before (conv_epilogue, STATS_ONLY); accumulate and the stores happen on the
 // row side (launches with a bias or the inference epilogue post_* keep conv_epilogue).  `stage`: this wave's own 12 KB.
+// BatchNorm partial statistics of a WHOLE 144 x 64 wave tile of the two-plane forward kernel: (sum, M2 about the tile mean) per channel over
+// its 144 rows, from the accumulators, before the row epilogue stores them sub-tile by sub-tile.  Round 6: with 48-row groups the
+// cross-lane reductions (a DPP row sum per channel and sub-tile, twice) made the statistics 15-28 % of the short-K 1x1 forward
+// launches (tools/bench_h2.py with and without `stats`: 1x1 256 -> 1024 at 48 x 48 94.9 vs 80.1 us, 64 -> 256 at 192 x 192 177.6 vs
+// 128.4); per wave tile they are a third as many, and the finalize kernels fold a third of the partial rows.
+// acc3[h][i][jj] = rows mw0 + 48 h + 16 jj + (lane & 15), channels nw0 + frag_chan<4>(i, lane >> 4) .. + 3
+template <int NT, int NS>
+__device__ __forceinline__ void ws_tile_stats(const f32x4 (&acc3)[NS][NT][3], const ConvArgs& a, const int mw0, const int nw0,
+                                              const int lr, const int lq) {
+    static_assert(NT == 4, "64-channel wave tile");
+    constexpr int TM = NS * 48;
+    const int cnt = min(TM, max(0, a.M - mw0));
+    if (cnt <= 0) return;
+    const float inv = 1.0f / (float)cnt;
+    float* sg = a.stats + (int64_t)(mw0 / TM) * a.N * 2;
+    float S[NT][4], Q[NT][4];
+#pragma unroll
+    for (int i = 0; i < NT; ++i) {
+        float s[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NS; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const bool v = (mw0 + h * 48 + jj * 16 + lr) < a.M;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) s[q] += v ? acc3[h][i][jj][q] : 0.f;
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) s[q] = row16_sum(s[q]);
+        float m2[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int h = 0; h < NS; ++h)
+#pragma unroll
+            for (int jj = 0; jj < 3; ++jj) {
+                const bool v = (mw0 + h * 48 + jj * 16 + lr) < a.M;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float dlt = acc3[h][i][jj][q] - s[q] * inv;
+                    m2[q] += v ? dlt * dlt : 0.f;
+                }
+            }
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            S[i][q] = s[q];
+            Q[i][q] = row16_sum(m2[q]);
+        }
+    }
+    // one store instruction per wave: lane (lq, lr = 2 i + h) writes the (sum, M2) pairs of channels 2 h, 2 h + 1 of tile i (conv_epilogue)
+    if (lr < 2 * NT && nw0 + NT * 16 <= a.N) {
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+#pragma unroll
+        for (int i = 0; i < NT; ++i)
+#pragma unroll
+            for (int h = 0; h < 2; ++h)
+                if (lr == 2 * i + h) { v0 = S[i][2 * h]; v1 = Q[i][2 * h]; v2 = S[i][2 * h + 1]; v3 = Q[i][2 * h + 1]; }
+        const int n = nw0 + frag_chan<NT>(lr >> 1, lq) + (lr & 1) * 2;
+        st16f(sg + (int64_t)n * 2, v0, v1, v2, v3, (a.nt_out & 2) != 0);
+    }
+}
+
 constexpr int WS_STAT_ROWS_C = 48;             // (= WS_STAT_ROWS, declared below)
 template <int NT, int MODE, bool OPS = true>      // OPS = false: launches with epilogue operands go to conv_epilogue_rows_ops
 __device__ __forceinline__ void conv_epilogue_rows(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
-                                                   const int lane, char* stage, char* mstage) {
+                                                   const int lane, char* stage, char* mstage, const bool do_stats = true) {
     static_assert(NT == 4, "64-channel wave tile");
     const int lr = lane & 15, lq = lane >> 4;
-    if (MODE == 0 && a.stats != nullptr) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
+    if (MODE == 0 && a.stats != nullptr && do_stats) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
 #pragma unroll
     for (int i = 0; i < NT; ++i)
 #pragma unroll
@@ -1698,10 +1758,10 @@ __device__ __forceinline__ void conv_epilogue_rows_ops(f32x4 (&acc3)[NS][NT][3],
 // those epilogues are bound by exactly that (+2 % on the step's data gradients); both versions in one kernel spill 300 bytes per lane.
 template <int NT, int MODE>
 __device__ __forceinline__ void conv_epilogue_rows8(f32x4 (&acc)[NT][3], const ConvArgs& a, const int mw0, const int nw0,
-                                                    const int lane, char* stage) {
+                                                    const int lane, char* stage, const bool do_stats = true) {
     static_assert(NT == 4 && MODE == 0, "64-channel wave tile, forward launches");
     const int lr = lane & 15, lq = lane >> 4;
-    if (a.stats != nullptr) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
+    if (a.stats != nullptr && do_stats) conv_epilogue<float, NT, 3, MODE, false, true>(acc, a, mw0, nw0, lr, lq);
     const int rr = lane >> 3, cc = lane & 7;                     // row side: row within 8, 16-byte chunk within the 128-byte half row
     float* const yb = static_cast<float*>(a.y);
     // chunk q = (fragment j = q >> 1, channel half = q & 1): tiles i = 2 half, 2 half + 1 of fragment j
@@ -2317,6 +2377,11 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& a, const uint32_t x
         // between (2 x 96 register moves): three inlined copies -- what a compile-time sub-tile index costs; a run-time index into
         // acc would send all of it through scratch memory -- made these kernels 10-19 K instructions, more than the instruction
         // cache two CUs share.
+        // forward, 144-row wave tiles: the BatchNorm statistics of the whole wave tile at once (ws_tile_stats)
+        constexpr bool TILE_STATS = PL == 2 && MODE == 0 && MT == 9;
+        if constexpr (TILE_STATS) {
+            if (a.stats != nullptr && !(DML_WS_ABL & 8)) ws_tile_stats<NT, MT / 3>(acc3, a, blk_m * BM + wm * (16 * MT), blk_n * BN + wn * 64, lr, lq);
+        }
         if constexpr (EPI != 0 && !(DML_WS_ABL & 8))
             conv_epilogue_rows_ops<NT, MT / 3, (EPI & 1) != 0, (EPI & 2) != 0>(
                 acc3, a, blk_m * BM + wm * (16 * MT), blk_n * BN + wn * 64, lane, rows_stage,
@@ -2328,9 +2393,10 @@ __device__ __forceinline__ void conv_ws_body(const ConvArgs& a, const uint32_t x
             else if (MODE == 0 && (a.bias != nullptr || a.post_scale != nullptr)) {
                 conv_epilogue<float, NT, 3, MODE, false>(acc3[0], a, mw0, nw0, lr, lq);      // (inference epilogue, bias: scattered stores)
             } else if (PRIV_STAGE) {
-                if constexpr (PRIV_STAGE) conv_epilogue_rows8<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage);
+                if constexpr (PRIV_STAGE) conv_epilogue_rows8<NT, MODE>(acc3[0], a, mw0, nw0, lane, rows_stage, !TILE_STATS);
             } else {
-                conv_epilogue_rows<NT, MODE, !EPI_OPS>(acc3[0], a, mw0, nw0, lane, rows_stage, smem + NST * SB + 64 + wave * MASK_STAGE);
+                conv_epilogue_rows<NT, MODE, !EPI_OPS>(acc3[0], a, mw0, nw0, lane, rows_stage, smem + NST * SB + 64 + wave * MASK_STAGE,
+                                                       !TILE_STATS);
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");      // its reads of the staging area, before the next group's writes
             }
             if constexpr (MT == 9) {
@@ -2387,6 +2453,18 @@ static bool conv_ws_eligible(const ConvArgs& a, const int64_t xb, const int64_t 
     const int bn = (a.N % 256) == 0 ? 256 : 128, bm = (a.N % 256) == 0 ? 144 : 288;
     const int64_t ntiles = ((int64_t)a.M + bm - 1) / bm * (a.N / bn);
     return ntiles >= (a.ws_min_tiles > 0 ? a.ws_min_tiles : 192);
+}
+// two planes, forward: 48 x 256 tiles instead of 144 x 256 for launches that leave most of the chip empty (launch_conv; also decides
+// the rows per statistics partial: dml_conv_stat_rows)
+static bool ws_planes_short(const ConvArgs& a, const int mode) {
+    static const int short_on = getenv("DML_WS_SHORT") ? atoi(getenv("DML_WS_SHORT")) : 1;
+    return mode == 0 && short_on != 0 && (a.N % 256) == 0 && ((a.M + 143) / 144) * (a.N / 256) * 2 <= 256;
+}
+// rows of the GEMM per BatchNorm statistics partial of a two-plane FORWARD launch: the whole 144-row wave tile (ws_tile_stats) except on
+// the 48-row wave tiles (64 output channels, short tiles)
+static int ws_planes_stat_rows(const ConvArgs& a, const int mode) {
+    if (mode != 0) return 48;
+    return (a.N == 64 || ws_planes_short(a, mode)) ? 48 : 144;
 }
 // the same kernel on two fp16 planes per operand (fp32 tensors, f32_split == 2): every shape it can address -- the alternative
 // is the three-term split kernel at a third of its rate
@@ -3797,8 +3875,7 @@ int launch_conv(const ConvArgs& base, hipStream_t st) {
             // Forward launches that leave most of the chip empty on 144-row tiles (batch-1 inference at 1024 x 2048: 57 row blocks on
             // layer3 / layer4 / ASPP; the small maps of the tests): 48 x 256 tiles -- three times the workgroups, each with a third
             // of the MFMAs per K step behind the same weight pieces.  (Round 6; 1024 x 2048 batch 1: see profiles/r06_infer_short_tiles.txt)
-            static const int short_on = getenv("DML_WS_SHORT") ? atoi(getenv("DML_WS_SHORT")) : 1;
-            const bool shortm = MODE == 0 && short_on != 0 && wide && ((a.M + 143) / 144) * (a.N / 256) * 2 <= CUS;
+            const bool shortm = ws_planes_short(a, MODE);
             const int bm = wide ? (shortm ? 48 : 144) : (n64 ? 192 : 288);
             a.nblk_m = (a.M + bm - 1) / bm;
             a.nblk_n = wide ? a.N / 256 : (n64 ? 1 : (a.N + 127) / 128);      // (a last 128-wide block may be half empty: zero rows, no stores)
@@ -3906,8 +3983,8 @@ extern "C" int dml_conv_stat_rows(const DmlConvDesc* d) {
         a.f32_split = d->f32_split; a.x_planes = d->x_planes; a.w_planes = d->w_planes;
         a.x_unscale = d->x_unscale; a.w_unscale = d->w_unscale;
         a.x_plane_bytes = (uint32_t)(d->x_plane_stride * 2); a.w_plane_bytes = (uint32_t)(d->w_plane_stride * 2);
-        return (d->x_plane_stride < (1ll << 30) && d->w_plane_stride < (1ll << 30) && conv_ws_planes_eligible(a, d->mode)) ? WS_STAT_ROWS
-                                                                                                                   : DML_STAT_ROWS;
+        return (d->x_plane_stride < (1ll << 30) && d->w_plane_stride < (1ll << 30) && conv_ws_planes_eligible(a, d->mode))
+                   ? ws_planes_stat_rows(a, d->mode) : DML_STAT_ROWS;
     }
     if (d->dtype != DML_BF16 || !d->w_tiled) return DML_STAT_ROWS;
     const int64_t xb = ((int64_t)(d->B * d->Hi) * d->Wi - 1) * d->ldx * 2 + (int64_t)d->C * 2;

@@ -1398,7 +1398,7 @@ def test_two_plane_forward_with_accumulate_falls_back_and_accumulates(lib):
     ref = y0.double() + torch.einsum("bhwc,nc->bhwn", x.double(), w.view(Cout, Cin).double())
     assert (y.double() - ref).abs().max().item() <= 2e-6 * ref.abs().max().item()
     d.accum = 0
-    assert lib.dml_conv_stat_rows(C.byref(d)) == 48
+    assert lib.dml_conv_stat_rows(C.byref(d)) == 144             # (forward on 144-row wave tiles: one statistics partial per wave tile)
 
 
 def h2_planes(lib, t2d, layout=0, amax=None):
@@ -1469,7 +1469,7 @@ def test_h2_split_table_equals_the_single_tensor_calls(lib):
 
 H2_CASES = [("h2_1x1", 2, 24, 20, 64, 128, 1, 1, 1), ("h2_3x3", 2, 19, 23, 64, 256, 3, 1, 1), ("h2_3x3_d2", 2, 16, 16, 128, 256, 3, 1, 2),
             ("h2_3x3_s2", 2, 22, 18, 128, 128, 3, 2, 1), ("h2_rows", 3, 40, 40, 256, 256, 3, 1, 1), ("h2_1x1_n384", 2, 13, 29, 96, 384, 1, 1, 1),
-            ("h2_3x3_n64", 2, 21, 17, 64, 64, 3, 1, 1),
+            ("h2_3x3_n64", 2, 21, 17, 64, 64, 3, 1, 1), ("h2_1x1_tile_stats", 5, 64, 61, 64, 256, 1, 1, 1),
             # K order of the two-plane kernel (64-channel groups outermost, taps inside): a last group of 32 channels (C = 96), five
             # groups (C = 320); three column blocks, the last one half empty, walked fastest (N = 320: forward of the first case and
             # data gradient of the second, the shape of the decoder's 3x3)
@@ -1517,7 +1517,10 @@ def test_conv_f16_two_plane_split_is_fp32_accurate(lib, case):
                 desc.x_planes, desc.x_unscale, desc.x_plane_stride = ap.data_ptr(), aw.data_ptr() + 4096, ap.shape[1]
                 desc.w_planes, desc.w_unscale, desc.w_plane_stride = wp.data_ptr(), ww.data_ptr() + 4096, wp.shape[1]
         rows = lib.dml_conv_stat_rows(C.byref(d))
-        assert rows == (48 if (split and Cout % 64 == 0) else 64)      # (64 output channels: the 288 x 128 tile, half of it empty)
+        # two-plane forward: one partial per 144-row wave tile -- 48 rows on the 48-row wave tiles (64 output channels; 48 x 256 tiles of
+        # launches with at most 128 tiles of 144 x 256)
+        short = Cout % 256 == 0 and ((M + 143) // 144) * (Cout // 256) * 2 <= 256
+        assert rows == ((48 if (Cout == 64 or short) else 144) if (split and Cout % 64 == 0) else 64)
         stats = torch.zeros((M + rows - 1) // rows * Cout * 2, device="cuda")
         d.stats = stats.data_ptr()
         chk(lib.dml_conv_igemm(C.byref(d), st()))
