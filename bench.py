@@ -332,16 +332,18 @@ CLASS_COLS = ["kind", "conv (kxk Cin->Cout @map)", "launches", "ms", "own_bound"
 
 
 def _time_launches(fn, n=20, warm=3):
-    """mean duration of `fn` (one kernel launch on torch's current stream) from a HIP event pair on that stream"""
+    """average duration of `fn` (one kernel launch on torch's current stream): a HIP event pair on that stream around EVERY launch,
+    mean of the n durations -- what rocprofv3's kernel trace reports as the kernel's average (one pair around the whole batch measures
+    the batch's throughput: consecutive launches overlap their ramp-up / drain, 5-12 % less per launch on some boxes)"""
     for _ in range(warm):
         fn()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record()
-    for _ in range(n):
+    pairs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(n)]
+    for e0, e1 in pairs:
+        e0.record()
         fn()
-    e1.record()
+        e1.record()
     torch.cuda.synchronize()
-    return e0.elapsed_time(e1) * 1e-3 / n
+    return sum(e0.elapsed_time(e1) for e0, e1 in pairs) * 1e-3 / n
 
 
 def bench_distance_kernel(batch, size, device):
